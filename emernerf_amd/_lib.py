@@ -1,0 +1,96 @@
+"""ctypes binding of libemernerf_hip.so -- the C-ABI boundary declared in include/emernerf_hip.h.
+
+There is NO fallback: if the shared library is missing or a symbol does not resolve, importing the
+product path raises.  A CPU/PyTorch fallback would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libemernerf_hip.so")
+EMER_MAX_LEVELS = 32
+
+F32, F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TRUNC_EXP = 0, 1, 2, 3
+STOT_TYPES = {"uniform": 0, "uniform_lindisp": 1, "lindisp": 2}
+
+
+class GridDesc(ctypes.Structure):
+    """struct emer_grid_desc (include/emernerf_hip.h)."""
+    _fields_ = [
+        ("n_dims", c_uint32), ("n_levels", c_uint32), ("n_features", c_uint32),
+        ("log2_hashmap_size", c_uint32), ("base_resolution", c_uint32), ("per_level_scale", c_float),
+        ("scale", c_float * EMER_MAX_LEVELS), ("res", c_uint32 * EMER_MAX_LEVELS),
+        ("size", c_uint32 * EMER_MAX_LEVELS), ("offset", c_uint32 * EMER_MAX_LEVELS),
+        ("hashed", c_uint32 * EMER_MAX_LEVELS), ("n_entries", c_uint32),
+    ]
+
+
+class EmerError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_GP = ctypes.POINTER(GridDesc)
+
+# name -> argtypes; every entry must be declared in include/emernerf_hip.h (tests check both ways)
+SIGNATURES = {
+    "emer_grid_desc_init": [_GP, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_float],
+    "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, c_int64, _P],
+    "emer_hashgrid_bwd_params": [_GP, _P, _P, c_int64, c_int64, _P, c_int, c_int64, _P],
+    "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
+    "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
+    "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
+    "emer_contract_bwd": [_P, _P, c_int, _P, _P, c_int64, _P],
+    "emer_ray_points": [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int64, c_int32, _P],
+    "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_float, c_float, c_int, _P],
+    "emer_stot": [_P, c_int64, c_float, c_float, c_int, _P, _P],
+    "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P],
+    "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
+    "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
+    "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
+    "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P],
+    "emer_linear_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32,
+                        c_int32, c_int, _P],
+    "emer_dir_encode": [_P, _P, c_int64, c_int32, _P],
+    "emer_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, _P],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EmerError(
+            f"{LIB_PATH} not found. Build it with `python -m emernerf_amd._build` (hipcc, gfx950). "
+            "emernerf_amd has no CPU/PyTorch fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.emer_last_error.restype = ctypes.c_char_p
+    lib.emer_version.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EmerError(f"{name} failed (rc={rc}): {lib.emer_last_error().decode()}")
+
+
+def make_grid_desc(n_dims, n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale) -> GridDesc:
+    d = GridDesc()
+    call("emer_grid_desc_init", ctypes.byref(d), n_dims, n_levels, n_features, log2_hashmap_size,
+         base_resolution, per_level_scale)
+    return d

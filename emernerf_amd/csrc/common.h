@@ -1,0 +1,63 @@
+// Shared helpers for the gfx950 kernels of libemernerf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/emernerf_hip.h"
+
+namespace emer {
+
+constexpr int kWave = 64;  // CDNA wavefront width (hard-coded on purpose: gfx950 only)
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Every launch goes through this so a failed launch surfaces as EMER_E_LAUNCH, not silence.
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return EMER_E_LAUNCH;
+    }
+    return EMER_OK;
+}
+
+#define EMER_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::emer::set_error(__VA_ARGS__); \
+            return EMER_E_INVALID;         \
+        }                                  \
+    } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave-level scans (DPP-backed __shfl; no LDS) ------------------------------------------
+__device__ __forceinline__ float wave_inclusive_sum(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        float o = __shfl_up(v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// inclusive suffix sum: lane i receives sum_{j >= i} v_j
+__device__ __forceinline__ float wave_inclusive_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        float o = __shfl_down(v, off, kWave);
+        if (lane + off < kWave) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+}  // namespace emer

@@ -1,0 +1,284 @@
+// Alpha-compositing volume renderer for gfx950.
+//
+// Replaces nerfacc's dense-tensor volrend as EmerNeRF calls it (render_transmittance_from_density,
+// render_weight_from_density, accumulate_along_rays: radiance_fields/render_utils.py:35-43,73-77,
+// 103-115,159-282; third_party/nerfacc_prop_net.py:165-168; loss/base.py:454-460).  Semantics:
+// SURVEY.md Appendix A.2; CPU restatement: oracle/emer_oracle.c (orc_render_weights, orc_accumulate).
+//
+// Mapping: one 64-lane wavefront owns one ray; lane i holds sample 64*c + i of chunk c.  The
+// exclusive cumsum of sigma*dt (and the reverse-mode suffix sums) are wave scans built from DPP
+// shuffles -- no LDS traffic, no atomics, fully coalesced (R,S) loads/stores.  S is unbounded
+// (chunks of 64 with a carried prefix); at the metric shape S=128 a ray is exactly two chunks.
+#include "common.h"
+
+namespace emer {
+
+constexpr int kRaysPerBlockC = 4;
+
+__global__ __launch_bounds__(256) void render_weights_fwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                                 const float *__restrict__ sigma, int64_t R, int32_t S,
+                                                                 float *__restrict__ weights, float *__restrict__ trans,
+                                                                 float *__restrict__ alphas, float *__restrict__ cdfs,
+                                                                 float *__restrict__ ray_stats) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    float carry = 0.0f;          // sum of sigma*dt over previous chunks
+    float wsum = 0.0f, wmid = 0.0f, wcarry = 0.0f;
+    float median = 0.0f;
+    bool found = false;
+    float last_mid = 0.0f;
+    for (int32_t base = 0; base < S; base += kWave) {
+        const int32_t s = base + lane;
+        const bool ok = s < S;
+        const int64_t i = r * S + s;
+        const float a = ok ? ts[i] : 0.0f, b = ok ? te[i] : 0.0f, sg = ok ? sigma[i] : 0.0f;
+        const float sdt = sg * (b - a);
+        const float incl = wave_inclusive_sum(sdt, lane);
+        const float excl = carry + (incl - sdt);
+        const float T = expf(-excl);
+        const float al = 1.0f - expf(-sdt);
+        const float w = ok ? T * al : 0.0f;
+        if (ok) {
+            if (weights) weights[i] = w;
+            if (trans) trans[i] = T;
+            if (alphas) alphas[i] = al;
+            if (cdfs) cdfs[r * (int64_t)(S + 1) + s] = 1.0f - T;
+        }
+        carry += __shfl(incl, kWave - 1, kWave);
+        if (ray_stats) {
+            const float mid = (a + b) / 2.0f;
+            // median depth: first sample whose inclusive cumsum(w) reaches 0.5 (render_utils.py:107-115)
+            const float cw = wcarry + wave_inclusive_sum(w, lane);
+            const unsigned long long hit = __ballot(ok && cw >= 0.5f);
+            if (!found && hit) {
+                const int first = __ffsll((long long)hit) - 1;
+                median = __shfl(mid, first, kWave);
+                found = true;
+            }
+            const int last_lane = (S - 1 - base) < (kWave - 1) ? (S - 1 - base) : (kWave - 1);
+            last_mid = __shfl(mid, last_lane, kWave);
+            wcarry = __shfl(cw, kWave - 1, kWave);
+            wsum += w;
+            wmid += w * mid;
+        }
+    }
+    if (cdfs && lane == 0) cdfs[r * (int64_t)(S + 1) + S] = 1.0f;  // 1 - [T, 0]
+    if (ray_stats) {
+        wsum = wave_sum(wsum);
+        wmid = wave_sum(wmid);
+        if (lane == 0) {
+            float4 st = make_float4(wsum, wmid, found ? median : last_mid, 0.0f);
+            *reinterpret_cast<float4 *>(ray_stats + r * 4) = st;
+        }
+    }
+}
+
+// Reverse mode.  With a_i = sigma_i*dt_i, T_i = exp(-sum_{j<i} a_j), w_i = T_i (1 - exp(-a_i)):
+//   dL/da_i = gw_i * T_{i+1} - sum_{k>i} (gw_k w_k + gT_k T_k),   T_{i+1} = T_i exp(-a_i)
+// with gw_i = d_weights_i + g(sum w) + g(sum w*mid) * mid_i.
+__global__ __launch_bounds__(256) void render_weights_bwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                                 const float *__restrict__ sigma,
+                                                                 const float *__restrict__ d_weights,
+                                                                 const float *__restrict__ d_trans,
+                                                                 const float *__restrict__ d_ray_stats, int64_t R, int32_t S,
+                                                                 float *__restrict__ d_sigma) {
+    __shared__ float chunk_base[kRaysPerBlockC][64];  // per-wave exclusive prefix of each 64-chunk (S <= 4096)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    const bool active = r < R;
+    const int32_t n_chunks = (S + kWave - 1) / kWave;
+    if (active) {
+        float carry = 0.0f;
+        for (int32_t c = 0; c < n_chunks; ++c) {
+            const int32_t s = c * kWave + lane;
+            const int64_t i = r * S + s;
+            const float sdt = s < S ? sigma[i] * (te[i] - ts[i]) : 0.0f;
+            if (lane == 0) chunk_base[wave][c] = carry;
+            carry += wave_sum(sdt);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float g0 = d_ray_stats ? d_ray_stats[r * 2 + 0] : 0.0f;
+    const float g1 = d_ray_stats ? d_ray_stats[r * 2 + 1] : 0.0f;
+    float suffix = 0.0f;  // sum over later chunks of (gw w + gT T)
+    for (int32_t c = n_chunks - 1; c >= 0; --c) {
+        const int32_t s = c * kWave + lane;
+        const bool ok = s < S;
+        const int64_t i = r * S + s;
+        const float a = ok ? ts[i] : 0.0f, b = ok ? te[i] : 0.0f, sg = ok ? sigma[i] : 0.0f;
+        const float dt = b - a;
+        const float sdt = sg * dt;
+        const float incl = wave_inclusive_sum(sdt, lane);
+        const float excl = chunk_base[wave][c] + (incl - sdt);
+        const float T = expf(-excl);
+        const float e = expf(-sdt);
+        const float w = T * (1.0f - e);
+        float gw = (ok && d_weights) ? d_weights[i] : 0.0f;
+        gw += g0 + g1 * ((a + b) / 2.0f);
+        const float gT = (ok && d_trans) ? d_trans[i] : 0.0f;
+        const float term = ok ? gw * w + gT * T : 0.0f;
+        const float sfx_incl = wave_inclusive_suffix_sum(term, lane);
+        const float later = suffix + (sfx_incl - term);  // strictly-later samples
+        if (ok) d_sigma[i] = dt * (gw * T * e - later);
+        suffix += __shfl(sfx_incl, 0, kWave);
+    }
+}
+
+// out[r,c] = sum_s w[r,s] * values[r,s,c].  Few channels (<= 8): lanes walk samples, one wave
+// reduction per channel.  Many channels: lanes walk channels (coalesced rows), w broadcast.
+template <int C>
+__global__ __launch_bounds__(256) void accumulate_fwd_small_kernel(const float *__restrict__ w, const float *__restrict__ v,
+                                                                   int64_t R, int32_t S, float *__restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (int32_t s = lane; s < S; s += kWave) {
+        const float ws = w[r * S + s];
+        if (v) {
+            const float *vp = v + (r * S + s) * (int64_t)C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += ws * vp[c];
+        } else {
+            acc[0] += ws;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = wave_sum(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[r * C + c] = acc[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void accumulate_fwd_wide_kernel(const float *__restrict__ w, const float *__restrict__ v,
+                                                                  int64_t R, int32_t S, int32_t C, float *__restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    for (int32_t c0 = 0; c0 < C; c0 += kWave) {
+        const int32_t c = c0 + lane;
+        float acc = 0.0f;
+        if (c < C)
+            for (int32_t s = 0; s < S; ++s) acc += w[r * S + s] * v[(r * S + s) * (int64_t)C + c];
+        if (c < C) out[r * (int64_t)C + c] = acc;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void accumulate_bwd_small_kernel(const float *__restrict__ w, const float *__restrict__ v,
+                                                                   const float *__restrict__ d_out, int64_t R, int32_t S,
+                                                                   float *__restrict__ d_w, float *__restrict__ d_v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // flat (r, s)
+    if (i >= R * S) return;
+    const int64_t r = i / S;
+    float g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = d_out[r * C + c];
+    if (d_w) {
+        float a = 0.0f;
+        if (v) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) a += g[c] * v[i * C + c];
+        } else {
+            a = g[0];
+        }
+        d_w[i] = a;
+    }
+    if (d_v) {
+        const float ws = w[i];
+#pragma unroll
+        for (int c = 0; c < C; ++c) d_v[i * C + c] = ws * g[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void accumulate_bwd_wide_kernel(const float *__restrict__ w, const float *__restrict__ v,
+                                                                  const float *__restrict__ d_out, int64_t R, int32_t S,
+                                                                  int32_t C, float *__restrict__ d_w, float *__restrict__ d_v) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    for (int32_t s = 0; s < S; ++s) {
+        const float ws = w[r * S + s];
+        float dot = 0.0f;
+        for (int32_t c = lane; c < C; c += kWave) {
+            const float g = d_out[r * (int64_t)C + c];
+            const int64_t j = (r * S + s) * (int64_t)C + c;
+            if (d_w) dot += g * v[j];
+            if (d_v) d_v[j] = ws * g;
+        }
+        if (d_w) {
+            dot = wave_sum(dot);
+            if (lane == 0) d_w[r * S + s] = dot;
+        }
+    }
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_render_weights_fwd(const float *ts, const float *te, const float *sigma, int64_t R, int32_t S,
+                                       float *weights, float *trans, float *alphas, float *cdfs, float *ray_stats,
+                                       void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1, "render_weights_fwd: bad sizes R=%lld S=%d", (long long)R, S);
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(ts && te && sigma, "render_weights_fwd: null input");
+    hipLaunchKernelGGL(render_weights_fwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream),
+                       ts, te, sigma, R, S, weights, trans, alphas, cdfs, ray_stats);
+    return check_launch("render_weights_fwd");
+}
+
+extern "C" int emer_render_weights_bwd(const float *ts, const float *te, const float *sigma, const float *d_weights,
+                                       const float *d_trans, const float *d_ray_stats, int64_t R, int32_t S,
+                                       float *d_sigma, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && S <= 4096, "render_weights_bwd: bad sizes R=%lld S=%d (S <= 4096)", (long long)R, S);
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(ts && te && sigma && d_sigma, "render_weights_bwd: null pointer");
+    hipLaunchKernelGGL(render_weights_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream),
+                       ts, te, sigma, d_weights, d_trans, d_ray_stats, R, S, d_sigma);
+    return check_launch("render_weights_bwd");
+}
+
+extern "C" int emer_accumulate_fwd(const float *w, const float *v, int64_t R, int32_t S, int32_t C, float *out,
+                                   void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "accumulate_fwd: bad sizes");
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(w && out, "accumulate_fwd: null pointer");
+    EMER_REQUIRE(v || C == 1, "accumulate_fwd: values == NULL requires n_channels == 1");
+    const dim3 grid((uint32_t)ceil_div(R, kRaysPerBlockC)), block(256);
+    hipStream_t st = as_stream(stream);
+    switch (C) {
+#define EMER_ACC(c) case c: hipLaunchKernelGGL(accumulate_fwd_small_kernel<c>, grid, block, 0, st, w, v, R, S, out); break;
+        EMER_ACC(1) EMER_ACC(2) EMER_ACC(3) EMER_ACC(4) EMER_ACC(5) EMER_ACC(6) EMER_ACC(7) EMER_ACC(8)
+#undef EMER_ACC
+        default: hipLaunchKernelGGL(accumulate_fwd_wide_kernel, grid, block, 0, st, w, v, R, S, C, out);
+    }
+    return check_launch("accumulate_fwd");
+}
+
+extern "C" int emer_accumulate_bwd(const float *w, const float *v, const float *d_out, int64_t R, int32_t S, int32_t C,
+                                   float *d_w, float *d_v, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "accumulate_bwd: bad sizes");
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(w && d_out, "accumulate_bwd: null pointer");
+    EMER_REQUIRE(v || (C == 1 && !d_v), "accumulate_bwd: values == NULL requires n_channels == 1 and d_values == NULL");
+    hipStream_t st = as_stream(stream);
+    const dim3 block(256);
+    if (C <= 8) {
+        const dim3 grid((uint32_t)ceil_div(R * S, 256));
+        switch (C) {
+#define EMER_ACC(c) case c: hipLaunchKernelGGL(accumulate_bwd_small_kernel<c>, grid, block, 0, st, w, v, d_out, R, S, d_w, d_v); break;
+            EMER_ACC(1) EMER_ACC(2) EMER_ACC(3) EMER_ACC(4) EMER_ACC(5) EMER_ACC(6) EMER_ACC(7) EMER_ACC(8)
+#undef EMER_ACC
+        }
+    } else {
+        hipLaunchKernelGGL(accumulate_bwd_wide_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), block, 0, st, w, v, d_out, R,
+                           S, C, d_w, d_v);
+    }
+    return check_launch("accumulate_bwd");
+}

@@ -1,0 +1,275 @@
+// Per-sample / per-parameter elementwise kernels of the hot path (gfx950):
+//   scene contraction fwd/bwd, ray sample points, sinusoidal direction encoding, fused Adam.
+// All are pure HBM-streaming kernels (grid-stride, 256-thread blocks, capped at 2048 blocks).
+//
+// FMA contraction is disabled in this file: sample positions and contracted coordinates decide
+// which grid cell a sample falls in, so they follow the reference's torch expression order exactly
+// (radiance_fields/render_utils.py:318,341; nerf_utils.py:13-28; radiance_field.py:278-300).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace emer {
+
+struct Aabb { float lo[3], hi[3]; };
+
+__device__ __forceinline__ Aabb load_aabb(const float *__restrict__ aabb) {
+    Aabb a;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.lo[d] = aabb[d]; a.hi[d] = aabb[3 + d]; }
+    return a;
+}
+
+// returns inside flag; v = contracted coords (already zeroed when outside)
+__device__ __forceinline__ bool contract_point(const Aabb &bb, bool unbounded, const float (&p)[3], float (&v)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v[d] = (p[d] - bb.lo[d]) / (bb.hi[d] - bb.lo[d]);
+    if (unbounded) {
+        float mag = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { v[d] = v[d] * 2.0f - 1.0f; mag = fmaxf(mag, fabsf(v[d])); }
+        if (!(mag < 1.0f)) {
+            const float s = 2.0f - 1.0f / mag;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) v[d] = s * (v[d] / mag);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] = v[d] / 4.0f + 0.5f;
+    }
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) inside = inside && (v[d] > 0.0f) && (v[d] < 1.0f);
+    if (!inside) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[d] = v[d] * 0.0f;
+    }
+    return inside;
+}
+
+__global__ __launch_bounds__(256) void contract_fwd_kernel(const float *__restrict__ pos, const float *__restrict__ aabb,
+                                                           int unbounded, float *__restrict__ out, int64_t n) {
+    const Aabb bb = load_aabb(aabb);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]}, v[3];
+        contract_point(bb, unbounded != 0, p, v);
+        out[i * 3] = v[0]; out[i * 3 + 1] = v[1]; out[i * 3 + 2] = v[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void contract_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ aabb,
+                                                           int unbounded, const float *__restrict__ dout,
+                                                           float *__restrict__ dpos, int64_t n) {
+    const Aabb bb = load_aabb(aabb);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]}, v[3];
+        const bool inside = contract_point(bb, unbounded != 0, p, v);
+        float g[3] = {0.0f, 0.0f, 0.0f};
+        if (inside) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d] = dout[i * 3 + d];
+            if (unbounded) {
+                float u[3], mag = 0.0f;
+                int k = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    u[d] = (p[d] - bb.lo[d]) / (bb.hi[d] - bb.lo[d]) * 2.0f - 1.0f;
+                    if (fabsf(u[d]) > mag) { mag = fabsf(u[d]); k = d; }
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) g[d] = g[d] / 4.0f;  // y = c/4 + 0.5
+                if (!(mag < 1.0f)) {
+                    // c_d = f(mag) u_d, f = 2/mag - 1/mag^2, mag = |u_k|
+                    const float inv = 1.0f / mag;
+                    const float f = 2.0f * inv - inv * inv;
+                    const float df = -2.0f * inv * inv + 2.0f * inv * inv * inv;
+                    const float dotug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+                    const float sgn = u[k] >= 0.0f ? 1.0f : -1.0f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) g[d] = f * g[d] + (d == k ? sgn * df * dotug : 0.0f);
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d) g[d] = g[d] * 2.0f;  // u = 2v - 1
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d] = g[d] / (bb.hi[d] - bb.lo[d]);
+        }
+        dpos[i * 3] = g[0]; dpos[i * 3 + 1] = g[1]; dpos[i * 3 + 2] = g[2];
+    }
+}
+
+// positions = o + d * (t0 + t1) / 2 (evaluated as ((d * (t0 + t1)) / 2) + o, render_utils.py:341)
+__global__ __launch_bounds__(256) void ray_points_kernel(const float *__restrict__ origins, const float *__restrict__ dirs,
+                                                         const float *__restrict__ ts, const float *__restrict__ te,
+                                                         const float *__restrict__ times, const float *__restrict__ aabb,
+                                                         int unbounded, float *__restrict__ normed, int out_dim,
+                                                         float *__restrict__ positions_out, int64_t R, int32_t S) {
+    const Aabb bb = load_aabb(aabb);
+    const int64_t n = R * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / S;
+        const float tsum = ts[i] + te[i];
+        float p[3], v[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) p[d] = origins[r * 3 + d] + dirs[r * 3 + d] * tsum / 2.0f;
+        contract_point(bb, unbounded != 0, p, v);
+        if (out_dim == 4) {
+            *reinterpret_cast<float4 *>(normed + i * 4) = make_float4(v[0], v[1], v[2], times[r]);
+        } else {
+            normed[i * 3] = v[0]; normed[i * 3 + 1] = v[1]; normed[i * 3 + 2] = v[2];
+        }
+        if (positions_out) { positions_out[i * 3] = p[0]; positions_out[i * 3 + 1] = p[1]; positions_out[i * 3 + 2] = p[2]; }
+    }
+}
+
+// SinusoidalEncoder(min_deg=0, max_deg) on (d+1)/2 (encodings.py:86-104; radiance_field.py:629):
+//   out = [x (3), sin(2^i x_d) (i-major, 3 per degree), sin(2^i x_d + pi/2)]
+__global__ __launch_bounds__(256) void dir_encode_kernel(const float *__restrict__ dirs, float *__restrict__ out, int64_t n,
+                                                         int32_t max_deg) {
+    const int32_t n_deg = max_deg + 1, width = 3 * (1 + 2 * n_deg);
+    const float half_pi = 0.5f * 3.14159265358979323846f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float x[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) x[d] = (dirs[i * 3 + d] + 1.0f) / 2.0f;
+        float *o = out + i * width;
+        if (max_deg == 0) {  // encoder degenerates to identity when max_deg == min_deg (encodings.py:93-94)
+            o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+            continue;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[d] = x[d];
+        float scale = 1.0f;
+        for (int32_t k = 0; k < n_deg; ++k) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float xb = x[d] * scale;
+                o[3 + k * 3 + d] = sinf(xb);
+                o[3 + 3 * n_deg + k * 3 + d] = sinf(xb + half_pi);
+            }
+            scale *= 2.0f;
+        }
+    }
+}
+
+// torch.optim.Adam (weight_decay as L2, no amsgrad) on a flat buffer; builders.py:50-60.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float gscale, float bc1, float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.0f) gi = gi + wd * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);   // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;  // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+
+// Layout glue between the grid kernels (level-major [L][N][F], coalesced per level) and the
+// row-major [N, L*F] tensor the reference API exposes (tcnn_modules.py:263).  64-sample tiles go
+// through LDS (pitch LF+1) so both the global reads and the global writes are fully coalesced.
+__global__ __launch_bounds__(256) void layout_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int32_t L, int64_t N, int32_t F, int to_row_major) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int32_t LF = L * F, pitch = LF + 1;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int32_t rows = (int32_t)((N - n0) < 64 ? (N - n0) : 64);
+    const int32_t per_level = rows * F;  // contiguous floats of one level inside this tile
+    if (to_row_major) {
+        for (int idx = threadIdx.x; idx < L * per_level; idx += 256) {
+            const int l = idx / per_level, rem = idx - l * per_level;
+            const int r = rem / F, f = rem - r * F;
+            tile[r * pitch + l * F + f] = src[((int64_t)l * N + n0) * F + rem];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < rows * LF; idx += 256) {
+            const int r = idx / LF, c = idx - r * LF;
+            dst[n0 * LF + idx] = tile[r * pitch + c];
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < rows * LF; idx += 256) {
+            const int r = idx / LF, c = idx - r * LF;
+            tile[r * pitch + c] = src[n0 * LF + idx];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < L * per_level; idx += 256) {
+            const int l = idx / per_level, rem = idx - l * per_level;
+            const int r = rem / F, f = rem - r * F;
+            dst[((int64_t)l * N + n0) * F + rem] = tile[r * pitch + l * F + f];
+        }
+    }
+}
+
+static inline uint32_t stream_blocks(int64_t n) {
+    const int64_t b = ceil_div(n, 256);
+    return (uint32_t)(b < 2048 ? b : 2048);
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_contract_fwd(const float *pos, const float *aabb, int unbounded, float *out, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0, "contract_fwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(pos && aabb && out, "contract_fwd: null pointer");
+    hipLaunchKernelGGL(contract_fwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), pos, aabb, unbounded, out, n);
+    return check_launch("contract_fwd");
+}
+
+extern "C" int emer_contract_bwd(const float *pos, const float *aabb, int unbounded, const float *dout, float *dpos,
+                                 int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0, "contract_bwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(pos && aabb && dout && dpos, "contract_bwd: null pointer");
+    hipLaunchKernelGGL(contract_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), pos, aabb, unbounded, dout,
+                       dpos, n);
+    return check_launch("contract_bwd");
+}
+
+extern "C" int emer_ray_points(const float *origins, const float *dirs, const float *ts, const float *te,
+                               const float *times, const float *aabb, int unbounded, float *normed, int out_dim,
+                               float *positions_out, int64_t R, int32_t S, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1, "ray_points: bad sizes");
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(origins && dirs && ts && te && aabb && normed, "ray_points: null pointer");
+    EMER_REQUIRE(out_dim == 3 || (out_dim == 4 && times), "ray_points: out_dim must be 3, or 4 with times != NULL");
+    hipLaunchKernelGGL(ray_points_kernel, dim3(stream_blocks(R * S)), dim3(256), 0, as_stream(stream), origins, dirs, ts, te,
+                       times, aabb, unbounded, normed, out_dim, positions_out, R, S);
+    return check_launch("ray_points");
+}
+
+extern "C" int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, void *stream) {
+    EMER_REQUIRE(n >= 0 && max_deg >= 0 && max_deg <= 16, "dir_encode: bad arguments");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(dirs && out, "dir_encode: null pointer");
+    hipLaunchKernelGGL(dir_encode_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), dirs, out, n, max_deg);
+    return check_launch("dir_encode");
+}
+
+extern "C" int emer_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t step,
+                              void *stream) {
+    EMER_REQUIRE(n >= 0 && step >= 1, "adam_step: bad arguments (step counts from 1)");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: null pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
+    return check_launch("adam_step");
+}
+
+extern "C" int emer_layout_transpose(const float *src, float *dst, int32_t n_levels, int64_t n, int32_t n_features,
+                                     int to_row_major, void *stream) {
+    EMER_REQUIRE(n >= 0 && n_levels >= 1 && n_features >= 1 && n_levels * n_features <= 512, "layout_transpose: bad sizes");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(src && dst && src != dst, "layout_transpose: null or aliased pointers");
+    const size_t lds = (size_t)64 * (n_levels * n_features + 1) * sizeof(float);
+    hipLaunchKernelGGL(layout_transpose_kernel, dim3((uint32_t)ceil_div(n, 64)), dim3(256), lds, as_stream(stream), src, dst,
+                       n_levels, n, n_features, to_row_major);
+    return check_launch("layout_transpose");
+}

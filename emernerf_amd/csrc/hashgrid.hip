@@ -1,0 +1,370 @@
+// Multiresolution hash-grid encode / backward for gfx950 (MI355X).
+//
+// Replaces tiny-cuda-nn's GridEncoding kernels behind tcnn.Encoding (reference call sites:
+// radiance_fields/encodings.py:159-160 -> third_party/tcnn_modules.py:122 (fwd), :161-163 (bwd)).
+// Semantics: SURVEY.md Appendix A.1; CPU restatement: oracle/emer_oracle.c.
+//
+// MI355X design notes
+//   * one thread = one (sample, level); a workgroup = 256 consecutive samples of ONE level, so all
+//     per-level constants live in SGPRs and the 64 lanes of a wave walk spatially adjacent samples
+//     of one ray (coarse-level corners coalesce in the texture-address unit / L1).
+//   * block -> (level, chunk) mapping is XCD-aware: MI355X dispatches block b to XCD b % 8 and every
+//     XCD has a private 4 MiB L2.  Levels are dealt to XCDs round-robin in groups of 8 and each XCD
+//     finishes one level before starting its next one, so a level's table (<= 4 MiB for T=2^19, F=2,
+//     fp32; 2 MiB in fp16) is gathered / scattered out of ONE L2 instead of thrashing all eight.
+//     This is a speed heuristic only: results never depend on placement.
+//   * output / dOut use caller-supplied (stride_n, stride_l) so the fused heads can ask for the
+//     level-major [L][N][F] layout (fully coalesced 64 x F*4 B stores per wave) while the drop-in
+//     HashEncoder.forward can still get the reference's row-major [N, L*F].
+#include "common.h"
+
+namespace emer {
+
+template <int F, typename PT>
+__device__ __forceinline__ void load_feats(const PT *__restrict__ p, float (&v)[F]);
+
+template <> __device__ __forceinline__ void load_feats<1, float>(const float *__restrict__ p, float (&v)[1]) { v[0] = p[0]; }
+template <> __device__ __forceinline__ void load_feats<2, float>(const float *__restrict__ p, float (&v)[2]) {
+    float2 t = *reinterpret_cast<const float2 *>(p); v[0] = t.x; v[1] = t.y;
+}
+template <> __device__ __forceinline__ void load_feats<4, float>(const float *__restrict__ p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4 *>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load_feats<8, float>(const float *__restrict__ p, float (&v)[8]) {
+    float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load_feats<1, __half>(const __half *__restrict__ p, float (&v)[1]) { v[0] = __half2float(p[0]); }
+template <> __device__ __forceinline__ void load_feats<2, __half>(const __half *__restrict__ p, float (&v)[2]) {
+    float2 t = __half22float2(*reinterpret_cast<const __half2 *>(p)); v[0] = t.x; v[1] = t.y;
+}
+template <> __device__ __forceinline__ void load_feats<4, __half>(const __half *__restrict__ p, float (&v)[4]) {
+    uint2 raw = *reinterpret_cast<const uint2 *>(p);
+    float2 a = __half22float2(*reinterpret_cast<__half2 *>(&raw.x)), b = __half22float2(*reinterpret_cast<__half2 *>(&raw.y));
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+template <> __device__ __forceinline__ void load_feats<8, __half>(const __half *__restrict__ p, float (&v)[8]) {
+    uint4 raw = *reinterpret_cast<const uint4 *>(p);
+    float2 a = __half22float2(*reinterpret_cast<__half2 *>(&raw.x)), b = __half22float2(*reinterpret_cast<__half2 *>(&raw.y));
+    float2 c = __half22float2(*reinterpret_cast<__half2 *>(&raw.z)), d = __half22float2(*reinterpret_cast<__half2 *>(&raw.w));
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
+}
+
+// Relaxed device-scope float atomics.  The file is built with -munsafe-fp-atomics so these lower
+// to global_atomic_add_f32 / global_atomic_pk_add_f16 (no CAS loop, no return value).
+template <int F>
+__device__ __forceinline__ void atomic_add_feats(float *p, const float (&v)[F]) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(p + f, v[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int F>
+__device__ __forceinline__ void atomic_add_feats(__half *p, const float (&v)[F]) {
+    static_assert(F % 2 == 0, "fp16 gradient tables need an even feature count");
+#pragma unroll
+    for (int f = 0; f < F; f += 2) unsafeAtomicAdd(reinterpret_cast<__half2 *>(p + f), __floats2half2_rn(v[f], v[f + 1]));
+}
+
+struct LevelInfo {
+    float scale;
+    uint32_t res, size, offset, hashed;
+};
+
+__device__ __forceinline__ LevelInfo level_info(const emer_grid_desc &g, uint32_t l) {
+    return LevelInfo{g.scale[l], g.res[l], g.size[l], g.offset[l], g.hashed[l]};
+}
+
+// XCD-aware block -> (level, chunk) map (see file header).  Returns false for padding blocks.
+__device__ __forceinline__ bool map_block(uint32_t bid, uint32_t L, uint32_t n_chunks, uint32_t &level, uint32_t &chunk) {
+    const uint32_t full_groups = L >> 3, rem = L & 7u;
+    const uint32_t x = bid & 7u, j = bid >> 3;
+    const uint32_t blocks_full = full_groups * n_chunks;  // per XCD
+    if (j < blocks_full) {
+        const uint32_t k = j / n_chunks;
+        chunk = j - k * n_chunks;
+        level = k * 8u + x;
+        return true;
+    }
+    const uint32_t id2 = (j - blocks_full) * 8u + x;  // leftover levels: spread over all XCDs
+    if (id2 >= rem * n_chunks) return false;
+    chunk = id2 / rem;
+    level = full_groups * 8u + (id2 - chunk * rem);
+    return true;
+}
+static inline uint32_t grid_blocks(uint32_t L, uint32_t n_chunks) {
+    const uint32_t full_groups = L >> 3, rem = L & 7u;
+    return 8u * full_groups * n_chunks + (uint32_t)ceil_div((int64_t)rem * n_chunks, 8) * 8u;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t grid_index(const LevelInfo &li, const uint32_t (&c)[D]) {
+    uint32_t idx;
+    if (li.hashed) {  // level-uniform branch
+        idx = c[0];
+        idx ^= c[1] * 2654435761u;
+        if (D > 2) idx ^= c[2 < D ? 2 : 0] * 805459861u;
+        if (D > 3) idx ^= c[3 < D ? 3 : 0] * 3674653429u;
+    } else {
+        uint32_t stride = 1;
+        idx = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (stride <= li.size) { idx += c[d] * stride; stride *= li.res; }
+        }
+    }
+    // idx % size without the integer divide on the common paths (size is level-uniform)
+    if ((li.size & (li.size - 1u)) == 0u) return idx & (li.size - 1u);
+    if (idx >= li.size) { idx -= li.size; if (idx >= li.size) idx %= li.size; }
+    return idx;
+}
+
+template <int D>
+__device__ __forceinline__ void load_x(const float *__restrict__ x, int64_t n, float (&v)[D]) {
+    if (D == 4) {
+        float4 t = *reinterpret_cast<const float4 *>(x + n * 4);
+        v[0] = t.x; v[1] = t.y; v[2 < D ? 2 : 0] = t.z; v[3 < D ? 3 : 0] = t.w;
+    } else if (D == 2) {
+        float2 t = *reinterpret_cast<const float2 *>(x + n * 2);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = x[n * D + d];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void cell_of(const LevelInfo &li, const float (&xv)[D], uint32_t (&gi)[D], float (&w)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float pos = fmaf(li.scale, xv[d], 0.5f);
+        const float fl = floorf(pos);
+        gi[d] = (uint32_t)(int32_t)fl;
+        w[d] = pos - fl;
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int D, int F, typename PT>
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc g, const float *__restrict__ x,
+                                                           const PT *__restrict__ params, float *__restrict__ out,
+                                                           int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
+    if (n >= N) return;
+    const LevelInfo li = level_info(g, level);
+    const PT *__restrict__ table = params + (size_t)li.offset * F;
+
+    float xv[D], w[D];
+    uint32_t gi[D];
+    load_x<D>(x, n, xv);
+    cell_of<D>(li, xv, gi, w);
+
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+#pragma unroll
+    for (uint32_t m = 0; m < (1u << D); ++m) {
+        float wt = 1.0f;
+        uint32_t c[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
+            else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
+        }
+        float v[F];
+        load_feats<F, PT>(table + (size_t)grid_index<D>(li, c) * F, v);
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
+    }
+    float *o = out + n * sn + (int64_t)level * sl;
+    if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
+    else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
+    else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = acc[f];
+    }
+}
+
+// ------------------------------------------------------------------------ backward (params)
+template <int D, int F, typename GT>
+__global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_grid_desc g, const float *__restrict__ x,
+                                                                  const float *__restrict__ dout, int64_t sn, int64_t sl,
+                                                                  GT *__restrict__ grad, int64_t N, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
+    if (n >= N) return;
+    const LevelInfo li = level_info(g, level);
+    GT *__restrict__ table = grad + (size_t)li.offset * F;
+
+    float go[F];
+    const float *gp = dout + n * sn + (int64_t)level * sl;
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) { go[f] = gp[f]; any |= (go[f] != 0.0f); }
+    if (!any) return;  // exact zeros add nothing (masked / fully occluded samples)
+
+    float xv[D], w[D];
+    uint32_t gi[D];
+    load_x<D>(x, n, xv);
+    cell_of<D>(li, xv, gi, w);
+#pragma unroll
+    for (uint32_t m = 0; m < (1u << D); ++m) {
+        float wt = 1.0f;
+        uint32_t c[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
+            else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
+        }
+        float v[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[f] = wt * go[f];
+        atomic_add_feats<F>(table + (size_t)grid_index<D>(li, c) * F, v);
+    }
+}
+
+// ------------------------------------------------------------------------- backward (input)
+// One thread per sample, all levels: deterministic, no atomics.  Only the flow configs reach this.
+template <int D, int F, typename PT>
+__global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(const emer_grid_desc g, const float *__restrict__ x,
+                                                                 const PT *__restrict__ params,
+                                                                 const float *__restrict__ dout, int64_t sn, int64_t sl,
+                                                                 float *__restrict__ dx, int64_t N) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float xv[D], gx[D];
+    load_x<D>(x, n, xv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) gx[d] = 0.0f;
+    for (uint32_t l = 0; l < g.n_levels; ++l) {
+        const LevelInfo li = level_info(g, l);
+        const PT *__restrict__ table = params + (size_t)li.offset * F;
+        float w[D], go[F];
+        uint32_t gi[D];
+        cell_of<D>(li, xv, gi, w);
+        const float *gp = dout + n * sn + (int64_t)l * sl;
+#pragma unroll
+        for (int f = 0; f < F; ++f) go[f] = gp[f];
+        // gather all 2^D corners once, projected on dOut: s[m] = sum_f dOut_f * table[corner m][f]
+        float s[1 << D];
+#pragma unroll
+        for (uint32_t m = 0; m < (1u << D); ++m) {
+            uint32_t c[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
+            float v[F];
+            load_feats<F, PT>(table + (size_t)grid_index<D>(li, c) * F, v);
+            float a = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) a += go[f] * v[f];
+            s[m] = a;
+        }
+#pragma unroll
+        for (int gd = 0; gd < D; ++gd) {
+            float acc = 0.0f;
+#pragma unroll
+            for (uint32_t m = 0; m < (1u << D); ++m) {
+                if (m & (1u << gd)) continue;  // enumerate corners with bit gd == 0
+                float wt = li.scale;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (d == gd) continue;
+                    wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                }
+                acc += wt * (s[m | (1u << gd)] - s[m]);
+            }
+            gx[gd] += acc;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dx[n * D + d] = gx[d];
+}
+
+// ------------------------------------------------------------------------------- dispatch
+template <typename Fn>
+static int dispatch_df(uint32_t D, uint32_t F, Fn &&fn) {
+#define EMER_CASE(d, f) if (D == d && F == f) return fn(std::integral_constant<int, d>{}, std::integral_constant<int, f>{});
+    EMER_CASE(2, 1) EMER_CASE(2, 2) EMER_CASE(2, 4) EMER_CASE(2, 8)
+    EMER_CASE(3, 1) EMER_CASE(3, 2) EMER_CASE(3, 4) EMER_CASE(3, 8)
+    EMER_CASE(4, 1) EMER_CASE(4, 2) EMER_CASE(4, 4) EMER_CASE(4, 8)
+#undef EMER_CASE
+    set_error("hashgrid: unsupported (n_dims=%u, n_features=%u); need D in 2..4, F in {1,2,4,8}", D, F);
+    return EMER_E_INVALID;
+}
+
+static int check_desc(const emer_grid_desc *g) {
+    EMER_REQUIRE(g != nullptr, "hashgrid: null descriptor");
+    EMER_REQUIRE(g->n_levels >= 1 && g->n_levels <= EMER_MAX_LEVELS, "hashgrid: n_levels=%u out of range", g->n_levels);
+    EMER_REQUIRE(g->n_entries > 0, "hashgrid: descriptor not initialised (call emer_grid_desc_init)");
+    return EMER_OK;
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const void *params, int param_dtype,
+                                 float *out, int64_t sn, int64_t sl, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0, "hashgrid_fwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && params && out, "hashgrid_fwd: null pointer");
+    EMER_REQUIRE(param_dtype == EMER_F32 || param_dtype == EMER_F16, "hashgrid_fwd: bad param_dtype %d", param_dtype);
+    const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
+    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, F = decltype(f)::value;
+        if (param_dtype == EMER_F32)
+            hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                               (const float *)params, out, sn, sl, n, n_chunks);
+        else
+            hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                               (const __half *)params, out, sn, sl, n, n_chunks);
+        return check_launch("hashgrid_fwd");
+    });
+}
+
+extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
+                                        int64_t sl, void *grad, int grad_dtype, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0, "hashgrid_bwd_params: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && dout && grad, "hashgrid_bwd_params: null pointer");
+    EMER_REQUIRE(grad_dtype == EMER_F32 || grad_dtype == EMER_F16, "hashgrid_bwd_params: bad grad_dtype %d", grad_dtype);
+    EMER_REQUIRE(!(grad_dtype == EMER_F16 && (g->n_features & 1u)), "hashgrid_bwd_params: fp16 gradients need an even n_features");
+    const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
+    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, F = decltype(f)::value;
+        if (grad_dtype == EMER_F32) {
+            hipLaunchKernelGGL((hashgrid_bwd_params_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g,
+                               x, dout, sn, sl, (float *)grad, n, n_chunks);
+        } else {
+            if constexpr (F % 2 == 0)
+                hipLaunchKernelGGL((hashgrid_bwd_params_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                                   *g, x, dout, sn, sl, (__half *)grad, n, n_chunks);
+        }
+        return check_launch("hashgrid_bwd_params");
+    });
+}
+
+extern "C" int emer_hashgrid_bwd_input(const emer_grid_desc *g, const float *x, const void *params, int param_dtype,
+                                       const float *dout, int64_t sn, int64_t sl, float *dx, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0, "hashgrid_bwd_input: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && params && dout && dx, "hashgrid_bwd_input: null pointer");
+    EMER_REQUIRE(param_dtype == EMER_F32 || param_dtype == EMER_F16, "hashgrid_bwd_input: bad param_dtype %d", param_dtype);
+    const uint32_t blocks = (uint32_t)ceil_div(n, 256);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, F = decltype(f)::value;
+        if (param_dtype == EMER_F32)
+            hipLaunchKernelGGL((hashgrid_bwd_input_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                               (const float *)params, dout, sn, sl, dx, n);
+        else
+            hipLaunchKernelGGL((hashgrid_bwd_input_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g,
+                               x, (const __half *)params, dout, sn, sl, dx, n);
+        return check_launch("hashgrid_bwd_input");
+    });
+}

@@ -1,0 +1,278 @@
+// Small-MLP head kernels for gfx950 on the fp32-input matrix cores.
+//
+// Replaces the torch.nn.Linear (+ReLU / Sigmoid / trunc_exp) chains of the reference's heads
+// (radiance_fields/radiance_field.py:74-198, radiance_fields/mlp.py:7-46), i.e. one cuBLAS GEMM plus
+// one or two elementwise launches per layer with [N,64] fp32 activations bouncing through HBM.
+//
+// Precision: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 -- f32 in, f32 accumulate, bit-identical
+// to a k-ordered fmaf chain (MI355X guide, "FP32-input MFMA"), so the heads keep the reference's
+// fp32 semantics (north-star tolerance 1e-4 on composited RGB/depth) while running on the matrix
+// pipe at the full fp32 rate and leaving the VALU free for bias/activation epilogues.
+//
+// Kernels
+//   linear_fwd  : Y = act(X W^T + b).  128-row workgroup tile, 4 waves x 32 rows; 64-wide (32x32x2)
+//                 or 16-wide (16x16x4, for 1/3/6-channel outputs) column tiles; X/W K-chunks of 32
+//                 staged in LDS with an odd (33) / even-offset (34) row pitch so every ds_read_b32
+//                 lane group is bank-conflict free.  Generic B strides serve dX = dPre W as well.
+//   act_bwd     : dPre = dY * act'(Y)  (act' from the saved output only).
+//   linear_dw   : dW += dPre^T X, db += colsum(dPre): split over rows, 32-row LDS tiles, per-wave
+//                 32x32 output tiles held in accumulators for the whole row range, one fp32 atomic
+//                 pass per workgroup at the end.
+#include "common.h"
+
+namespace emer {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float apply_act(int act, float x) {
+    switch (act) {
+        case EMER_ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case EMER_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case EMER_ACT_TRUNC_EXP: return expf(x - 1.0f);
+        default: return x;
+    }
+}
+// derivative expressed through the saved OUTPUT y
+__device__ __forceinline__ float act_grad_from_y(int act, float y) {
+    switch (act) {
+        case EMER_ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case EMER_ACT_SIGMOID: return y * (1.0f - y);
+        case EMER_ACT_TRUNC_EXP: return fminf(y, 3269017.3724721107f);  // exp(min(x-1, 15)) = min(y, e^15)
+        default: return 1.0f;
+    }
+}
+
+constexpr int kBM = 128;  // rows per workgroup
+constexpr int kBK = 32;   // K chunk staged in LDS
+
+// b(j, kk) = wmat[j * sbj + kk * sbk]:  fwd: W[N,K] row-major -> (K, 1);  dX: W^T -> (1, K)
+template <int BN>  // 64 -> mfma 32x32x2, 16 -> mfma 16x16x4
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ wmat,
+                                                         int64_t sbj, int64_t sbk, const float *__restrict__ bias,
+                                                         float *__restrict__ y, int64_t ldy, int64_t M, int32_t N, int32_t K,
+                                                         int act) {
+    constexpr int PITCH = (BN == 64) ? 33 : 34;
+    __shared__ float xs[kBM * PITCH];
+    __shared__ float ws[BN * PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t row0 = (int64_t)blockIdx.x * kBM;
+    const int32_t n0 = blockIdx.y * BN;
+
+    f32x16 acc0 = {0}, acc1 = {0};  // BN == 64: two 32x32 column tiles
+    f32x4 c0 = {0}, c1 = {0};       // BN == 16: two 16-row tiles
+
+    for (int32_t k0 = 0; k0 < K; k0 += kBK) {
+        // stage X[row0 : row0+128, k0 : k0+32] (zero padded), coalesced along k
+        for (int idx = tid; idx < kBM * kBK; idx += 256) {
+            const int r = idx >> 5, c = idx & 31;
+            const int64_t gr = row0 + r;
+            const int32_t gk = k0 + c;
+            xs[r * PITCH + c] = (gr < M && gk < K) ? x[gr * ldx + gk] : 0.0f;
+        }
+        for (int idx = tid; idx < BN * kBK; idx += 256) {
+            const int j = idx >> 5, c = idx & 31;
+            const int32_t gn = n0 + j, gk = k0 + c;
+            ws[j * PITCH + c] = (gn < N && gk < K) ? wmat[gn * sbj + gk * sbk] : 0.0f;
+        }
+        __syncthreads();
+        if constexpr (BN == 64) {
+            const float *xa = xs + (wave * 32 + (lane & 31)) * PITCH + (lane >> 5);
+            const float *wb = ws + (lane & 31) * PITCH + (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < kBK / 2; ++s) {
+                const float a = xa[2 * s];
+                const float b0 = wb[2 * s], b1 = wb[32 * PITCH + 2 * s];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        } else {
+            const float *xa = xs + (wave * 32 + (lane & 15)) * PITCH + (lane >> 4);
+            const float *wb = ws + (lane & 15) * PITCH + (lane >> 4);
+#pragma unroll
+            for (int s = 0; s < kBK / 4; ++s) {
+                const float b = wb[4 * s];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * s], b, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[16 * PITCH + 4 * s], b, c1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    if constexpr (BN == 64) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int32_t col = n0 + t * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M) y[row * ldy + col] = apply_act(act, (t == 0 ? acc0[r] : acc1[r]) + bv);
+            }
+        }
+    } else {
+        const int32_t col = n0 + (lane & 15);
+        if (col < N) {
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + wave * 32 + t * 16 + (lane >> 4) * 4 + r;
+                    if (row < M) y[row * ldy + col] = apply_act(act, (t == 0 ? c0[r] : c1[r]) + bv);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ y,
+                                                      int64_t ldy, float *__restrict__ dpre, int64_t M, int32_t N, int act) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / N;
+        const int32_t c = (int32_t)(i - r * N);
+        dpre[i] = dy[r * lddy + c] * act_grad_from_y(act, y[r * ldy + c]);
+    }
+}
+
+// dW[N,K] += dPre[M,N]^T X[M,K];  db[N] += colsum(dPre).
+// grid = (row blocks, K groups, N groups); a workgroup covers n in [ng*NG, ng*NG+NG) and
+// k in [kg*KG, kg*KG+KG) as (NG/32)*(KG/32) tiles dealt round-robin to its 4 waves (TPW per wave).
+template <int TPW>
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict__ dpre, const float *__restrict__ x, int64_t ldx,
+                                                        float *__restrict__ dw, float *__restrict__ dbias, int64_t M, int32_t N,
+                                                        int32_t K, int32_t rows_per_block, int32_t NG, int32_t KG) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ds = smem;            // [32][NG]
+    float *xs = smem + 32 * NG;  // [32][KG]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int32_t n_base = blockIdx.z * NG, k_base = blockIdx.y * KG;
+    const int32_t ktiles = KG / 32, ntiles = NG / 32, total_tiles = ktiles * ntiles;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < M) ? r_begin + rows_per_block : M;
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = f32x16{0};
+    float bsum0 = 0.0f, bsum1 = 0.0f;  // wave 0: column sums for n = lane, lane + 64
+
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+        for (int idx = tid; idx < 32 * NG; idx += 256) {
+            const int r = idx / NG, c = idx - r * NG;
+            const int64_t gr = r0 + r;
+            const int32_t gn = n_base + c;
+            ds[idx] = (gr < r_end && gn < N) ? dpre[gr * (int64_t)N + gn] : 0.0f;
+        }
+        for (int idx = tid; idx < 32 * KG; idx += 256) {
+            const int r = idx / KG, c = idx - r * KG;
+            const int64_t gr = r0 + r;
+            const int32_t gk = k_base + c;
+            xs[idx] = (gr < r_end && gk < K) ? x[gr * ldx + gk] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int t = wave + 4 * j;
+            if (t < total_tiles) {  // wave-uniform
+                const int nt = t / ktiles, kt = t - nt * ktiles;
+                const float *ap = ds + (lane >> 5) * NG + nt * 32 + (lane & 31);
+                const float *bp = xs + (lane >> 5) * KG + kt * 32 + (lane & 31);
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * NG], bp[2 * s * KG], acc[j], 0, 0, 0);
+            }
+        }
+        if (dbias && blockIdx.y == 0 && wave == 0) {
+            if (lane < NG) { for (int r = 0; r < 32; ++r) bsum0 += ds[r * NG + lane]; }
+            if (lane + 64 < NG) { for (int r = 0; r < 32; ++r) bsum1 += ds[r * NG + lane + 64]; }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = wave + 4 * j;
+        if (t >= total_tiles) continue;
+        const int nt = t / ktiles, kt = t - nt * ktiles;
+        const int32_t k = k_base + kt * 32 + (lane & 31);
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int32_t n = n_base + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < N) __hip_atomic_fetch_add(dw + (int64_t)n * K + k, acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (dbias && blockIdx.y == 0 && wave == 0) {
+        if (lane < NG && n_base + lane < N) __hip_atomic_fetch_add(dbias + n_base + lane, bsum0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane + 64 < NG && n_base + lane + 64 < N) __hip_atomic_fetch_add(dbias + n_base + lane + 64, bsum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,
+                         int64_t ldy, int64_t M, int32_t N, int32_t K, int act, hipStream_t st) {
+    const uint32_t gx = (uint32_t)ceil_div(M, kBM);
+    if (N <= 16) {
+        hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3(gx, (uint32_t)ceil_div(N, 16)), dim3(256), 0, st, x, ldx, w, sbj, sbk, bias, y,
+                           ldy, M, N, K, act);
+    } else {
+        hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(gx, (uint32_t)ceil_div(N, 64)), dim3(256), 0, st, x, ldx, w, sbj, sbk, bias, y,
+                           ldy, M, N, K, act);
+    }
+    return check_launch("linear");
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_linear_fwd(const float *x, int64_t ldx, const float *w, const float *bias, float *y, int64_t ldy,
+                               int64_t m, int32_t n, int32_t k, int act, void *stream) {
+    EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "linear_fwd: bad sizes m=%lld n=%d k=%d", (long long)m, n, k);
+    if (m == 0) return EMER_OK;
+    EMER_REQUIRE(x && w && y, "linear_fwd: null pointer");
+    EMER_REQUIRE(ldx >= k && ldy >= n, "linear_fwd: leading dimension smaller than the row");
+    EMER_REQUIRE(act >= EMER_ACT_NONE && act <= EMER_ACT_TRUNC_EXP, "linear_fwd: unknown activation %d", act);
+    return launch_linear(x, ldx, w, k, 1, bias, y, ldy, m, n, k, act, as_stream(stream));
+}
+
+extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x, int64_t ldx,
+                               const float *w, float *dpre_ws, float *dx, int64_t lddx, float *dw, float *dbias, int64_t m,
+                               int32_t n, int32_t k, int act, void *stream) {
+    EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "linear_bwd: bad sizes m=%lld n=%d k=%d", (long long)m, n, k);
+    if (m == 0) return EMER_OK;
+    EMER_REQUIRE(dy && dpre_ws, "linear_bwd: null pointer");
+    EMER_REQUIRE(act >= EMER_ACT_NONE && act <= EMER_ACT_TRUNC_EXP, "linear_bwd: unknown activation %d", act);
+    EMER_REQUIRE(act == EMER_ACT_NONE || y, "linear_bwd: saved output y required for a non-linear activation");
+    hipStream_t st = as_stream(stream);
+    {
+        const int64_t total = m * n;
+        const uint32_t blocks = (uint32_t)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, y ? y : dy, y ? ldy : lddy, dpre_ws, m, n, act);
+        if (int rc = check_launch("act_bwd")) return rc;
+    }
+    if (dx) {
+        EMER_REQUIRE(w && lddx >= k, "linear_bwd: dx requested but w missing or lddx too small");
+        // dX[M,K] = dPre[M,N] @ W[N,K]: a linear with reduction dim N and b(j=k, kk=n) = W[n*K + k]
+        if (int rc = launch_linear(dpre_ws, n, w, 1, k, nullptr, dx, lddx, m, k, n, EMER_ACT_NONE, st)) return rc;
+    }
+    if (dw) {
+        EMER_REQUIRE(x && ldx >= k, "linear_bwd: dw requested but x missing or ldx too small");
+        const int32_t NG = n <= 32 ? 32 : (n <= 64 ? 64 : 128);
+        const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
+        const int32_t tiles = (NG / 32) * (KG / 32);
+        const int32_t tpw = (tiles + 3) / 4;
+        const int32_t rows_per_block = 4096;
+        const dim3 grid((uint32_t)ceil_div(m, rows_per_block), (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
+        const size_t lds = (size_t)32 * (NG + KG) * sizeof(float);
+#define EMER_DW(T) hipLaunchKernelGGL(linear_dw_kernel<T>, grid, dim3(256), lds, st, dpre_ws, x, ldx, dw, dbias, m, n, k, rows_per_block, NG, KG)
+        if (tpw <= 1) EMER_DW(1);
+        else if (tpw <= 2) EMER_DW(2);
+        else if (tpw <= 4) EMER_DW(4);
+        else EMER_DW(8);
+#undef EMER_DW
+        if (int rc = check_launch("linear_dw")) return rc;
+    }
+    return EMER_OK;
+}

@@ -1,0 +1,108 @@
+// Proposal-network importance sampler for gfx950.
+//
+// Replaces nerfacc.pdf.importance_sampling (batched mode) and _transform_stot as called from
+// third_party/nerfacc_prop_net.py:153-157,172-173.  Frozen spec: SURVEY.md Appendix A.2; CPU
+// restatement: oracle/emer_oracle.c (orc_importance_sample / orc_stot).
+//
+// BIT-EXACTNESS: sample offsets must match the oracle bit for bit, so this translation unit
+// forbids FMA contraction (the oracle is built with -ffp-contract=off) and uses only IEEE
+// + - * / on fp32 (hipcc's default fp32 division is correctly rounded).
+//
+// Mapping: one 64-lane wavefront owns one ray.  The ray's m (<= 4096) CDF edges are staged once
+// into a wave-private LDS slice with coalesced loads; each lane then inverts the CDF for outputs
+// k = lane, lane+64, ... with a branch-free binary search over LDS.  No cross-lane traffic, no
+// atomics; output stores are coalesced (consecutive lanes -> consecutive k).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace emer {
+
+__host__ __device__ __forceinline__ float stot_fwd_map(int type, float t) {
+    if (type == EMER_STOT_UNIFORM_LINDISP) return t < 200.0f ? t / 400.0f : 1.0f - 1.0f / (2.0f * t / 200.0f);
+    if (type == EMER_STOT_LINDISP) return 1.0f / t;
+    return t;
+}
+__device__ __forceinline__ float stot_inv_map(int type, float s) {
+    if (type == EMER_STOT_UNIFORM_LINDISP) return s < 0.5f ? s * 400.0f : 200.0f / (2.0f - 2.0f * s);
+    if (type == EMER_STOT_LINDISP) return 1.0f / s;
+    return s;
+}
+__device__ __forceinline__ float stot_apply(int type, float s, float s_min, float s_max) {
+    return stot_inv_map(type, s * s_max + (1.0f - s) * s_min);
+}
+
+constexpr int kRaysPerBlock = 4;  // 4 waves per workgroup
+
+__global__ __launch_bounds__(256) void importance_sample_kernel(const float *__restrict__ vals, const float *__restrict__ cdfs,
+                                                                int64_t R, int32_t m, int32_t n,
+                                                                const float *__restrict__ jitter, float *__restrict__ s_out,
+                                                                float *__restrict__ t_out, float s_min, float s_max, int type) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wave;
+    float *c = smem + (size_t)wave * 2 * m, *v = c + m;
+    if (r < R) {
+        for (int i = lane; i < m; i += kWave) { c[i] = cdfs[r * m + i]; v[i] = vals[r * m + i]; }
+    }
+    __syncthreads();
+    if (r >= R) return;
+    const float c0 = c[0], cl = c[m - 1];
+    const float step = (cl - c0) / (float)(n + 1);
+    const float beta = jitter ? jitter[r] : 0.5f;
+    for (int k = lane; k <= n; k += kWave) {
+        const float u = c0 + ((float)k + beta) * step;
+        int lo = 0, hi = m;  // first j with c[j] > u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        int p = lo - 1;
+        p = p < 0 ? 0 : p;
+        p = p > m - 2 ? m - 2 : p;
+        const float cp = c[p], cq = c[p + 1], vp = v[p], vq = v[p + 1];
+        const float d = cq - cp;
+        float s;
+        if (d < 1e-10f) s = (vp + vq) * 0.5f;
+        else s = (u - cp) * ((vq - vp) / d) + vp;
+        const int64_t o = r * (int64_t)(n + 1) + k;
+        s_out[o] = s;
+        if (t_out) t_out[o] = stot_apply(type, s, s_min, s_max);
+    }
+}
+
+__global__ __launch_bounds__(256) void stot_kernel(const float *__restrict__ s, int64_t n, float s_min, float s_max, int type,
+                                                   float *__restrict__ t) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        t[i] = stot_apply(type, s[i], s_min, s_max);
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_importance_sample(const float *vals, const float *cdfs, int64_t R, int32_t m, int32_t n,
+                                      const float *jitter, float *s_out, float *t_out, float t_min, float t_max,
+                                      int stot_type, void *stream) {
+    EMER_REQUIRE(R >= 0 && n >= 1, "importance_sample: bad sizes R=%lld n=%d", (long long)R, n);
+    EMER_REQUIRE(m >= 2 && m <= 4096, "importance_sample: m=%d edges per ray not in 2..4096", m);
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(vals && cdfs && s_out, "importance_sample: null pointer");
+    EMER_REQUIRE(stot_type >= 0 && stot_type <= 2, "importance_sample: unknown stot_type %d", stot_type);
+    const float s_min = stot_fwd_map(stot_type, t_min), s_max = stot_fwd_map(stot_type, t_max);
+    const size_t lds = (size_t)kRaysPerBlock * 2 * m * sizeof(float);
+    hipLaunchKernelGGL(importance_sample_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlock)), dim3(256), lds, as_stream(stream),
+                       vals, cdfs, R, m, n, jitter, s_out, t_out, s_min, s_max, stot_type);
+    return check_launch("importance_sample");
+}
+
+extern "C" int emer_stot(const float *s, int64_t n, float t_min, float t_max, int stot_type, float *t, void *stream) {
+    EMER_REQUIRE(n >= 0, "stot: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(s && t, "stot: null pointer");
+    EMER_REQUIRE(stot_type >= 0 && stot_type <= 2, "stot: unknown stot_type %d", stot_type);
+    const float s_min = stot_fwd_map(stot_type, t_min), s_max = stot_fwd_map(stot_type, t_max);
+    const uint32_t blocks = (uint32_t)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
+    hipLaunchKernelGGL(stot_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s, n, s_min, s_max, stot_type, t);
+    return check_launch("stot");
+}

@@ -1,0 +1,330 @@
+"""torch.autograd wrappers over the C-ABI kernels (PyTorch here is plumbing: device memory, streams,
+autograd bookkeeping).  Every op launches hand-written HIP through ``_lib.call``; nothing in this
+module computes on the CPU or through torch math, so a missing extension fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TRUNC_EXP, F16, F32, GridDesc, STOT_TYPES
+
+_ACTS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "trunc_exp": ACT_TRUNC_EXP}
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check_cuda(*ts: Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EmerError("emernerf_amd ops need GPU (HIP) tensors; there is no CPU fallback")
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _dtype_tag(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise _lib.EmerError(f"unsupported table dtype {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------ hash grid
+def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True) -> Tensor:
+    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32."""
+    _check_cuda(x, params)
+    N, L, F = x.shape[0], desc.n_levels, desc.n_features
+    assert x.shape[1] == desc.n_dims and params.numel() == desc.n_entries * F
+    with torch.cuda.device(x.device):
+        if level_major:
+            out = torch.empty((L, N, F), device=x.device, dtype=torch.float32)
+            sn, sl = F, N * F
+        else:
+            out = torch.empty((N, L * F), device=x.device, dtype=torch.float32)
+            sn, sl = L * F, F
+        _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl, N,
+                  _stream(x))
+    return out
+
+
+def layout_transpose(src: Tensor, L: int, N: int, F: int, to_row_major: bool) -> Tensor:
+    _check_cuda(src)
+    with torch.cuda.device(src.device):
+        dst = torch.empty((N, L * F) if to_row_major else (L, N, F), device=src.device, dtype=torch.float32)
+        _lib.call("emer_layout_transpose", _ptr(src), _ptr(dst), L, N, F, int(to_row_major), _stream(src))
+    return dst
+
+
+class _HashGridFn(torch.autograd.Function):
+    """tcnn ``_module_function`` (third_party/tcnn_modules.py:115-174) on HIP.
+
+    The grid kernels run level-major (coalesced); the row-major [N, L*F] tensor the reference API
+    returns is produced / consumed through the LDS transpose kernel.
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype):
+        xc, pc = _f32c(x), params.detach().contiguous()
+        N, L, F = xc.shape[0], desc.n_levels, desc.n_features
+        lm = hashgrid_fwd_raw(desc, xc, pc, level_major=True)
+        out = layout_transpose(lm, L, N, F, to_row_major=True)
+        ctx.desc, ctx.grad_dtype = desc, grad_dtype
+        ctx.save_for_backward(xc, pc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        xc, pc = ctx.saved_tensors
+        desc = ctx.desc
+        N, L, F = xc.shape[0], desc.n_levels, desc.n_features
+        dx = dp = None
+        with torch.cuda.device(xc.device):
+            dlm = layout_transpose(_f32c(dout), L, N, F, to_row_major=False)
+            st = _stream(xc)
+            if ctx.needs_input_grad[1]:
+                gdt = ctx.grad_dtype or torch.float32
+                grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
+                _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
+                          _dtype_tag(grad), N, st)
+                dp = grad.to(pc.dtype) if grad.dtype != pc.dtype else grad
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(xc)
+                _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,
+                          N * F, _ptr(dx), N, st)
+        return dx, dp, None, None
+
+
+def hashgrid_encode(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:
+    """x [N,D] in [0,1] -> [N, L*F] fp32, differentiable w.r.t. params and x."""
+    return _HashGridFn.apply(x, params, desc, grad_dtype)
+
+
+# ------------------------------------------------------------------------------ contraction
+class _ContractFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos: Tensor, aabb: Tensor, unbounded: bool):
+        pc = _f32c(pos).view(-1, 3)
+        ab = _f32c(aabb).view(-1)
+        with torch.cuda.device(pc.device):
+            out = torch.empty_like(pc)
+            _lib.call("emer_contract_fwd", _ptr(pc), _ptr(ab), int(unbounded), _ptr(out), pc.shape[0], _stream(pc))
+        ctx.save_for_backward(pc, ab)
+        ctx.unbounded, ctx.shape = unbounded, pos.shape
+        return out.view(pos.shape)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        pc, ab = ctx.saved_tensors
+        dc = _f32c(dout).view(-1, 3)
+        with torch.cuda.device(pc.device):
+            dpos = torch.empty_like(pc)
+            _lib.call("emer_contract_bwd", _ptr(pc), _ptr(ab), int(ctx.unbounded), _ptr(dc), _ptr(dpos), pc.shape[0],
+                      _stream(pc))
+        return dpos.view(ctx.shape), None, None
+
+
+def contract_points(pos: Tensor, aabb: Tensor, unbounded: bool) -> Tensor:
+    """contract() + selector zeroing (nerf_utils.py:13-28, radiance_field.py:278-300)."""
+    _check_cuda(pos, aabb)
+    return _ContractFn.apply(pos, aabb, unbounded)
+
+
+def ray_points(origins: Tensor, dirs: Tensor, t_starts: Tensor, t_ends: Tensor, aabb: Tensor, unbounded: bool,
+               times: Optional[Tensor] = None, want_positions: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """Sample positions along rays, contracted (no grad: sample positions never carry grad,
+    nerfacc_prop_net.py:89).  Returns (normed [R,S,3|4], positions [R,S,3] | None)."""
+    _check_cuda(origins, dirs, t_starts, t_ends, aabb)
+    R, S = t_starts.shape
+    o, d, ts, te, ab = _f32c(origins), _f32c(dirs), _f32c(t_starts), _f32c(t_ends), _f32c(aabb).view(-1)
+    tm = None if times is None else _f32c(times).view(-1)
+    od = 3 if tm is None else 4
+    with torch.cuda.device(o.device):
+        normed = torch.empty((R, S, od), device=o.device, dtype=torch.float32)
+        pos = torch.empty((R, S, 3), device=o.device, dtype=torch.float32) if want_positions else None
+        _lib.call("emer_ray_points", _ptr(o), _ptr(d), _ptr(ts), _ptr(te), _ptr(tm), _ptr(ab), int(unbounded), _ptr(normed),
+                  od, _ptr(pos), R, S, _stream(o))
+    return normed, pos
+
+
+# ---------------------------------------------------------------------------------- sampler
+def importance_sample(vals: Tensor, cdfs: Tensor, n_intervals: int, jitter: Optional[Tensor] = None,
+                      stot: Optional[Tuple[float, float, str]] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """nerfacc.pdf.importance_sampling (batched).  Returns (s_edges [R,n+1], t_edges | None)."""
+    _check_cuda(vals, cdfs)
+    v, c = _f32c(vals), _f32c(cdfs)
+    R, m = v.shape
+    j = None if jitter is None else _f32c(jitter).view(-1)
+    if j is not None:
+        assert j.numel() == R
+    with torch.cuda.device(v.device):
+        s_out = torch.empty((R, n_intervals + 1), device=v.device, dtype=torch.float32)
+        t_out = torch.empty_like(s_out) if stot is not None else None
+        t_min, t_max, typ = stot if stot is not None else (0.0, 1.0, "uniform")
+        _lib.call("emer_importance_sample", _ptr(v), _ptr(c), R, m, n_intervals, _ptr(j), _ptr(s_out), _ptr(t_out),
+                  float(t_min), float(t_max), STOT_TYPES[typ], _stream(v))
+    return s_out, t_out
+
+
+def stot(s: Tensor, t_min: float, t_max: float, transform_type: str) -> Tensor:
+    _check_cuda(s)
+    sc = _f32c(s)
+    with torch.cuda.device(sc.device):
+        t = torch.empty_like(sc)
+        _lib.call("emer_stot", _ptr(sc), sc.numel(), float(t_min), float(t_max), STOT_TYPES[transform_type], _ptr(t),
+                  _stream(sc))
+    return t
+
+
+# ------------------------------------------------------------------------------- compositing
+class _RenderWeightsFn(torch.autograd.Function):
+    """(weights, trans, alphas, cdfs, ray_stats) from density; grads flow to sigma only."""
+
+    @staticmethod
+    def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigma: Tensor):
+        ctx.set_materialize_grads(False)
+        ts, te, sg = _f32c(t_starts), _f32c(t_ends), _f32c(sigma)
+        R, S = sg.shape
+        with torch.cuda.device(sg.device):
+            w, T, a = (torch.empty_like(sg) for _ in range(3))
+            cdfs = torch.empty((R, S + 1), device=sg.device, dtype=torch.float32)
+            stats = torch.empty((R, 4), device=sg.device, dtype=torch.float32)
+            _lib.call("emer_render_weights_fwd", _ptr(ts), _ptr(te), _ptr(sg), R, S, _ptr(w), _ptr(T), _ptr(a), _ptr(cdfs),
+                      _ptr(stats), _stream(sg))
+        ctx.save_for_backward(ts, te, sg)
+        ctx.mark_non_differentiable(a)
+        return w, T, a, cdfs, stats
+
+    @staticmethod
+    def backward(ctx, dw, dT, da, dcdfs, dstats):
+        ts, te, sg = ctx.saved_tensors
+        R, S = sg.shape
+        gT = None
+        if dT is not None:
+            gT = _f32c(dT)
+        if dcdfs is not None:  # cdfs = 1 - [T, 0]
+            g = -_f32c(dcdfs)[:, :S]
+            gT = g.contiguous() if gT is None else gT + g
+        gw = None if dw is None else _f32c(dw)
+        gs = None if dstats is None else _f32c(dstats)[:, :2].contiguous()
+        if gw is None and gT is None and gs is None:
+            return None, None, None
+        with torch.cuda.device(sg.device):
+            dsig = torch.empty_like(sg)
+            _lib.call("emer_render_weights_bwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(gw), _ptr(gT), _ptr(gs), R, S, _ptr(dsig),
+                      _stream(sg))
+        return None, None, dsig
+
+
+def render_weights(t_starts: Tensor, t_ends: Tensor, sigma: Tensor):
+    """Returns (weights, trans, alphas, cdfs [R,S+1], ray_stats [R,4] = (sum w, sum w*mid, median_depth, 0))."""
+    _check_cuda(t_starts, t_ends, sigma)
+    return _RenderWeightsFn.apply(t_starts, t_ends, sigma)
+
+
+class _AccumulateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights: Tensor, values: Optional[Tensor]):
+        w = _f32c(weights)
+        R, S = w.shape
+        v = None if values is None else _f32c(values)
+        C = 1 if v is None else v.shape[-1]
+        with torch.cuda.device(w.device):
+            out = torch.empty((R, C), device=w.device, dtype=torch.float32)
+            _lib.call("emer_accumulate_fwd", _ptr(w), _ptr(v), R, S, C, _ptr(out), _stream(w))
+        ctx.save_for_backward(w, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        w, v = ctx.saved_tensors
+        R, S = w.shape
+        C = 1 if v is None else v.shape[-1]
+        g = _f32c(dout)
+        need_w, need_v = ctx.needs_input_grad[0], (v is not None and ctx.needs_input_grad[1])
+        with torch.cuda.device(w.device):
+            dw = torch.empty_like(w) if need_w else None
+            dv = torch.empty_like(v) if need_v else None
+            if need_w or need_v:
+                _lib.call("emer_accumulate_bwd", _ptr(w), _ptr(v), _ptr(g), R, S, C, _ptr(dw), _ptr(dv), _stream(w))
+        return dw, dv
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None) -> Tensor:
+    """nerfacc.accumulate_along_rays on dense (R,S)/(R,S,C) tensors -> (R,C)."""
+    _check_cuda(weights, values)
+    return _AccumulateFn.apply(weights, values)
+
+
+# ---------------------------------------------------------------------------------- MLP heads
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int):
+        lead = x.shape[:-1]
+        K = x.shape[-1]
+        x2 = _f32c(x).view(-1, K)
+        wc = _f32c(weight)
+        bc = None if bias is None else _f32c(bias)
+        M, N = x2.shape[0], wc.shape[0]
+        with torch.cuda.device(x2.device):
+            y = torch.empty((M, N), device=x2.device, dtype=torch.float32)
+            _lib.call("emer_linear_fwd", _ptr(x2), K, _ptr(wc), _ptr(bc), _ptr(y), N, M, N, K, act, _stream(x2))
+        ctx.save_for_backward(x2, wc, y)
+        ctx.act, ctx.lead, ctx.has_bias = act, lead, bias is not None
+        return y.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, wc, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = wc.shape[0]
+        g = _f32c(dy).view(M, N)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        with torch.cuda.device(x2.device):
+            ws = torch.empty((M, N), device=x2.device, dtype=torch.float32)
+            dx = torch.empty((M, K), device=x2.device, dtype=torch.float32) if need_x else None
+            dw = torch.zeros((N, K), device=x2.device, dtype=torch.float32) if (need_w or need_b) else None
+            db = torch.zeros((N,), device=x2.device, dtype=torch.float32) if need_b else None
+            _lib.call("emer_linear_bwd", _ptr(g), N, _ptr(y), N, _ptr(x2), K, _ptr(wc), _ptr(ws), _ptr(dx), K, _ptr(dw),
+                      _ptr(db), M, N, K, ctx.act, _stream(x2))
+        return (dx.view(*ctx.lead, K) if need_x else None), (dw if need_w else None), db, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tensor:
+    """act(x @ weight.T + bias) on the fp32 matrix cores; act in {None,'relu','sigmoid','trunc_exp'}."""
+    _check_cuda(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias, _ACTS[act])
+
+
+def dir_encode(dirs: Tensor, max_deg: int = 4) -> Tensor:
+    """SinusoidalEncoder(3, 0, max_deg) applied to (dirs+1)/2 (radiance_field.py:629; no grad)."""
+    _check_cuda(dirs)
+    d = _f32c(dirs).view(-1, 3)
+    width = 3 if max_deg == 0 else 3 * (1 + 2 * (max_deg + 1))
+    with torch.cuda.device(d.device):
+        out = torch.empty((d.shape[0], width), device=d.device, dtype=torch.float32)
+        _lib.call("emer_dir_encode", _ptr(d), _ptr(out), d.shape[0], max_deg, _stream(d))
+    return out.view(*dirs.shape[:-1], width)
+
+
+def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float, beta2: float,
+              eps: float, weight_decay: float, grad_scale: float, step: int) -> None:
+    """In-place torch.optim.Adam step on one flat fp32 buffer."""
+    _check_cuda(params, grads, exp_avg, exp_avg_sq)
+    assert params.is_contiguous() and grads.is_contiguous() and params.dtype == torch.float32
+    with torch.cuda.device(params.device):
+        _lib.call("emer_adam_step", _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), float(lr),
+                  float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), int(step), _stream(params))

@@ -1,0 +1,192 @@
+/*
+ * emernerf_hip.h -- C ABI of libemernerf_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * This is the drop-in boundary of the EmerNeRF volumetric-rendering hot path.  Each entry point
+ * replaces one native call the reference makes into tiny-cuda-nn / nerfacc / cuBLAS-via-torch;
+ * the reference interface it replaces is cited next to it (paths relative to /root/reference).
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns every buffer (the library never allocates device memory, never syncs);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are enqueued on it;
+ *   - return 0 on success, a negative EMER_E_* code on failure; emer_last_error() gives the text;
+ *   - re-entrant across streams/devices (no mutable globals except the thread-local error string).
+ */
+#ifndef EMERNERF_HIP_H
+#define EMERNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMER_MAX_LEVELS 32
+
+#define EMER_OK 0
+#define EMER_E_INVALID (-1)  /* bad argument / unsupported configuration */
+#define EMER_E_LAUNCH (-2)   /* hipLaunchKernel failed                   */
+
+/* dtype tags for table / gradient storage */
+#define EMER_F32 0
+#define EMER_F16 1
+
+/* activation tags (epilogues of emer_linear_*) */
+#define EMER_ACT_NONE 0
+#define EMER_ACT_RELU 1
+#define EMER_ACT_SIGMOID 2
+#define EMER_ACT_TRUNC_EXP 3 /* y = exp(x - 1); bwd g*min(y, e^15)  (nerf_utils.py:59-75, radiance_field.py:28) */
+
+/* s->t transforms (third_party/nerfacc_prop_net.py:299-315) */
+#define EMER_STOT_UNIFORM 0
+#define EMER_STOT_UNIFORM_LINDISP 1
+#define EMER_STOT_LINDISP 2
+
+const char *emer_last_error(void);
+int emer_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multiresolution hash grid (replaces tcnn.Encoding{otype: HashGrid}:
+ *   radiance_fields/encodings.py:133-160, third_party/tcnn_modules.py:122 (fwd), :161-163 (bwd),
+ *   :420-423 (_C.create_encoding)).  Level table rules: SURVEY.md Appendix A.1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct emer_grid_desc {
+    uint32_t n_dims;            /* D: 2..4                                  */
+    uint32_t n_levels;          /* L <= EMER_MAX_LEVELS                     */
+    uint32_t n_features;        /* F: 1, 2, 4 or 8                          */
+    uint32_t log2_hashmap_size; /* T                                        */
+    uint32_t base_resolution;
+    float per_level_scale;
+    float scale[EMER_MAX_LEVELS];
+    uint32_t res[EMER_MAX_LEVELS];
+    uint32_t size[EMER_MAX_LEVELS];   /* entries in the level                */
+    uint32_t offset[EMER_MAX_LEVELS]; /* first entry of the level            */
+    uint32_t hashed[EMER_MAX_LEVELS]; /* 1 -> coherent-prime hash, 0 -> dense */
+    uint32_t n_entries;               /* n_params = n_entries * n_features   */
+} emer_grid_desc;
+
+/* Host-only: fill the level table (replaces _C.create_encoding + native.n_params()). */
+int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_levels,
+                        uint32_t n_features, uint32_t log2_hashmap_size, uint32_t base_resolution,
+                        float per_level_scale);
+
+/* Encode.  x [N,D] f32 in [0,1]; params flat (level, entry, feature), dtype param_dtype.
+ * out element (n, l, f) is written at out[n*out_stride_n + l*out_stride_l + f] (f32):
+ *   row-major [N, L*F] (the reference's layout): stride_n = L*F, stride_l = F;
+ *   level-major [L][N][F] (coalesced, what the fused heads read): stride_n = F, stride_l = N*F.
+ * Replaces native.fwd (tcnn_modules.py:122). */
+int emer_hashgrid_fwd(const emer_grid_desc *host_desc, const float *x, const void *params,
+                      int param_dtype, float *out, int64_t out_stride_n, int64_t out_stride_l,
+                      int64_t n, void *stream);
+
+/* dParams[l, idx, f] += w_corner * dOut[n, l, f]  (atomic scatter; grad is NOT zeroed here).
+ * grad dtype: EMER_F32 (f32 atomics) or EMER_F16 (packed half2 atomics, F even).
+ * Replaces the params path of native.bwd (tcnn_modules.py:161-163). */
+int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, const float *dout,
+                             int64_t dout_stride_n, int64_t dout_stride_l, void *grad,
+                             int grad_dtype, int64_t n, void *stream);
+
+/* dX[n, d] = sum_l scale_l sum_f dOut * d(interp)/dx.  Replaces the input path of native.bwd
+ * (needed by the flow configs, radiance_fields/radiance_field.py:572-608). */
+int emer_hashgrid_bwd_input(const emer_grid_desc *host_desc, const float *x, const void *params,
+                            int param_dtype, const float *dout, int64_t dout_stride_n,
+                            int64_t dout_stride_l, float *dx, int64_t n, void *stream);
+
+/* Layout glue: level-major [L][N][F] <-> row-major [N, L*F] (the layout tcnn_modules.py:263 returns).
+ * to_row_major != 0: src is level-major, dst row-major; 0: the reverse.  src != dst. */
+int emer_layout_transpose(const float *src, float *dst, int32_t n_levels, int64_t n,
+                          int32_t n_features, int to_row_major, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene contraction + ray sample points
+ *   (radiance_fields/nerf_utils.py:13-28, radiance_field.py:278-300 and :828-835,
+ *    render_utils.py:316-318,341).
+ * ---------------------------------------------------------------------------------------------- */
+/* out = contract(pos) with rows outside (0,1)^3 zeroed.  aabb: 6 floats (device). */
+int emer_contract_fwd(const float *pos, const float *aabb, int unbounded, float *out, int64_t n,
+                      void *stream);
+/* dpos = J^T dout (zero for rejected rows). */
+int emer_contract_bwd(const float *pos, const float *aabb, int unbounded, const float *dout,
+                      float *dpos, int64_t n, void *stream);
+/* positions[r,s,:] = origins[r] + dirs[r] * (t_starts[r,s] + t_ends[r,s]) / 2, then contract.
+ * Writes normed [R*S, out_dim] (out_dim 3, or 4 with times[r] appended as the 4th column);
+ * positions_out (optional, may be NULL) receives the un-contracted world positions [R*S,3]. */
+int emer_ray_points(const float *origins, const float *dirs, const float *t_starts,
+                    const float *t_ends, const float *times, const float *aabb, int unbounded,
+                    float *normed, int out_dim, float *positions_out, int64_t n_rays,
+                    int32_t n_samples, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Proposal sampler (replaces nerfacc.pdf.importance_sampling + _transform_stot:
+ *   third_party/nerfacc_prop_net.py:153,156,172-173,299-339).  Frozen spec: SURVEY.md A.2.
+ * ---------------------------------------------------------------------------------------------- */
+/* vals/cdfs [R,m] -> s_out [R,n+1] (sorted edges in s) and, if t_out != NULL, t_out = stot(s_out).
+ * jitter: NULL (centre of bin) or [R] U(0,1) per ray (stratified). Bit-exact vs the oracle. */
+int emer_importance_sample(const float *vals, const float *cdfs, int64_t n_rays, int32_t m,
+                           int32_t n_intervals, const float *jitter, float *s_out, float *t_out,
+                           float t_min, float t_max, int stot_type, void *stream);
+int emer_stot(const float *s, int64_t n, float t_min, float t_max, int stot_type, float *t,
+              void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense volume rendering (replaces nerfacc.render_transmittance_from_density /
+ *   render_weight_from_density / accumulate_along_rays on (R,S) tensors:
+ *   radiance_fields/render_utils.py:35-43,73-77,103-115,159-282; nerfacc_prop_net.py:165-168).
+ * ---------------------------------------------------------------------------------------------- */
+/* Per ray: sigma_dt = sigma*(t_end-t_start); T = exp(-excl_cumsum); alpha = 1-exp(-sigma_dt);
+ * w = T*alpha.  Any of weights/trans/alphas/cdfs/ray_stats may be NULL.
+ *   cdfs [R,S+1]  = 1 - [T, 0]                        (nerfacc_prop_net.py:166-168)
+ *   ray_stats [R,4] = (sum w, sum w*mid, median_depth, reserved), mid = (t_start+t_end)/2;
+ *   median_depth follows render_utils.py:107-115 (first s with cumsum(w) >= 0.5, clamped). */
+int emer_render_weights_fwd(const float *t_starts, const float *t_ends, const float *sigma,
+                            int64_t n_rays, int32_t n_samples, float *weights, float *trans,
+                            float *alphas, float *cdfs, float *ray_stats, void *stream);
+/* Given dL/dweights, dL/dtrans (either may be NULL) and dL/d(sum w), dL/d(sum w*mid) per ray
+ * (d_ray_stats [R,2], may be NULL) produce dL/dsigma. */
+int emer_render_weights_bwd(const float *t_starts, const float *t_ends, const float *sigma,
+                            const float *d_weights, const float *d_trans, const float *d_ray_stats,
+                            int64_t n_rays, int32_t n_samples, float *d_sigma, void *stream);
+/* out[r,c] = sum_s w[r,s] * values[r,s,c]   (values == NULL: C = 1, out[r] = sum_s w). */
+int emer_accumulate_fwd(const float *weights, const float *values, int64_t n_rays,
+                        int32_t n_samples, int32_t n_channels, float *out, void *stream);
+/* d_weights[r,s] (+)= sum_c d_out[r,c]*values[r,s,c]; d_values[r,s,c] = w[r,s]*d_out[r,c]. */
+int emer_accumulate_bwd(const float *weights, const float *values, const float *d_out,
+                        int64_t n_rays, int32_t n_samples, int32_t n_channels, float *d_weights,
+                        float *d_values, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small MLP heads (replaces the torch.nn.Linear / ReLU / Sigmoid / trunc_exp chains of
+ *   radiance_fields/radiance_field.py:74-198 and radiance_fields/mlp.py:7-46, i.e. cuBLAS GEMM +
+ *   elementwise launches).  fp32-exact MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain.
+ * ---------------------------------------------------------------------------------------------- */
+/* Y[M,N] = act(X[M,K] @ W[N,K]^T + bias[N]).  ldx/ldy: row strides (elements).  W row-major
+ * [N,K] (torch Linear layout).  bias may be NULL. */
+int emer_linear_fwd(const float *x, int64_t ldx, const float *w, const float *bias, float *y,
+                    int64_t ldy, int64_t m, int32_t n, int32_t k, int act, void *stream);
+/* Backward of the above.  dy [M,N] (ld ldy), y [M,N] = saved forward output (for act').
+ *   dpre = dy * act'(y)                     (written to dpre_ws [M,N], contiguous workspace)
+ *   dx [M,K] = dpre @ W                     (skipped when dx == NULL)
+ *   dw [N,K] += dpre^T @ X ; dbias [N] += column sums of dpre   (skipped when dw == NULL) */
+int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x,
+                    int64_t ldx, const float *w, float *dpre_ws, float *dx, int64_t lddx,
+                    float *dw, float *dbias, int64_t m, int32_t n, int32_t k, int act,
+                    void *stream);
+
+/* Direction encoding used by the rgb / sky heads: d -> (d+1)/2 -> [x, sin(2^i x), sin(2^i x + pi/2)]
+ * i = 0..max_deg (radiance_fields/encodings.py:60-104, radiance_field.py:629-632).
+ * dirs [n,3] -> out [n, 3*(1+2*(max_deg+1))]. */
+int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer (torch.optim.Adam as configured in builders.py:50-60,114-120: eps 1e-15,
+ * betas (0.9, 0.99), weight_decay as L2) over one flat fp32 buffer; grad_scale multiplies the
+ * gradient first (1/world_size after the RCCL all-reduce; GradScaler quirk).
+ * ---------------------------------------------------------------------------------------------- */
+int emer_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, int32_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMERNERF_HIP_H */

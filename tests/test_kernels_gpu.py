@@ -1,0 +1,358 @@
+"""Kernel-level parity: every C-ABI entry point vs the CPU oracle on seeded inputs (MI355X only).
+
+Tolerances: sampler offsets bit-exact; everything else fp32 with the tolerance written at the check.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = {
+    # name: (D, L, base, max, log2T, F)
+    "cfg2_static": (3, 16, 16, 2048, 19, 2),       # HashEncoder defaults, encodings.py:110-118
+    "default_static": (3, 10, 16, 8192, 20, 4),    # default_config.yaml:62-69
+    "dynamic_xyzt": (4, 10, 32, 8192, 18, 4),      # default_config.yaml:70-77
+    "flow_xyzt": (4, 10, 16, 4096, 18, 4),         # radiance_field.py:916-923
+    "prop0": (3, 8, 16, 512, 20, 1),               # default_config.yaml:51-58
+    "tiny_f8": (3, 4, 4, 64, 10, 8),
+    "tiny_2d": (2, 5, 8, 256, 12, 2),
+}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _mk(oracle, name):
+    from emernerf_amd import _lib
+    D, L, base, mx, T, F = GRIDS[name]
+    meta = oracle.grid_meta_from_encoder_args(D, L, base, mx, T, F)
+    desc = _lib.make_grid_desc(D, L, F, T, base, meta.per_level_scale)
+    return meta, desc
+
+
+def _inputs(meta, n, seed, edge=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, meta.n_dims, generator=g)
+    if edge and n >= 8:  # edge cases the reference hits: zeroed rows, values next to 0 and 1
+        x[0] = 0.0
+        x[1] = 1.0 - 2 ** -24
+        x[2] = 2 ** -20
+        x[3] = 0.999
+        x[4, 0] = 0.9671  # level-0 corner wrap (res 16 -> c = 16)
+    p = torch.rand(meta.n_params, generator=g) - 0.5
+    return x, p
+
+
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_grid_desc_matches_oracle(hip_lib, oracle, name):
+    meta, desc = _mk(oracle, name)
+    L = meta.n_levels
+    assert desc.n_entries == meta.n_entries
+    assert np.array_equal(np.array(desc.scale[:L], np.float32).view(np.uint32), meta.scale.view(np.uint32))
+    for fld in ("res", "size", "offset", "hashed"):
+        assert np.array_equal(np.array(getattr(desc, fld)[:L], np.uint32), getattr(meta, fld))
+
+
+@pytest.mark.parametrize("name", list(GRIDS))
+@pytest.mark.parametrize("n", [1, 257, 5000])
+def test_hashgrid_fwd(hip_lib, oracle, name, n):
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    x, p = _inputs(meta, n, 1)
+    ref = oracle.hashgrid_fwd(meta, x, p)
+    dev = _dev()
+    lm = ops.hashgrid_fwd_raw(desc, x.to(dev), p.to(dev), level_major=True)
+    rm = ops.hashgrid_fwd_raw(desc, x.to(dev), p.to(dev), level_major=False)
+    L, F = meta.n_levels, meta.n_features
+    lm_as_rows = lm.permute(1, 0, 2).reshape(n, L * F).cpu().numpy()
+    # same fmaf cell + same corner order => only the FMA contraction of acc += w*v may differ
+    np.testing.assert_allclose(rm.cpu().numpy(), ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lm_as_rows, ref, rtol=0, atol=2e-6)
+    tr = ops.layout_transpose(lm, L, n, F, to_row_major=True)
+    assert torch.equal(tr, rm)
+    back = ops.layout_transpose(tr, L, n, F, to_row_major=False)
+    assert torch.equal(back, lm)
+
+
+@pytest.mark.parametrize("name", ["cfg2_static", "dynamic_xyzt", "prop0", "tiny_f8", "tiny_2d"])
+def test_hashgrid_fp16_tables(hip_lib, oracle, name):
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    x, p = _inputs(meta, 3000, 2)
+    ph = p.half()
+    ref = oracle.hashgrid_fwd(meta, x, ph.float())  # oracle on the fp16-rounded table, fp32 accumulate
+    dev = _dev()
+    out = ops.hashgrid_fwd_raw(desc, x.to(dev), ph.to(dev), level_major=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_hashgrid_backward(hip_lib, oracle, name):
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    n = 4099
+    x, p = _inputs(meta, n, 3)
+    g = torch.Generator().manual_seed(4)
+    dout = torch.randn(n, meta.n_output_dims, generator=g)
+    dout[5] = 0.0  # exact-zero rows are skipped by the kernel
+    ref_dp = oracle.hashgrid_bwd_params(meta, x, dout)
+    ref_dx = oracle.hashgrid_bwd_input(meta, x, p, dout)
+    dev = _dev()
+    xd = x.to(dev).requires_grad_(True)
+    pd = p.to(dev).requires_grad_(True)
+    out = ops.hashgrid_encode(xd, pd, desc)
+    out.backward(dout.to(dev))
+    # fp32 atomics in arbitrary order vs double accumulation: error ~ sqrt(k) ulp of the partial sums
+    scale = np.abs(ref_dp).max()
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), ref_dp, rtol=0, atol=2e-5 * scale)
+    sx = np.abs(ref_dx).max()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), ref_dx, rtol=0, atol=2e-5 * sx)
+
+
+def test_hashgrid_fp16_grads(hip_lib, oracle):
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, "cfg2_static")
+    n = 2048
+    x, p = _inputs(meta, n, 5)
+    dout = torch.randn(n, meta.n_output_dims, generator=torch.Generator().manual_seed(6)) * 1e-2
+    ref = oracle.hashgrid_bwd_params(meta, x, dout)
+    dev = _dev()
+    pd = p.to(dev).requires_grad_(True)
+    out = ops.hashgrid_encode(x.to(dev), pd, desc, grad_dtype=torch.float16)
+    out.backward(dout.to(dev))
+    got = pd.grad.cpu().numpy()
+    # half2 atomics: each add rounds to fp16 (rel 2^-11); stated deviation from the fp32 path
+    assert np.abs(got - ref).max() <= 4e-3 * np.abs(ref).max() + 1e-6
+
+
+def test_hashgrid_errors(hip_lib):
+    from emernerf_amd import _lib
+    with pytest.raises(_lib.EmerError):
+        _lib.make_grid_desc(5, 4, 2, 19, 16, 1.5)
+    with pytest.raises(_lib.EmerError):
+        _lib.make_grid_desc(3, 4, 3, 19, 16, 1.5)
+
+
+@pytest.mark.parametrize("R,m,n", [(1, 2, 128), (37, 129, 64), (64, 65, 128), (5, 2, 1), (9, 300, 257)])
+@pytest.mark.parametrize("stratified", [False, True])
+def test_importance_sample_bit_exact(hip_lib, oracle, R, m, n, stratified):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(R * 1000 + m)
+    w = torch.rand(R, m - 1, generator=g) ** 4  # peaky histograms
+    w[0, : (m - 1) // 2] = 0.0  # flat CDF stretch (delta < 1e-10 branch)
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(w, -1)], -1)
+    cdf = cdf / cdf[:, -1:].clamp_min(1e-12)
+    if R > 2:
+        cdf[2] = cdf[2] * 0.6 + 0.1  # cdf_first != 0, cdf_last != 1
+    vals = torch.sort(torch.rand(R, m, generator=g), -1).values
+    jit = torch.rand(R, generator=g) if stratified else None
+    ref = oracle.importance_sample(vals, cdf, n, jit)
+    ref_t = oracle.stot(ref, 0.1, 1000.0, "uniform_lindisp")
+    dev = _dev()
+    s, t = ops.importance_sample(vals.to(dev), cdf.to(dev), n, None if jit is None else jit.to(dev),
+                                 stot=(0.1, 1000.0, "uniform_lindisp"))
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "sample offsets must be bit-exact"
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), ref_t.view(np.uint32)), "s->t must be bit-exact"
+    assert (np.diff(ref, axis=-1) >= 0).all()
+    for typ in ("uniform", "lindisp", "uniform_lindisp"):
+        a = ops.stot(s, 0.5, 300.0, typ).cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), oracle.stot(ref, 0.5, 300.0, typ).view(np.uint32))
+
+
+def _torch_render(ts, te, sg):
+    sdt = sg * (te - ts)
+    cum = torch.cumsum(sdt, -1)
+    excl = torch.cat([torch.zeros_like(cum[:, :1]), cum[:, :-1]], -1)
+    T = torch.exp(-excl)
+    a = 1 - torch.exp(-sdt)
+    return T * a, T, a
+
+
+@pytest.mark.parametrize("R,S", [(1, 1), (3, 64), (50, 128), (7, 130), (4, 333)])
+def test_render_weights(hip_lib, oracle, R, S):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(R + S)
+    edges = torch.sort(torch.rand(R, S + 1, generator=g) * 50 + 0.1, -1).values
+    ts, te = edges[:, :-1].contiguous(), edges[:, 1:].contiguous()
+    sg = torch.rand(R, S, generator=g) ** 3 * 2.0
+    w_ref, T_ref, a_ref = oracle.render_weights(ts, te, sg)
+    dev = _dev()
+    sgd = sg.to(dev).requires_grad_(True)
+    w, T, a, cdfs, stats = ops.render_weights(ts.to(dev), te.to(dev), sgd)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), w_ref, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(T.detach().cpu().numpy(), T_ref, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(a.cpu().numpy(), a_ref, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(cdfs.detach().cpu().numpy()[:, :S], 1 - T_ref, rtol=0, atol=2e-6)
+    assert (cdfs.detach().cpu().numpy()[:, S] == 1.0).all()
+    mid = ((ts + te) / 2).numpy()
+    np.testing.assert_allclose(stats[:, 0].detach().cpu().numpy(), w_ref.sum(-1), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(stats[:, 1].detach().cpu().numpy(), (w_ref * mid).sum(-1), rtol=2e-5, atol=1e-5)
+    # median depth (render_utils.py:107-115); tolerate a one-sample slip when cumsum sits on 0.5
+    cw = np.cumsum(w_ref, -1)
+    idx = np.minimum((cw < 0.5).sum(-1), S - 1)
+    med = stats[:, 2].detach().cpu().numpy()
+    ok = [np.isclose(med[r], mid[r, max(idx[r] - 1, 0):idx[r] + 2], rtol=1e-6).any() for r in range(R)]
+    assert all(ok)
+    # backward through weights, trans, cdfs and the per-ray sums vs torch autograd (fp64 on CPU)
+    gw, gT, gc = (torch.randn(R, S, generator=g), torch.randn(R, S, generator=g), torch.randn(R, S + 1, generator=g))
+    gs = torch.randn(R, 2, generator=g)
+    loss = (w * gw.to(dev)).sum() + (T * gT.to(dev)).sum() + (cdfs * gc.to(dev)).sum() + (stats[:, :2] * gs.to(dev)).sum()
+    loss.backward()
+    s64 = sg.double().requires_grad_(True)
+    w2, T2, _ = _torch_render(ts.double(), te.double(), s64)
+    c2 = 1 - torch.cat([T2, torch.zeros(R, 1, dtype=torch.double)], -1)
+    st2 = torch.stack([w2.sum(-1), (w2 * (ts + te).double() / 2).sum(-1)], -1)
+    ((w2 * gw).sum() + (T2 * gT).sum() + (c2 * gc).sum() + (st2 * gs).sum()).backward()
+    ref_g = s64.grad.numpy()
+    np.testing.assert_allclose(sgd.grad.cpu().numpy(), ref_g, rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
+
+
+@pytest.mark.parametrize("C", [None, 1, 3, 6, 64, 100])
+def test_accumulate(hip_lib, oracle, C):
+    from emernerf_amd import ops
+    R, S = 33, 128
+    g = torch.Generator().manual_seed(7)
+    w = torch.rand(R, S, generator=g)
+    v = None if C is None else torch.randn(R, S, C, generator=g)
+    ref = oracle.accumulate(w, v)
+    dev = _dev()
+    wd = w.to(dev).requires_grad_(True)
+    vd = None if v is None else v.to(dev).requires_grad_(True)
+    out = ops.accumulate_along_rays(wd, vd)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(dev))
+    if v is None:
+        np.testing.assert_allclose(wd.grad.cpu().numpy(), go.expand(R, S).numpy(), rtol=1e-6)
+    else:
+        np.testing.assert_allclose(wd.grad.cpu().numpy(), torch.einsum("rc,rsc->rs", go, v).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(vd.grad.cpu().numpy(), (w[..., None] * go[:, None, :]).numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("unbounded", [True, False])
+def test_contract(hip_lib, oracle, unbounded):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(8)
+    aabb = torch.tensor([-20.0, -40.0, 0.0, 80.0, 40.0, 20.0])
+    pos = (torch.rand(5000, 3, generator=g) - 0.5) * torch.tensor([400.0, 300.0, 100.0]) + torch.tensor([30.0, 0.0, 10.0])
+    pos[0] = torch.tensor([-20.0, 0.0, 5.0])  # on the aabb face -> contracted coordinate outside (0,1) when bounded
+    pos[1] = torch.tensor([1e6, -1e6, 3.0])
+    ref = oracle.contract(pos, aabb, unbounded)
+    dev = _dev()
+    pd = pos.to(dev).requires_grad_(True)
+    out = ops.contract_points(pd, aabb.to(dev), unbounded)
+    assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), ref.view(np.uint32)), "contraction is bit-exact"
+    go = torch.randn(5000, 3, generator=g)
+    out.backward(go.to(dev))
+    # torch autograd of the reference expression (nerf_utils.py:13-28 + radiance_field.py:294-299), fp64
+    p64 = pos.double().requires_grad_(True)
+    lo, hi = aabb[:3].double(), aabb[3:].double()
+    v = (p64 - lo) / (hi - lo)
+    if unbounded:
+        v = v * 2 - 1
+        mag = torch.linalg.norm(v, ord=float("inf"), dim=-1, keepdim=True)
+        v = torch.where(mag < 1, v, (2 - 1 / mag) * (v / mag))
+        v = v / 4 + 0.5
+    sel = torch.from_numpy((ref != 0).any(-1, keepdims=True)).double()  # selector of the fp32 path
+    (v * sel * go.double()).sum().backward()
+    ref_g = p64.grad.numpy()
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), ref_g, rtol=2e-4, atol=1e-6 * np.abs(ref_g).max())
+
+
+def test_ray_points(hip_lib, oracle):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(9)
+    R, S = 67, 128
+    o = torch.rand(R, 3, generator=g) * torch.tensor([60.0, 4.0, 1.0]) + torch.tensor([0.0, -2.0, 1.5])
+    d = torch.nn.functional.normalize(torch.tensor([1.0, 0, 0]) + 0.6 * torch.randn(R, 3, generator=g), dim=-1)
+    edges = torch.sort(torch.rand(R, S + 1, generator=g) * 300 + 0.1, -1).values
+    ts, te = edges[:, :-1].contiguous(), edges[:, 1:].contiguous()
+    aabb = torch.tensor([-20.0, -40.0, 0.0, 80.0, 40.0, 20.0])
+    times = torch.rand(R, generator=g)
+    pos_ref = (o[:, None, :] + d[:, None, :] * (ts + te)[..., None] / 2.0).numpy()  # render_utils.py:341
+    ref = oracle.contract(pos_ref, aabb, True)
+    dev = _dev()
+    n3, p3 = ops.ray_points(o.to(dev), d.to(dev), ts.to(dev), te.to(dev), aabb.to(dev), True, want_positions=True)
+    assert np.array_equal(p3.cpu().numpy().view(np.uint32), pos_ref.view(np.uint32)), "positions are bit-exact"
+    assert np.array_equal(n3.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    n4, _ = ops.ray_points(o.to(dev), d.to(dev), ts.to(dev), te.to(dev), aabb.to(dev), True, times=times.to(dev))
+    assert np.array_equal(n4[..., :3].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert torch.equal(n4[..., 3].cpu(), times[:, None].expand(R, S))
+
+
+def test_dir_encode(hip_lib):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(10)
+    d = torch.nn.functional.normalize(torch.randn(1000, 3, generator=g), dim=-1)
+    x = (d + 1.0) / 2.0
+    scales = torch.tensor([2.0 ** i for i in range(5)])
+    xb = (x[..., None, :] * scales[:, None]).reshape(1000, 15)  # encodings.py:95-103
+    ref = torch.cat([x, torch.sin(torch.cat([xb, xb + 0.5 * torch.pi], -1))], -1)
+    out = ops.dir_encode(d.to(_dev()), 4).cpu()
+    assert out.shape == (1000, 33)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [
+    (1000, 32, 64, "relu", True), (257, 64, 64, None, True), (4096, 113, 64, "relu", True),
+    (300, 177, 64, "relu", True), (513, 64, 3, "sigmoid", True), (129, 8, 64, "relu", True),
+    (777, 64, 1, "trunc_exp", True), (64, 40, 128, None, False), (100, 64, 6, None, True),
+    (50, 49, 64, "relu", True), (31, 256, 200, "relu", True),
+])
+def test_linear(hip_lib, M, K, N, act, bias):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1 if bias else None
+    dev = _dev()
+    xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    bd = None if b is None else b.to(dev).requires_grad_(True)
+    y = ops.linear(xd, Wd, bd, act)
+    x64, W64 = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    b64 = None if b is None else b.double().requires_grad_(True)
+    pre = torch.nn.functional.linear(x64, W64, b64)
+    ref = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "trunc_exp": lambda t: torch.exp(t - 1)}[act](pre)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    go = torch.randn(M, N, generator=g)
+    y.backward(go.to(dev))
+    ref.backward(go.double())
+    for got, want in ((xd.grad, x64.grad), (Wd.grad, W64.grad)) + (() if b is None else ((bd.grad, b64.grad),)):
+        want = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=2e-5 * np.abs(want).max())
+
+
+def test_linear_asymmetric_layout(hip_lib):
+    """A = I with an asymmetric W catches a transposed MFMA fragment (CDNA guide, G9)."""
+    from emernerf_amd import ops
+    dev = _dev()
+    K, N = 64, 64
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 251.0
+    y = ops.linear(torch.eye(K, device=dev), W.to(dev))
+    assert torch.equal(y.cpu(), W.t().contiguous())
+
+
+def test_adam_matches_torch(hip_lib):
+    from emernerf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))  # builders.py:54-60
+    dev = _dev()
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (0.1 if step != 3 else 0.0)
+        ref_p.grad = grad.clone()
+        opt.step()
+        ops.adam_step(p, (grad * 1024).to(dev), m, v, 0.01, 0.9, 0.99, 1e-15, 1e-5, 1.0 / 1024, step)
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_cpu_tensor_is_rejected(hip_lib):
+    from emernerf_amd import _lib, ops
+    with pytest.raises(_lib.EmerError):
+        ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
