@@ -41,6 +41,7 @@ SIGNATURES = {
     "emer_grid_desc_init": [_GP, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_float],
     "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, c_int64, _P],
     "emer_hashgrid_bwd_params": [_GP, _P, _P, c_int64, c_int64, _P, c_int, c_int64, _P],
+    "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
@@ -52,10 +53,12 @@ SIGNATURES = {
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
-    "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P],
+    "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P, _P],
     "emer_linear_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32,
-                        c_int32, c_int, _P],
-    "emer_dir_encode": [_P, _P, c_int64, c_int32, _P],
+                        c_int32, c_int, _P, _P, _P],
+    "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
+    "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
+    "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
     "emer_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, _P],
 }
 

@@ -124,13 +124,13 @@ __global__ __launch_bounds__(256) void ray_points_kernel(const float *__restrict
 // SinusoidalEncoder(min_deg=0, max_deg) on (d+1)/2 (encodings.py:86-104; radiance_field.py:629):
 //   out = [x (3), sin(2^i x_d) (i-major, 3 per degree), sin(2^i x_d + pi/2)]
 __global__ __launch_bounds__(256) void dir_encode_kernel(const float *__restrict__ dirs, float *__restrict__ out, int64_t n,
-                                                         int32_t max_deg) {
+                                                         int32_t max_deg, int remap) {
     const int32_t n_deg = max_deg + 1, width = 3 * (1 + 2 * n_deg);
     const float half_pi = 0.5f * 3.14159265358979323846f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float x[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) x[d] = (dirs[i * 3 + d] + 1.0f) / 2.0f;
+        for (int d = 0; d < 3; ++d) x[d] = remap ? (dirs[i * 3 + d] + 1.0f) / 2.0f : dirs[i * 3 + d];
         float *o = out + i * width;
         if (max_deg == 0) {  // encoder degenerates to identity when max_deg == min_deg (encodings.py:93-94)
             o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
@@ -204,6 +204,18 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(const float *__re
     }
 }
 
+
+// density_activation = trunc_exp(x - 1) (radiance_field.py:28, nerf_utils.py:59-75) on a strided column
+__global__ __launch_bounds__(256) void trunc_exp_fwd_kernel(const float *__restrict__ x, int64_t stride, float *__restrict__ y,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = expf(x[i * stride] - 1.0f);
+}
+__global__ __launch_bounds__(256) void trunc_exp_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                            float *__restrict__ dx, int64_t stride, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i * stride] = dy[i] * fminf(y[i], 3269017.3724721107f);  // g * exp(min(x - 1, 15))
+}
+
 static inline uint32_t stream_blocks(int64_t n) {
     const int64_t b = ceil_div(n, 256);
     return (uint32_t)(b < 2048 ? b : 2048);
@@ -243,11 +255,11 @@ extern "C" int emer_ray_points(const float *origins, const float *dirs, const fl
     return check_launch("ray_points");
 }
 
-extern "C" int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, void *stream) {
+extern "C" int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, int remap, void *stream) {
     EMER_REQUIRE(n >= 0 && max_deg >= 0 && max_deg <= 16, "dir_encode: bad arguments");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(dirs && out, "dir_encode: null pointer");
-    hipLaunchKernelGGL(dir_encode_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), dirs, out, n, max_deg);
+    hipLaunchKernelGGL(dir_encode_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), dirs, out, n, max_deg, remap);
     return check_launch("dir_encode");
 }
 
@@ -272,4 +284,20 @@ extern "C" int emer_layout_transpose(const float *src, float *dst, int32_t n_lev
     hipLaunchKernelGGL(layout_transpose_kernel, dim3((uint32_t)ceil_div(n, 64)), dim3(256), lds, as_stream(stream), src, dst,
                        n_levels, n, n_features, to_row_major);
     return check_launch("layout_transpose");
+}
+
+extern "C" int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0 && x_stride >= 1, "trunc_exp_fwd: bad arguments");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && y, "trunc_exp_fwd: null pointer");
+    hipLaunchKernelGGL(trunc_exp_fwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), x, x_stride, y, n);
+    return check_launch("trunc_exp_fwd");
+}
+
+extern "C" int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_stride, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0 && dx_stride >= 1, "trunc_exp_bwd: bad arguments");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(dy && y && dx, "trunc_exp_bwd: null pointer");
+    hipLaunchKernelGGL(trunc_exp_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), dy, y, dx, dx_stride, n);
+    return check_launch("trunc_exp_bwd");
 }

@@ -224,6 +224,85 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
     }
 }
 
+
+// ------------------------------------------------------- backward (params), owner-computes
+// Measured on MI355X (tools/atomic_probe.hip): L2 float atomics retire ~21 G cache-line requests/s
+// no matter the table size, dtype (f32 = pk_f16 = f64) or scope, so the tcnn-style global scatter
+// (2^D * L * F * N = 268 M requests at the metric shape) costs 13-20 ms.  LDS atomics are an order
+// of magnitude faster and need no L2 round trip, so the scatter is turned inside out:
+//   * the table of a level is cut into slices of E = 2^k entries that fit the CU's LDS
+//     (T = 2^19, F = 2, fp32: 32 slices x 128 KiB = one slice per CU of an XCD);
+//   * a workgroup OWNS one (level, slice): it streams every sample of that level (coalesced reads
+//     of x and the level-major dOut, shared by the XCD's 32 CUs through its L2), recomputes the
+//     2^D corner indices with integer VALU, and ds_add_f32's the corners that fall in its slice;
+//   * at the end it writes its slice with plain coalesced stores -- every table entry is written by
+//     exactly one workgroup, so there are no global atomics and the gradient buffer needs no memset.
+// Work items are dealt XCD-aware (block b -> XCD b % 8): an XCD finishes all slices of one level
+// before starting its next level, so the streamed inputs of that level stay L2-resident.
+// Placement only affects speed, never results.
+struct SlicePlan {
+    uint32_t log2_e[EMER_MAX_LEVELS];    // slice = idx >> log2_e
+    uint32_t n_slices[EMER_MAX_LEVELS];
+};
+
+template <int D, int F>
+__global__ __launch_bounds__(1024) void hashgrid_bwd_params_sliced_kernel(const emer_grid_desc g, const SlicePlan plan,
+                                                                          const float *__restrict__ x,
+                                                                          const float *__restrict__ dout, int64_t sn, int64_t sl,
+                                                                          float *__restrict__ grad, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    // XCD-aware work lookup: XCD xcd walks levels xcd, xcd+8, ... ; j-th block of that XCD
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t j = blockIdx.x >> 3;
+    uint32_t level = xcd, slice = 0;
+    bool have = false;
+    for (; level < g.n_levels; level += 8u) {
+        const uint32_t ns = plan.n_slices[level];
+        if (j < ns) { slice = j; have = true; break; }
+        j -= ns;
+    }
+    if (!have) return;
+    const LevelInfo li = level_info(g, level);
+    const uint32_t log2_e = plan.log2_e[level], E = 1u << log2_e;
+    const uint32_t first = slice << log2_e;
+    const uint32_t count = (li.size - first) < E ? (li.size - first) : E;  // entries this slice really has
+
+    for (uint32_t i = threadIdx.x; i < E * F; i += 1024) acc[i] = 0.0f;
+    __syncthreads();
+
+    const float *__restrict__ dl = dout + (int64_t)level * sl;
+    for (int64_t n = threadIdx.x; n < N; n += 1024) {
+        float xv[D], w[D], go[F];
+        uint32_t gi[D];
+        load_x<D>(x, n, xv);
+        if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; }
+        else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; go[2 < F ? 2 : 0] = t.z; go[3 < F ? 3 : 0] = t.w; }
+        else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) go[f] = dl[n * sn + f];
+        }
+        cell_of<D>(li, xv, gi, w);
+#pragma unroll
+        for (uint32_t m = 0; m < (1u << D); ++m) {
+            uint32_t c[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
+            const uint32_t idx = grid_index<D>(li, c);
+            if ((idx >> log2_e) == slice) {
+                float wt = 1.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                float *a = acc + (size_t)(idx - first) * F;
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(a + f, wt * go[f]);  // ds_add_f32 (no return)
+            }
+        }
+    }
+    __syncthreads();
+    float *__restrict__ out = grad + ((size_t)li.offset + first) * F;
+    for (uint32_t i = threadIdx.x; i < count * F; i += 1024) out[i] = acc[i];
+}
+
 // ------------------------------------------------------------------------- backward (input)
 // One thread per sample, all levels: deterministic, no atomics.  Only the flow configs reach this.
 template <int D, int F, typename PT>
@@ -346,6 +425,44 @@ extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x,
                                    *g, x, dout, sn, sl, (__half *)grad, n, n_chunks);
         }
         return check_launch("hashgrid_bwd_params");
+    });
+}
+
+
+// Owner-computes variant: OVERWRITES grad (f32) -- every entry of every level is written exactly
+// once, so the caller does not zero the buffer.  max_lds_bytes bounds the slice size.
+extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
+                                               int64_t sl, float *grad, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0, "hashgrid_bwd_params_sliced: negative n");
+    EMER_REQUIRE(x && dout && grad, "hashgrid_bwd_params_sliced: null pointer");
+    const uint32_t F = g->n_features;
+    const uint32_t max_entries = (128u * 1024u) / (F * 4u);  // 128 KiB of the CU's 160 KiB LDS
+    SlicePlan plan;
+    uint32_t max_e = 0, per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t l = 0; l < g->n_levels; ++l) {
+        // aim for 32 slices per level (one per CU of an XCD), capped by the LDS budget
+        uint32_t k = 0;
+        while ((1ull << k) * 32ull < g->size[l]) ++k;
+        while ((1u << k) > max_entries) --k;
+        if (k < 6) k = 6;
+        plan.log2_e[l] = k;
+        plan.n_slices[l] = (uint32_t)ceil_div(g->size[l], 1ll << k);
+        if ((1u << k) > max_e) max_e = 1u << k;
+        per_xcd[l & 7u] += plan.n_slices[l];
+    }
+    uint32_t max_blocks = 0;
+    for (int i = 0; i < 8; ++i) max_blocks = per_xcd[i] > max_blocks ? per_xcd[i] : max_blocks;
+    const size_t lds = (size_t)max_e * F * sizeof(float);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, FF = decltype(f)::value;
+        auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
+        }
+        hipLaunchKernelGGL(kern, dim3(max_blocks * 8u), dim3(1024), lds, as_stream(stream), *g, plan, x, dout, sn, sl, grad, n);
+        return check_launch("hashgrid_bwd_params_sliced");
     });
 }
 

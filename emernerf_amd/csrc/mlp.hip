@@ -51,7 +51,7 @@ template <int BN>  // 64 -> mfma 32x32x2, 16 -> mfma 16x16x4
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ wmat,
                                                          int64_t sbj, int64_t sbk, const float *__restrict__ bias,
                                                          float *__restrict__ y, int64_t ldy, int64_t M, int32_t N, int32_t K,
-                                                         int act) {
+                                                         int act, float *__restrict__ aux) {
     constexpr int PITCH = (BN == 64) ? 33 : 34;
     __shared__ float xs[kBM * PITCH];
     __shared__ float ws[BN * PITCH];
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M) y[row * ldy + col] = apply_act(act, (t == 0 ? acc0[r] : acc1[r]) + bv);
+                if (row < M) {
+                    const float pre = (t == 0 ? acc0[r] : acc1[r]) + bv;
+                    y[row * ldy + col] = apply_act(act, pre);
+                    if (aux && col == 0) aux[row] = expf(pre - 1.0f);  // density side output (radiance_field.py:422)
+                }
             }
         }
     } else {
@@ -120,7 +124,11 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = row0 + wave * 32 + t * 16 + (lane >> 4) * 4 + r;
-                    if (row < M) y[row * ldy + col] = apply_act(act, (t == 0 ? c0[r] : c1[r]) + bv);
+                    if (row < M) {
+                        const float pre = (t == 0 ? c0[r] : c1[r]) + bv;
+                        y[row * ldy + col] = apply_act(act, pre);
+                        if (aux && col == 0) aux[row] = expf(pre - 1.0f);
+                    }
                 }
             }
         }
@@ -128,12 +136,15 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ y,
-                                                      int64_t ldy, float *__restrict__ dpre, int64_t M, int32_t N, int act) {
+                                                      int64_t ldy, float *__restrict__ dpre, int64_t M, int32_t N, int act,
+                                                      const float *__restrict__ d_aux, const float *__restrict__ aux_y) {
     const int64_t total = M * N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / N;
         const int32_t c = (int32_t)(i - r * N);
-        dpre[i] = dy[r * lddy + c] * act_grad_from_y(act, y[r * ldy + c]);
+        float g = dy ? dy[r * lddy + c] * act_grad_from_y(act, y[r * ldy + c]) : 0.0f;
+        if (d_aux && c == 0) g += d_aux[r] * act_grad_from_y(EMER_ACT_TRUNC_EXP, aux_y[r]);  // trunc_exp bwd (nerf_utils.py:69-72)
+        dpre[i] = g;
     }
 }
 
@@ -211,14 +222,14 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict_
 }
 
 static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,
-                         int64_t ldy, int64_t M, int32_t N, int32_t K, int act, hipStream_t st) {
+                         int64_t ldy, int64_t M, int32_t N, int32_t K, int act, float *aux, hipStream_t st) {
     const uint32_t gx = (uint32_t)ceil_div(M, kBM);
     if (N <= 16) {
         hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3(gx, (uint32_t)ceil_div(N, 16)), dim3(256), 0, st, x, ldx, w, sbj, sbk, bias, y,
-                           ldy, M, N, K, act);
+                           ldy, M, N, K, act, aux);
     } else {
         hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(gx, (uint32_t)ceil_div(N, 64)), dim3(256), 0, st, x, ldx, w, sbj, sbk, bias, y,
-                           ldy, M, N, K, act);
+                           ldy, M, N, K, act, aux);
     }
     return check_launch("linear");
 }
@@ -228,34 +239,37 @@ static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sb
 using namespace emer;
 
 extern "C" int emer_linear_fwd(const float *x, int64_t ldx, const float *w, const float *bias, float *y, int64_t ldy,
-                               int64_t m, int32_t n, int32_t k, int act, void *stream) {
+                               int64_t m, int32_t n, int32_t k, int act, float *aux_density, void *stream) {
     EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "linear_fwd: bad sizes m=%lld n=%d k=%d", (long long)m, n, k);
     if (m == 0) return EMER_OK;
     EMER_REQUIRE(x && w && y, "linear_fwd: null pointer");
     EMER_REQUIRE(ldx >= k && ldy >= n, "linear_fwd: leading dimension smaller than the row");
     EMER_REQUIRE(act >= EMER_ACT_NONE && act <= EMER_ACT_TRUNC_EXP, "linear_fwd: unknown activation %d", act);
-    return launch_linear(x, ldx, w, k, 1, bias, y, ldy, m, n, k, act, as_stream(stream));
+    return launch_linear(x, ldx, w, k, 1, bias, y, ldy, m, n, k, act, aux_density, as_stream(stream));
 }
 
 extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x, int64_t ldx,
                                const float *w, float *dpre_ws, float *dx, int64_t lddx, float *dw, float *dbias, int64_t m,
-                               int32_t n, int32_t k, int act, void *stream) {
+                               int32_t n, int32_t k, int act, const float *d_aux_density, const float *aux_density,
+                               void *stream) {
     EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "linear_bwd: bad sizes m=%lld n=%d k=%d", (long long)m, n, k);
     if (m == 0) return EMER_OK;
-    EMER_REQUIRE(dy && dpre_ws, "linear_bwd: null pointer");
+    EMER_REQUIRE((dy || d_aux_density) && dpre_ws, "linear_bwd: null pointer");
+    EMER_REQUIRE(!d_aux_density || aux_density, "linear_bwd: d_aux_density needs the saved aux_density");
     EMER_REQUIRE(act >= EMER_ACT_NONE && act <= EMER_ACT_TRUNC_EXP, "linear_bwd: unknown activation %d", act);
-    EMER_REQUIRE(act == EMER_ACT_NONE || y, "linear_bwd: saved output y required for a non-linear activation");
+    EMER_REQUIRE(act == EMER_ACT_NONE || y || !dy, "linear_bwd: saved output y required for a non-linear activation");
     hipStream_t st = as_stream(stream);
     {
         const int64_t total = m * n;
         const uint32_t blocks = (uint32_t)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
-        hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, y ? y : dy, y ? ldy : lddy, dpre_ws, m, n, act);
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, lddy, y ? y : dy, y ? ldy : lddy, dpre_ws, m, n, act,
+                           d_aux_density, aux_density);
         if (int rc = check_launch("act_bwd")) return rc;
     }
     if (dx) {
         EMER_REQUIRE(w && lddx >= k, "linear_bwd: dx requested but w missing or lddx too small");
         // dX[M,K] = dPre[M,N] @ W[N,K]: a linear with reduction dim N and b(j=k, kk=n) = W[n*K + k]
-        if (int rc = launch_linear(dpre_ws, n, w, 1, k, nullptr, dx, lddx, m, k, n, EMER_ACT_NONE, st)) return rc;
+        if (int rc = launch_linear(dpre_ws, n, w, 1, k, nullptr, dx, lddx, m, k, n, EMER_ACT_NONE, nullptr, st)) return rc;
     }
     if (dw) {
         EMER_REQUIRE(x && ldx >= k, "linear_bwd: dw requested but x missing or ldx too small");

@@ -96,9 +96,15 @@ class _HashGridFn(torch.autograd.Function):
             st = _stream(xc)
             if ctx.needs_input_grad[1]:
                 gdt = ctx.grad_dtype or torch.float32
-                grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
-                _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
-                          _dtype_tag(grad), N, st)
+                if gdt == torch.float32:
+                    # owner-computes LDS scatter: writes every entry once (no memset, no global atomics)
+                    grad = torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
+                    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
+                              N, st)
+                else:  # tcnn-style packed-half atomics (kept for the fp16-gradient mode)
+                    grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
+                    _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
+                              _dtype_tag(grad), N, st)
                 dp = grad.to(pc.dtype) if grad.dtype != pc.dtype else grad
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xc)
@@ -270,8 +276,11 @@ def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None) -> T
 
 # ---------------------------------------------------------------------------------- MLP heads
 class _LinearFn(torch.autograd.Function):
+    """act(x W^T + b) (+ optional density side output exp(pre[:,0] - 1))."""
+
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int, with_density: bool):
+        ctx.set_materialize_grads(False)
         lead = x.shape[:-1]
         K = x.shape[-1]
         x2 = _f32c(x).view(-1, K)
@@ -280,17 +289,23 @@ class _LinearFn(torch.autograd.Function):
         M, N = x2.shape[0], wc.shape[0]
         with torch.cuda.device(x2.device):
             y = torch.empty((M, N), device=x2.device, dtype=torch.float32)
-            _lib.call("emer_linear_fwd", _ptr(x2), K, _ptr(wc), _ptr(bc), _ptr(y), N, M, N, K, act, _stream(x2))
-        ctx.save_for_backward(x2, wc, y)
+            aux = torch.empty((M,), device=x2.device, dtype=torch.float32) if with_density else None
+            _lib.call("emer_linear_fwd", _ptr(x2), K, _ptr(wc), _ptr(bc), _ptr(y), N, M, N, K, act, _ptr(aux), _stream(x2))
+        ctx.save_for_backward(x2, wc, y, aux)
         ctx.act, ctx.lead, ctx.has_bias = act, lead, bias is not None
+        if with_density:
+            return y.view(*lead, N), aux.view(*lead)
         return y.view(*lead, N)
 
     @staticmethod
-    def backward(ctx, dy: Tensor):
-        x2, wc, y = ctx.saved_tensors
+    def backward(ctx, dy: Optional[Tensor], daux: Optional[Tensor] = None):
+        x2, wc, y, aux = ctx.saved_tensors
         M, K = x2.shape
         N = wc.shape[0]
-        g = _f32c(dy).view(M, N)
+        if dy is None and daux is None:
+            return None, None, None, None, None
+        g = None if dy is None else _f32c(dy).view(M, N)
+        ga = None if daux is None else _f32c(daux).view(M)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         with torch.cuda.device(x2.device):
@@ -299,24 +314,66 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.zeros((N, K), device=x2.device, dtype=torch.float32) if (need_w or need_b) else None
             db = torch.zeros((N,), device=x2.device, dtype=torch.float32) if need_b else None
             _lib.call("emer_linear_bwd", _ptr(g), N, _ptr(y), N, _ptr(x2), K, _ptr(wc), _ptr(ws), _ptr(dx), K, _ptr(dw),
-                      _ptr(db), M, N, K, ctx.act, _stream(x2))
-        return (dx.view(*ctx.lead, K) if need_x else None), (dw if need_w else None), db, None
+                      _ptr(db), M, N, K, ctx.act, _ptr(ga), _ptr(aux), _stream(x2))
+        return (dx.view(*ctx.lead, K) if need_x else None), (dw if need_w else None), db, None, None
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: Optional[str] = None) -> Tensor:
     """act(x @ weight.T + bias) on the fp32 matrix cores; act in {None,'relu','sigmoid','trunc_exp'}."""
     _check_cuda(x, weight, bias)
-    return _LinearFn.apply(x, weight, bias, _ACTS[act])
+    return _LinearFn.apply(x, weight, bias, _ACTS[act], False)
 
 
-def dir_encode(dirs: Tensor, max_deg: int = 4) -> Tensor:
-    """SinusoidalEncoder(3, 0, max_deg) applied to (dirs+1)/2 (radiance_field.py:629; no grad)."""
+def linear_with_density(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """(x @ weight.T + bias, exp(pre[..., 0] - 1)): last base-MLP layer with the density activation
+    of geometry feature 0 fused into the epilogue (radiance_field.py:28,315,422)."""
+    _check_cuda(x, weight, bias)
+    return _LinearFn.apply(x, weight, bias, ACT_NONE, True)
+
+
+class _TruncExpFn(torch.autograd.Function):
+    """density = exp(x[..., col] - 1) read off one column of a feature tensor."""
+
+    @staticmethod
+    def forward(ctx, feats: Tensor, col: int):
+        f = feats.detach()
+        assert f.dtype == torch.float32 and f.is_contiguous()
+        C = f.shape[-1]
+        n = f.numel() // C
+        with torch.cuda.device(f.device):
+            y = torch.empty(f.shape[:-1], device=f.device, dtype=torch.float32)
+            src = f.view(-1)[col:]
+            _lib.call("emer_trunc_exp_fwd", _ptr(src), C, _ptr(y), n, _stream(f))
+        ctx.save_for_backward(y)
+        ctx.col, ctx.shape = col, feats.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (y,) = ctx.saved_tensors
+        C = ctx.shape[-1]
+        g = _f32c(dy)
+        with torch.cuda.device(y.device):
+            dx = torch.zeros(ctx.shape, device=y.device, dtype=torch.float32)
+            dst = dx.view(-1)[ctx.col:]
+            _lib.call("emer_trunc_exp_bwd", _ptr(g), _ptr(y), _ptr(dst), C, y.numel(), _stream(y))
+        return dx, None
+
+
+def trunc_exp_column(feats: Tensor, col: int = 0) -> Tensor:
+    """trunc_exp(feats[..., col] - 1) (radiance_field.py:28,461)."""
+    _check_cuda(feats)
+    return _TruncExpFn.apply(feats.contiguous(), col)
+
+
+def dir_encode(dirs: Tensor, max_deg: int = 4, remap: bool = True) -> Tensor:
+    """SinusoidalEncoder(3, 0, max_deg); remap=True applies (dirs+1)/2 first (radiance_field.py:629; no grad)."""
     _check_cuda(dirs)
     d = _f32c(dirs).view(-1, 3)
     width = 3 if max_deg == 0 else 3 * (1 + 2 * (max_deg + 1))
     with torch.cuda.device(d.device):
         out = torch.empty((d.shape[0], width), device=d.device, dtype=torch.float32)
-        _lib.call("emer_dir_encode", _ptr(d), _ptr(out), d.shape[0], max_deg, _stream(d))
+        _lib.call("emer_dir_encode", _ptr(d), _ptr(out), d.shape[0], max_deg, int(remap), _stream(d))
     return out.view(*dirs.shape[:-1], width)
 
 

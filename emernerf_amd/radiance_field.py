@@ -1,0 +1,503 @@
+"""RadianceField / DensityField with the reference's interface on the HIP kernels.
+
+Mirrors radiance_fields/radiance_field.py (and radiance_fields/mlp.py) of the reference: same
+constructor arguments, same sub-module / parameter names (reference checkpoints load with
+``load_state_dict``), same ``forward`` contract, same default initialisation order
+(so ``torch.manual_seed`` reproduces the reference's nn.Linear weights).  The arithmetic runs in
+``emernerf_amd.ops`` (hand-written HIP): hash-grid encode/backward, contraction, fp32-MFMA linear layers
+with fused ReLU / sigmoid / density epilogues.  torch itself only supplies parameter containers,
+``torch.cat`` / indexing glue, the appearance-embedding gather and ``grid_sample`` for the (optional)
+learnable PE map.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import ops
+from .encodings import HashEncoder, SinusoidalEncoder, build_xyz_encoder_from_cfg
+
+logger = logging.getLogger()
+
+
+def _run_sequential(seq: nn.Sequential, x: Tensor, density_from_col0: bool = False):
+    """Evaluate nn.Sequential(Linear, ReLU, ..., Linear[, Sigmoid]) with fused-activation HIP linears."""
+    mods = list(seq)
+    i, density = 0, None
+    while i < len(mods):
+        lin = mods[i]
+        assert isinstance(lin, nn.Linear), f"unexpected module {type(lin)} in head"
+        act, step = None, 1
+        if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            act, step = "relu", 2
+        elif i + 1 < len(mods) and isinstance(mods[i + 1], nn.Sigmoid):
+            act, step = "sigmoid", 2
+        last = i + step >= len(mods)
+        if last and density_from_col0:
+            assert act is None
+            x, density = ops.linear_with_density(x, lin.weight, lin.bias)
+        else:
+            x = ops.linear(x, lin.weight, lin.bias, act)
+        i += step
+    return (x, density) if density_from_col0 else x
+
+
+class MLP(nn.Module):
+    """radiance_fields/mlp.py:7-46 (skip-connection MLP of the rgb / sky heads)."""
+
+    def __init__(self, in_dims: int, out_dims: int, num_layers: int = 3, hidden_dims: Optional[int] = 256,
+                 skip_connections: Optional[Tuple[int]] = [0]) -> None:
+        super().__init__()
+        self.in_dims, self.hidden_dims, self.n_output_dims = in_dims, hidden_dims, out_dims
+        self.num_layers, self.skip_connections = num_layers, skip_connections
+        layers = []
+        if num_layers == 1:
+            layers.append(nn.Linear(in_dims, out_dims))
+        else:
+            for i in range(num_layers - 1):
+                if i == 0:
+                    layers.append(nn.Linear(in_dims, hidden_dims))
+                elif i in skip_connections:
+                    layers.append(nn.Linear(in_dims + hidden_dims, hidden_dims))
+                else:
+                    layers.append(nn.Linear(hidden_dims, hidden_dims))
+            layers.append(nn.Linear(hidden_dims, out_dims))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x: Tensor, final_act: Optional[str] = None) -> Tensor:
+        inp = x
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            if i in self.skip_connections:
+                x = torch.cat([x, inp], -1)
+            x = ops.linear(x, layer.weight, layer.bias, "relu" if i < n - 1 else final_act)
+        return x
+
+
+class RadianceField(nn.Module):
+    """radiance_fields/radiance_field.py:20-785."""
+
+    def __init__(
+        self,
+        xyz_encoder: HashEncoder,
+        dynamic_xyz_encoder: Optional[HashEncoder] = None,
+        flow_xyz_encoder: Optional[HashEncoder] = None,
+        aabb: Union[Tensor, List[float]] = [-1, -1, -1, 1, 1, 1],
+        num_dims: int = 3,
+        density_activation: Optional[Callable] = None,
+        unbounded: bool = True,
+        geometry_feature_dim: int = 15,
+        base_mlp_layer_width: int = 64,
+        head_mlp_layer_width: int = 64,
+        enable_cam_embedding: bool = False,
+        enable_img_embedding: bool = False,
+        num_cams: int = 3,
+        appearance_embedding_dim: int = 16,
+        semantic_feature_dim: int = 64,
+        feature_mlp_layer_width: int = 256,
+        feature_embedding_dim: int = 768,
+        enable_sky_head: bool = False,
+        enable_shadow_head: bool = False,
+        enable_feature_head: bool = False,
+        num_train_timesteps: int = 0,
+        interpolate_xyz_encoding: bool = False,
+        enable_learnable_pe: bool = True,
+        enable_temporal_interpolation: bool = False,
+    ) -> None:
+        super().__init__()
+        if density_activation is not None:
+            raise NotImplementedError("only the reference's default density activation trunc_exp(x - 1) is fused")
+        if enable_temporal_interpolation:
+            raise NotImplementedError("enable_temporal_interpolation is eval-only and off in every shipped config")
+        if not isinstance(aabb, Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb)
+        self.unbounded, self.num_cams, self.num_dims = unbounded, num_cams, num_dims
+        self.enable_cam_embedding, self.enable_img_embedding = enable_cam_embedding, enable_img_embedding
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.geometry_feature_dim = geometry_feature_dim
+        if not enable_feature_head:
+            semantic_feature_dim = 0
+        self.semantic_feature_dim = semantic_feature_dim
+
+        # ---- static field (radiance_field.py:72-80)
+        self.xyz_encoder = xyz_encoder
+        self.base_mlp = nn.Sequential(
+            nn.Linear(self.xyz_encoder.n_output_dims, base_mlp_layer_width), nn.ReLU(),
+            nn.Linear(base_mlp_layer_width, geometry_feature_dim + semantic_feature_dim))
+        # ---- dynamic field (:82-96)
+        self.interpolate_xyz_encoding = interpolate_xyz_encoding
+        self.dynamic_xyz_encoder = dynamic_xyz_encoder
+        self.enable_temporal_interpolation = enable_temporal_interpolation
+        if self.dynamic_xyz_encoder is not None:
+            self.register_buffer("training_timesteps", torch.zeros(num_train_timesteps))
+            self.dynamic_base_mlp = nn.Sequential(
+                nn.Linear(self.dynamic_xyz_encoder.n_output_dims, base_mlp_layer_width), nn.ReLU(),
+                nn.Linear(base_mlp_layer_width, geometry_feature_dim + semantic_feature_dim))
+        # ---- flow field (:98-111)
+        self.flow_xyz_encoder = flow_xyz_encoder
+        if self.flow_xyz_encoder is not None:
+            self.flow_mlp = nn.Sequential(
+                nn.Linear(self.flow_xyz_encoder.n_output_dims, base_mlp_layer_width), nn.ReLU(),
+                nn.Linear(base_mlp_layer_width, base_mlp_layer_width), nn.ReLU(),
+                nn.Linear(base_mlp_layer_width, 6))
+        # ---- appearance embedding (:113-123)
+        if self.enable_cam_embedding:
+            self.appearance_embedding = nn.Embedding(num_cams, appearance_embedding_dim)
+        elif self.enable_img_embedding:
+            self.appearance_embedding = nn.Embedding(num_train_timesteps * num_cams, appearance_embedding_dim)
+        else:
+            self.appearance_embedding = None
+        self.direction_encoding = SinusoidalEncoder(n_input_dims=3, min_deg=0, max_deg=4)
+        emb = appearance_embedding_dim if (enable_cam_embedding or enable_img_embedding) else 0
+        # ---- colour head (:130-143)
+        self.rgb_head = MLP(in_dims=geometry_feature_dim + self.direction_encoding.n_output_dims + emb, out_dims=3,
+                            num_layers=3, hidden_dims=head_mlp_layer_width, skip_connections=[1])
+        # ---- shadow head (:145-153)
+        self.enable_shadow_head = enable_shadow_head
+        if enable_shadow_head:
+            self.shadow_head = nn.Sequential(nn.Linear(geometry_feature_dim, base_mlp_layer_width), nn.ReLU(),
+                                             nn.Linear(base_mlp_layer_width, 1), nn.Sigmoid())
+        # ---- sky heads (:155-187)
+        self.enable_sky_head = enable_sky_head
+        if enable_sky_head:
+            self.sky_head = MLP(in_dims=self.direction_encoding.n_output_dims + emb, out_dims=3, num_layers=3,
+                                hidden_dims=head_mlp_layer_width, skip_connections=[1])
+            if enable_feature_head:
+                self.dino_sky_head = nn.Sequential(
+                    nn.Linear(self.direction_encoding.n_output_dims + emb, feature_mlp_layer_width), nn.ReLU(),
+                    nn.Linear(feature_mlp_layer_width, feature_mlp_layer_width), nn.ReLU(),
+                    nn.Linear(feature_mlp_layer_width, feature_embedding_dim))
+        # ---- feature head (:189-217)
+        self.enable_feature_head = enable_feature_head
+        if enable_feature_head:
+            self.dino_head = nn.Sequential(
+                nn.Linear(semantic_feature_dim, feature_mlp_layer_width), nn.ReLU(),
+                nn.Linear(feature_mlp_layer_width, feature_mlp_layer_width), nn.ReLU(),
+                nn.Linear(feature_mlp_layer_width, feature_embedding_dim))
+            self.register_buffer("feats_reduction_mat", torch.zeros(feature_embedding_dim, 3))
+            self.register_buffer("feat_color_min", torch.zeros(3, dtype=torch.float32))
+            self.register_buffer("feat_color_max", torch.ones(3, dtype=torch.float32))
+            self.enable_learnable_pe = enable_learnable_pe
+            if enable_learnable_pe:
+                self.learnable_pe_map = nn.Parameter(0.05 * torch.randn(1, feature_embedding_dim // 2, 80, 120), requires_grad=True)
+                self.pe_head = nn.Sequential(nn.Linear(feature_embedding_dim // 2, feature_embedding_dim))
+        self.time_diff = 0
+
+    # ------------------------------------------------------------------ bookkeeping (:219-276)
+    def register_normalized_training_timesteps(self, normalized_timesteps: Tensor, time_diff: float = None) -> None:
+        if self.dynamic_xyz_encoder is not None:
+            self.training_timesteps.copy_(normalized_timesteps)
+            self.training_timesteps = self.training_timesteps.to(self.device)
+            if time_diff is not None:
+                self.time_diff = time_diff
+            elif len(self.training_timesteps) > 1:
+                self.time_diff = self.training_timesteps[1] - self.training_timesteps[0]
+            else:
+                self.time_diff = 0
+
+    def set_aabb(self, aabb: Union[Tensor, List[float]]) -> None:
+        if not isinstance(aabb, Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        logger.info(f"Set aabb from {self.aabb} to {aabb}")
+        self.aabb.copy_(aabb)
+        self.aabb = self.aabb.to(self.device)
+
+    def register_feats_reduction_mat(self, feats_reduction_mat: Tensor, feat_color_min: Tensor, feat_color_max: Tensor) -> None:
+        self.feats_reduction_mat.copy_(feats_reduction_mat)
+        self.feat_color_min.copy_(feat_color_min)
+        self.feat_color_max.copy_(feat_color_max)
+
+    @property
+    def device(self) -> torch.device:
+        return self.aabb.device
+
+    # ------------------------------------------------------------------ field pieces
+    def contract_points(self, positions: Tensor) -> Tensor:
+        """:278-300 (contraction + selector zeroing), one fused kernel, differentiable."""
+        return ops.contract_points(positions, self.aabb, self.unbounded)
+
+    def _static_from_normed(self, normed_positions: Tensor):
+        enc = self.xyz_encoder(normed_positions.reshape(-1, self.num_dims))
+        feats, density = _run_sequential(self.base_mlp, enc, density_from_col0=True)
+        lead = normed_positions.shape[:-1]
+        return feats.view(*lead, -1), density.view(*lead)
+
+    def forward_static_hash(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
+        """:302-318.  Returns (encoded_features, normed_positions)."""
+        normed_positions = self.contract_points(positions)
+        feats, _ = self._static_from_normed(normed_positions)
+        return feats, normed_positions
+
+    def _dynamic(self, normed_positions: Tensor, normed_timestamps: Tensor, want_density: bool):
+        if normed_timestamps.shape[-1] != 1:
+            normed_timestamps = normed_timestamps.unsqueeze(-1)
+        temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
+        enc = self.dynamic_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
+        lead = temporal_positions.shape[:-1]
+        if want_density:
+            feats, density = _run_sequential(self.dynamic_base_mlp, enc, density_from_col0=True)
+            return feats.view(*lead, -1), enc.view(*lead, -1), density.view(*lead)
+        feats = _run_sequential(self.dynamic_base_mlp, enc)
+        return feats.view(*lead, -1), enc.view(*lead, -1), None
+
+    def forward_dynamic_hash(self, normed_positions: Tensor, normed_timestamps: Tensor, return_hash_encodings: bool = False):
+        """:320-357 (the ``if True:`` branch: no temporal interpolation)."""
+        feats, enc, _ = self._dynamic(normed_positions, normed_timestamps, want_density=False)
+        return (feats, enc) if return_hash_encodings else feats
+
+    def forward_flow_hash(self, normed_positions: Tensor, normed_timestamps: Tensor) -> Tensor:
+        """:359-389."""
+        if normed_timestamps.shape[-1] != 1:
+            normed_timestamps = normed_timestamps.unsqueeze(-1)
+        temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
+        enc = self.flow_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
+        flow = _run_sequential(self.flow_mlp, enc)
+        return flow.view(*temporal_positions.shape[:-1], 6)
+
+    def _noise(self, like: Tensor) -> Tensor:
+        """Temporal-aggregation noise (:567-570); overridable so tests can replay the reference's draw."""
+        if self.training:
+            return torch.rand_like(like)[..., 0:1]
+        return torch.ones_like(like)[..., 0:1]
+
+    def temporal_aggregation(self, positions: Tensor, normed_timestamps: Tensor, forward_flow: Tensor,
+                             backward_flow: Tensor, dynamic_feats: Tensor) -> Dict[str, Tensor]:
+        """:553-620 (Eq. 8 of the paper)."""
+        if normed_timestamps.shape[-1] != 1:
+            normed_timestamps = normed_timestamps.unsqueeze(-1)
+        noise = self._noise(forward_flow)
+        fwd_pos = self.contract_points(positions + forward_flow * noise)
+        bwd_pos = self.contract_points(positions + backward_flow * noise)
+        fwd_t = torch.clamp(normed_timestamps + self.time_diff * noise, 0, 1.0)
+        bwd_t = torch.clamp(normed_timestamps - self.time_diff * noise, 0, 1.0)
+        fwd_feats, fwd_enc = self.forward_dynamic_hash(fwd_pos, fwd_t, return_hash_encodings=True)
+        bwd_feats, bwd_enc = self.forward_dynamic_hash(bwd_pos, bwd_t, return_hash_encodings=True)
+        fwd_pred_flow = self.forward_flow_hash(fwd_pos, fwd_t)
+        bwd_pred_flow = self.forward_flow_hash(bwd_pos, bwd_t)
+        aggregated = (dynamic_feats + 0.5 * fwd_feats + 0.5 * bwd_feats) / 2.0
+        return {
+            "dynamic_feats": aggregated,
+            "forward_pred_backward_flow": fwd_pred_flow[..., 3:],
+            "backward_pred_forward_flow": bwd_pred_flow[..., :3],
+            "forward_dynamic_hash_encodings": fwd_enc,
+            "backward_dynamic_hash_encodings": bwd_enc,
+        }
+
+    def _appearance(self, directions: Tensor, data_dict: Optional[Dict[str, Tensor]]):
+        if not (self.enable_cam_embedding or self.enable_img_embedding):
+            return None
+        data_dict = data_dict or {}
+        if "cam_idx" in data_dict and self.enable_cam_embedding:
+            return self.appearance_embedding(data_dict["cam_idx"])
+        if "img_idx" in data_dict and self.enable_img_embedding:
+            return self.appearance_embedding(data_dict["img_idx"])
+        return torch.ones((*directions.shape[:-1], self.appearance_embedding_dim), device=directions.device) \
+            * self.appearance_embedding.weight.mean(dim=0)
+
+    def query_rgb(self, directions: Tensor, geo_feats: Tensor, dynamic_geo_feats: Tensor = None,
+                  data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
+        """:622-658."""
+        h = self.direction_encoding(directions, remap=True)  # (d + 1) / 2 folded into the kernel
+        emb = self._appearance(directions, data_dict)
+        if emb is not None:
+            h = torch.cat([h, emb], dim=-1)
+        results = {"rgb": self.rgb_head(torch.cat([h, geo_feats], dim=-1), final_act="sigmoid")}
+        if self.dynamic_xyz_encoder is not None:
+            assert dynamic_geo_feats is not None, "Dynamic geometry features are not provided."
+            results["dynamic_rgb"] = self.rgb_head(torch.cat([h, dynamic_geo_feats], dim=-1), final_act="sigmoid")
+        return results
+
+    def query_sky(self, directions: Tensor, data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
+        """:660-686 (per ray).  Note: the reference does NOT remap directions for the sky head."""
+        d = directions if directions.dim() == 2 else directions[:, 0]
+        dd = self.direction_encoding(d, remap=False)
+        emb = self._appearance(directions, data_dict)
+        if emb is not None:
+            dd = torch.cat([dd, emb], dim=-1)
+        results = {"rgb_sky": self.sky_head(dd, final_act="sigmoid")}
+        if self.enable_feature_head:
+            results["dino_sky_feat"] = _run_sequential(self.dino_sky_head, dd)
+        return results
+
+    # ------------------------------------------------------------------ forward (:391-551)
+    def forward(self, positions: Tensor, directions: Tensor = None, data_dict: Dict[str, Tensor] = {},
+                return_density_only: bool = False, combine_static_dynamic: bool = False,
+                query_feature_head: bool = True, query_pe_head: bool = True) -> Dict[str, Tensor]:
+        results_dict = {}
+        normed_positions = self.contract_points(positions)
+        encoded_features, static_density = self._static_from_normed(normed_positions)
+        geo_feats, semantic_feats = torch.split(encoded_features, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
+
+        has_timestamps = "normed_timestamps" in data_dict or "lidar_normed_timestamps" in data_dict
+        dynamic = self.dynamic_xyz_encoder is not None and has_timestamps
+        if dynamic:
+            normed_timestamps = data_dict["normed_timestamps"] if "normed_timestamps" in data_dict \
+                else data_dict["lidar_normed_timestamps"]
+            use_flow = self.flow_xyz_encoder is not None
+            dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
+                normed_positions, normed_timestamps, want_density=not use_flow)
+            if use_flow:
+                flow = self.forward_flow_hash(normed_positions, normed_timestamps)
+                forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
+                results_dict["forward_flow"] = forward_flow
+                results_dict["backward_flow"] = backward_flow
+                agg = self.temporal_aggregation(positions, normed_timestamps, forward_flow, backward_flow, dynamic_feats)
+                dynamic_feats = agg["dynamic_feats"]
+                agg["current_dynamic_hash_encodings"] = dynamic_hash_encodings
+                results_dict.update(agg)
+                dynamic_density = ops.trunc_exp_column(dynamic_feats, 0)
+            dynamic_geo_feats, dynamic_semantic_feats = torch.split(
+                dynamic_feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
+            density = static_density + dynamic_density
+            results_dict.update({"density": density, "static_density": static_density, "dynamic_density": dynamic_density})
+            if return_density_only:
+                return results_dict
+            if directions is not None:
+                rgb_results = self.query_rgb(directions, geo_feats, dynamic_geo_feats, data_dict=data_dict)
+                results_dict["dynamic_rgb"] = rgb_results["dynamic_rgb"]
+                results_dict["static_rgb"] = rgb_results["rgb"]
+                if combine_static_dynamic:
+                    static_ratio = static_density / (density + 1e-6)
+                    dynamic_ratio = dynamic_density / (density + 1e-6)
+                    results_dict["rgb"] = static_ratio[..., None] * results_dict["static_rgb"] \
+                        + dynamic_ratio[..., None] * results_dict["dynamic_rgb"]
+            if self.enable_shadow_head:
+                shadow_ratio = _run_sequential(self.shadow_head, dynamic_geo_feats)
+                results_dict["shadow_ratio"] = shadow_ratio
+                if combine_static_dynamic and "rgb" in results_dict:
+                    results_dict["rgb"] = static_ratio[..., None] * results_dict["rgb"] * (1 - shadow_ratio) \
+                        + dynamic_ratio[..., None] * results_dict["dynamic_rgb"]
+        else:
+            results_dict["density"] = static_density
+            if return_density_only:
+                return results_dict
+            if directions is not None:
+                results_dict["rgb"] = self.query_rgb(directions, geo_feats, data_dict=data_dict)["rgb"]
+
+        if self.enable_feature_head and query_feature_head:
+            if self.enable_learnable_pe and query_pe_head:
+                pe = F.grid_sample(self.learnable_pe_map, data_dict["pixel_coords"].reshape(1, 1, -1, 2) * 2 - 1,
+                                   align_corners=False, mode="bilinear").squeeze(2).squeeze(0).permute(1, 0)
+                results_dict["dino_pe"] = _run_sequential(self.pe_head, pe.contiguous())
+            dino_feats = _run_sequential(self.dino_head, semantic_feats)
+            if dynamic:
+                dynamic_dino_feats = _run_sequential(self.dino_head, dynamic_semantic_feats)
+                results_dict["static_dino_feat"] = dino_feats
+                results_dict["dynamic_dino_feat"] = dynamic_dino_feats
+                if combine_static_dynamic:
+                    static_ratio = static_density / (density + 1e-6)
+                    dynamic_ratio = dynamic_density / (density + 1e-6)
+                    results_dict["dino_feat"] = static_ratio[..., None] * dino_feats + dynamic_ratio[..., None] * dynamic_dino_feats
+            else:
+                results_dict["dino_feat"] = dino_feats
+
+        # sky (the reference's gate looks for a key that never exists, so lidar rays skip sky only through
+        # return_density_only; reproduced as is, :540-549)
+        if self.enable_sky_head and "lidar_origin" not in data_dict and directions is not None:
+            sky_dirs = directions[:, 0]
+            reduced = {k: v[:, 0] for k, v in data_dict.items()}
+            results_dict.update(self.query_sky(sky_dirs, data_dict=reduced))
+        return results_dict
+
+    def query_flow(self, positions: Tensor, normed_timestamps: Tensor, query_density: bool = True) -> Dict[str, Tensor]:
+        """:688-713."""
+        normed_positions = self.contract_points(positions)
+        flow = self.forward_flow_hash(normed_positions, normed_timestamps)
+        results = {"forward_flow": flow[..., :3], "backward_flow": flow[..., 3:]}
+        if query_density:
+            _, _, density = self._dynamic(normed_positions, normed_timestamps, want_density=True)
+            results["dynamic_density"] = density
+        return results
+
+    def query_attributes(self, positions: Tensor, normed_timestamps: Tensor = None, query_feature_head: bool = True):
+        """:715-785."""
+        data = {} if normed_timestamps is None else {"normed_timestamps": normed_timestamps}
+        out = self.forward(positions, None, data, combine_static_dynamic=False,
+                           query_feature_head=query_feature_head, query_pe_head=False)
+        if "static_dino_feat" in out:
+            d = out["density"].unsqueeze(-1)
+            out["dino_feat"] = (out["static_density"].unsqueeze(-1) * out["static_dino_feat"]
+                                + out["dynamic_density"].unsqueeze(-1) * out["dynamic_dino_feat"]) / (d + 1e-6)
+        return out
+
+
+class DensityField(nn.Module):
+    """Proposal network: radiance_fields/radiance_field.py:788-841."""
+
+    def __init__(self, xyz_encoder: HashEncoder, aabb: Union[Tensor, List[float]] = [[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]],
+                 num_dims: int = 3, density_activation: Optional[Callable] = None, unbounded: bool = False,
+                 base_mlp_layer_width: int = 64) -> None:
+        super().__init__()
+        if density_activation is not None:
+            raise NotImplementedError("only the reference's default density activation trunc_exp(x - 1) is fused")
+        if not isinstance(aabb, Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb)
+        self.num_dims, self.unbounded = num_dims, unbounded
+        self.xyz_encoder = xyz_encoder
+        self.base_mlp = nn.Sequential(nn.Linear(self.xyz_encoder.n_output_dims, base_mlp_layer_width), nn.ReLU(),
+                                      nn.Linear(base_mlp_layer_width, 1))
+
+    @property
+    def device(self) -> torch.device:
+        return self.aabb.device
+
+    def set_aabb(self, aabb: Union[Tensor, List[float]]) -> None:
+        if not isinstance(aabb, Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        logger.info(f"Set propnet aabb from {self.aabb} to {aabb}")
+        self.aabb.copy_(aabb)
+        self.aabb = self.aabb.to(self.device)
+
+    def density_from_normed(self, normed: Tensor) -> Tensor:
+        """normed [..., 3] already contracted -> density [..., 1]."""
+        enc = self.xyz_encoder(normed.reshape(-1, self.num_dims))
+        lin0, lin1 = self.base_mlp[0], self.base_mlp[2]
+        h = ops.linear(enc, lin0.weight, lin0.bias, "relu")
+        d = ops.linear(h, lin1.weight, lin1.bias, "trunc_exp")
+        return d.view(*normed.shape[:-1], 1)
+
+    def forward(self, positions: Tensor, data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
+        normed = ops.contract_points(positions, self.aabb.reshape(-1), self.unbounded)
+        return {"density": self.density_from_normed(normed)}
+
+
+def build_radiance_field_from_cfg(cfg, verbose=True) -> RadianceField:
+    """radiance_fields/radiance_field.py:907-946 (including the hard-coded flow grid, :916-923)."""
+    xyz_encoder = build_xyz_encoder_from_cfg(cfg.xyz_encoder, verbose=verbose)
+    dynamic_xyz_encoder = flow_xyz_encoder = None
+    if cfg.head.enable_dynamic_branch:
+        dynamic_xyz_encoder = build_xyz_encoder_from_cfg(cfg.dynamic_xyz_encoder, verbose=verbose)
+    if cfg.head.enable_flow_branch:
+        flow_xyz_encoder = HashEncoder(n_input_dims=4, n_levels=10, base_resolution=16, max_resolution=4096,
+                                       log2_hashmap_size=18, n_features_per_level=4, verbose=verbose)
+    return RadianceField(
+        xyz_encoder=xyz_encoder, dynamic_xyz_encoder=dynamic_xyz_encoder, flow_xyz_encoder=flow_xyz_encoder,
+        unbounded=cfg.unbounded, num_cams=cfg.num_cams,
+        geometry_feature_dim=cfg.neck.geometry_feature_dim, base_mlp_layer_width=cfg.neck.base_mlp_layer_width,
+        head_mlp_layer_width=cfg.head.head_mlp_layer_width, enable_cam_embedding=cfg.head.enable_cam_embedding,
+        enable_img_embedding=cfg.head.enable_img_embedding, appearance_embedding_dim=cfg.head.appearance_embedding_dim,
+        enable_sky_head=cfg.head.enable_sky_head, enable_feature_head=cfg.head.enable_feature_head,
+        semantic_feature_dim=cfg.neck.semantic_feature_dim, feature_mlp_layer_width=cfg.head.feature_mlp_layer_width,
+        feature_embedding_dim=cfg.head.feature_embedding_dim, enable_shadow_head=cfg.head.enable_shadow_head,
+        num_train_timesteps=cfg.num_train_timesteps, interpolate_xyz_encoding=cfg.head.interpolate_xyz_encoding,
+        enable_learnable_pe=cfg.head.enable_learnable_pe,
+        enable_temporal_interpolation=cfg.head.enable_temporal_interpolation)
+
+
+def build_density_field(aabb=[[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]], type: str = "HashEncoder", n_input_dims: int = 3,
+                        n_levels: int = 5, base_resolution: int = 16, max_resolution: int = 128,
+                        log2_hashmap_size: int = 20, n_features_per_level: int = 2, unbounded: bool = True) -> DensityField:
+    """radiance_fields/radiance_field.py:949-975."""
+    if type != "HashEncoder":
+        raise NotImplementedError(f"Unknown (xyz_encoder) type: {type}")
+    enc = HashEncoder(n_input_dims=n_input_dims, n_levels=n_levels, base_resolution=base_resolution,
+                      max_resolution=max_resolution, log2_hashmap_size=log2_hashmap_size,
+                      n_features_per_level=n_features_per_level, verbose=False)
+    return DensityField(xyz_encoder=enc, aabb=aabb, unbounded=unbounded)

@@ -86,6 +86,13 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
                              int64_t dout_stride_n, int64_t dout_stride_l, void *grad,
                              int grad_dtype, int64_t n, void *stream);
 
+/* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
+ * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice and
+ * streams the samples ("owner computes"; see csrc/hashgrid.hip).  This is the training path. */
+int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
+                                    const float *dout, int64_t dout_stride_n,
+                                    int64_t dout_stride_l, float *grad, int64_t n, void *stream);
+
 /* dX[n, d] = sum_l scale_l sum_f dOut * d(interp)/dx.  Replaces the input path of native.bwd
  * (needed by the flow configs, radiance_fields/radiance_field.py:572-608). */
 int emer_hashgrid_bwd_input(const emer_grid_desc *host_desc, const float *x, const void *params,
@@ -160,22 +167,32 @@ int emer_accumulate_bwd(const float *weights, const float *values, const float *
  *   elementwise launches).  fp32-exact MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain.
  * ---------------------------------------------------------------------------------------------- */
 /* Y[M,N] = act(X[M,K] @ W[N,K]^T + bias[N]).  ldx/ldy: row strides (elements).  W row-major
- * [N,K] (torch Linear layout).  bias may be NULL. */
+ * [N,K] (torch Linear layout).  bias may be NULL.  aux_density (may be NULL): receives
+ * exp(pre[:,0] - 1), the density read off geometry feature 0 (radiance_field.py:28,422). */
 int emer_linear_fwd(const float *x, int64_t ldx, const float *w, const float *bias, float *y,
-                    int64_t ldy, int64_t m, int32_t n, int32_t k, int act, void *stream);
+                    int64_t ldy, int64_t m, int32_t n, int32_t k, int act, float *aux_density,
+                    void *stream);
 /* Backward of the above.  dy [M,N] (ld ldy), y [M,N] = saved forward output (for act').
  *   dpre = dy * act'(y)                     (written to dpre_ws [M,N], contiguous workspace)
+ *   dpre[:,0] += d_aux_density * min(aux_density, e^15)   (when d_aux_density != NULL; dy may then be NULL)
  *   dx [M,K] = dpre @ W                     (skipped when dx == NULL)
  *   dw [N,K] += dpre^T @ X ; dbias [N] += column sums of dpre   (skipped when dw == NULL) */
 int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x,
                     int64_t ldx, const float *w, float *dpre_ws, float *dx, int64_t lddx,
                     float *dw, float *dbias, int64_t m, int32_t n, int32_t k, int act,
-                    void *stream);
+                    const float *d_aux_density, const float *aux_density, void *stream);
+
+/* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
+ * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */
+int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, void *stream);
+int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_stride, int64_t n,
+                       void *stream);
 
 /* Direction encoding used by the rgb / sky heads: d -> (d+1)/2 -> [x, sin(2^i x), sin(2^i x + pi/2)]
  * i = 0..max_deg (radiance_fields/encodings.py:60-104, radiance_field.py:629-632).
- * dirs [n,3] -> out [n, 3*(1+2*(max_deg+1))]. */
-int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, void *stream);
+ * dirs [n,3] -> out [n, 3*(1+2*(max_deg+1))].  remap != 0 applies the (d+1)/2 step first. */
+int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, int remap,
+                    void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam as configured in builders.py:50-60,114-120: eps 1e-15,

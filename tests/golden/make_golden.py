@@ -1,0 +1,269 @@
+"""Generate golden vectors by running the REFERENCE's own Python on CPU (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+/root/reference's radiance_fields / render_utils / nerfacc_prop_net are imported UNMODIFIED on top of the
+import shims of oracle/ref_shims.py (CPU oracle standing in for the absent tcnn / nerfacc binaries).  Each
+case records everything a second implementation needs to reproduce the run bit-for-bit in control flow:
+seeded inputs, every parameter tensor (by the reference's state_dict name), the stratified jitter and
+temporal-aggregation noise the reference drew, then the outputs, the loss and selected gradients.
+
+The .npz files are committed; the GPU box has no /root/reference, so tests only ever read the fixtures.
+Tables are kept tiny (log2_hashmap_size 11-13) so the fixtures stay small.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+AABB = [-20.0, -40.0, 0.0, 80.0, 40.0, 20.0]  # configs/default_config.yaml:42
+
+
+def model_cfg(kind: str):
+    """Nested config equivalent to configs/default_config.yaml:40-105 with small grids."""
+    from oracle.ref_shims import ns
+    dyn = kind in ("dynamic", "flow", "feature")
+    return ns(
+        xyz_encoder=dict(type="HashEncoder", n_input_dims=3, n_levels=6, n_features_per_level=4, base_resolution=16,
+                         max_resolution=512, log2_hashmap_size=13),
+        dynamic_xyz_encoder=dict(type="HashEncoder", n_input_dims=4, n_levels=5, n_features_per_level=4,
+                                 base_resolution=8, max_resolution=128, log2_hashmap_size=12),
+        neck=dict(base_mlp_layer_width=64, geometry_feature_dim=64, semantic_feature_dim=16),
+        head=dict(head_mlp_layer_width=64, enable_cam_embedding=kind == "feature", enable_img_embedding=kind != "feature",
+                  appearance_embedding_dim=16, enable_sky_head=True, enable_feature_head=kind == "feature",
+                  feature_embedding_dim=16, feature_mlp_layer_width=32, enable_learnable_pe=True,
+                  enable_dynamic_branch=dyn, enable_shadow_head=dyn, interpolate_xyz_encoding=True,
+                  enable_temporal_interpolation=False, enable_flow_branch=kind in ("flow", "feature")),
+        unbounded=True, num_cams=3 if kind == "feature" else 1, num_train_timesteps=10,
+    )
+
+
+def render_cfg(prop_samples, num_samples, chunk=100):
+    from oracle.ref_shims import ns
+    return ns(nerf=dict(sampling=dict(num_samples=num_samples),
+                        propnet=dict(num_samples_per_prop=prop_samples, near_plane=0.1, far_plane=1000.0,
+                                     sampling_type="uniform_lindisp")),
+              render=dict(render_chunk_size=chunk))
+
+
+PROP_KW = [dict(n_levels=4, max_resolution=64, log2_hashmap_size=11, n_features_per_level=1),
+           dict(n_levels=4, max_resolution=128, log2_hashmap_size=12, n_features_per_level=1)]
+
+
+def make_rays(R, seed, n_timesteps=10, num_cams=1, image_shape=None):
+    """Synthetic rays of SURVEY.md section 8d."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.stack([torch.rand(R, generator=g) * 60, torch.rand(R, generator=g) * 4 - 2, torch.rand(R, generator=g) + 1.5], -1)
+    d = torch.nn.functional.normalize(torch.tensor([1.0, 0.0, 0.0]) + 0.6 * torch.randn(R, 3, generator=g), dim=-1)
+    img_idx = torch.randint(0, n_timesteps * num_cams, (R,), generator=g)
+    data = {
+        "origins": o, "viewdirs": d, "direction_norms": torch.ones(R, 1),
+        "pixel_coords": torch.rand(R, 2, generator=g),
+        "normed_timestamps": torch.randint(0, n_timesteps, (R,), generator=g).float() / (n_timesteps - 1),
+        "img_idx": img_idx, "cam_idx": img_idx % num_cams,
+        "pixels": torch.rand(R, 3, generator=g), "sky_masks": (torch.rand(R, generator=g) < 0.15).float(),
+        "features": torch.rand(R, 16, generator=g),
+    }
+    if image_shape is not None:
+        H, W = image_shape
+        data = {k: v.reshape(H, W, *v.shape[1:]) for k, v in data.items()}
+    return data
+
+
+def table_values(tag: str, numel: int, seed: int) -> torch.Tensor:
+    """Deterministic U(-0.5, 0.5) table for the parameter called ``tag`` (tables are NOT stored in the
+    fixtures: the reference hard-codes a 9.7 M-parameter flow grid, radiance_field.py:916-923)."""
+    import zlib
+    g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(tag.encode()) % 1000003)
+    return torch.rand(numel, generator=g) - 0.5
+
+
+def randomize_tables(named_modules, seed):
+    """tcnn's +-1e-4 init makes every output degenerate; parity runs on tables ~U(-0.5,0.5).
+    named_modules: {prefix: module}; every '*tcnn_encoding.params' gets table_values(prefix + name)."""
+    with torch.no_grad():
+        for prefix, m in named_modules.items():
+            for name, p in m.named_parameters():
+                if name.endswith("tcnn_encoding.params"):
+                    p.copy_(table_values(prefix + name, p.numel(), seed).to(p.device))
+
+
+BIG = 200_000  # tensors above this size are stored as digests
+
+
+def digest_indices(numel: int) -> torch.Tensor:
+    return torch.randint(0, numel, (4096,), generator=torch.Generator().manual_seed(numel))
+
+
+def put(out: dict, key: str, t: torch.Tensor):
+    """Store a tensor, or for big ones a digest: 4096 sampled entries + L2 norm + sum."""
+    t = t.detach().cpu()
+    if t.numel() <= BIG:
+        out[key] = t.numpy()
+    else:
+        flat = t.reshape(-1).double()
+        out[key + "@sample"] = flat[digest_indices(flat.numel())].float().numpy()
+        out[key + "@norm"] = flat.norm().numpy()
+        out[key + "@sum"] = flat.sum().numpy()
+
+
+def golden_loss(results, data, prefix=""):
+    """The scalar every implementation back-propagates in the golden step (pieces of
+    train_emernerf.py:657-741 with the default coefficients of configs/default_config.yaml:116-150)."""
+    import torch.nn.functional as F
+    loss = 0.0
+    if "rgb" in results:
+        loss = loss + F.mse_loss(results["rgb"].squeeze(), data["pixels"].squeeze())
+        loss = loss + 0.001 * F.binary_cross_entropy(results["opacity"].squeeze(), 1 - data["sky_masks"].float().squeeze())
+    else:  # lidar rays: depth only
+        loss = loss + F.mse_loss(results["depth"].squeeze(), data["lidar_ranges"].squeeze()) * 1e-4
+    ex = results["extras"]
+    if "dino_feat" in results:
+        loss = loss + 0.5 * F.mse_loss(results["dino_feat"], data["features"])
+    if "dynamic_density" in ex:
+        loss = loss + 0.01 * ex["dynamic_density"].mean()
+    if "shadow_ratio" in results:
+        loss = loss + 0.01 * results["shadow_ratio"].mean()
+    if "forward_flow" in ex:
+        cyc = 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
+                     + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
+        loss = loss + 0.01 * cyc
+    return loss
+
+
+GRAD_KEYS = ["base_mlp.0.weight", "base_mlp.2.bias", "rgb_head.layers.1.weight", "rgb_head.layers.2.weight",
+             "xyz_encoder.tcnn_encoding.params", "dynamic_xyz_encoder.tcnn_encoding.params",
+             "flow_xyz_encoder.tcnn_encoding.params", "dynamic_base_mlp.2.weight", "flow_mlp.4.weight",
+             "shadow_head.0.weight", "appearance_embedding.weight", "sky_head.layers.0.weight", "dino_head.4.weight",
+             "learnable_pe_map", "pe_head.0.weight"]
+
+
+def _flat(prefix, d, out):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _flat(prefix + k + "/", v, out)
+        elif isinstance(v, torch.Tensor):
+            out[prefix + k] = v.detach().cpu().numpy()
+
+
+def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int, image_shape=None, lidar=False):
+    """mode: 'train' (stratified, prop nets trained, backward) or 'eval' (decomposition, chunked)."""
+    from oracle import ref_shims
+    ref_shims.install()
+    import radiance_fields as ref_rf  # the reference's own package
+    from radiance_fields import render_utils as ref_render
+    from third_party import nerfacc_prop_net as ref_prop
+
+    torch.manual_seed(seed)
+    cfg = model_cfg(kind)
+    model = ref_rf.build_radiance_field_from_cfg(cfg, verbose=False)
+    model.set_aabb(AABB)
+    model.register_normalized_training_timesteps(torch.linspace(0, 1, cfg.num_train_timesteps), time_diff=1 / cfg.num_train_timesteps)
+    props = [ref_rf.build_density_field(aabb=AABB, unbounded=True, **kw) for kw in PROP_KW]
+    randomize_tables({"model/": model, **{f"prop{i}/": p for i, p in enumerate(props)}}, seed + 1)
+    out_seed = seed + 1
+    prop_opt = torch.optim.Adam([p for n in props for p in n.parameters()], lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
+    est = ref_prop.PropNetEstimator(prop_opt, None)
+    rcfg = render_cfg(list(prop_samples), num_samples)
+
+    data = make_rays(R, seed + 2, cfg.num_train_timesteps, cfg.num_cams, image_shape)
+    prefix = ""
+    if lidar:
+        prefix = "lidar_"
+        data = {"lidar_origins": data["origins"], "lidar_viewdirs": data["viewdirs"],
+                "lidar_ranges": torch.rand(R, 1, generator=torch.Generator().manual_seed(seed + 3)) * 60 + 2,
+                "lidar_normed_timestamps": data["normed_timestamps"]}
+
+    out = {}
+    state = {}
+    _flat("model/", dict(model.state_dict()), state)
+    for i, p in enumerate(props):
+        _flat(f"prop{i}/", dict(p.state_dict()), state)
+    _flat("data/", data, out)
+    out.update({"state/" + k: v for k, v in state.items() if not k.endswith("tcnn_encoding.params")})
+    out["table_seed"] = np.array(out_seed)
+
+    train = mode == "train"
+    model.train(train); est.train(train)
+    for p in props:
+        p.train(train)
+    ref_shims.JITTER_LOG.clear()
+    noise_log = []
+    orig_rand_like = torch.rand_like
+
+    def logging_rand_like(t, *a, **k):  # temporal-aggregation noise (radiance_field.py:567-568)
+        r = orig_rand_like(t, *a, **k)
+        noise_log.append(r.detach().clone())
+        return r
+
+    torch.rand_like = logging_rand_like
+    try:
+        results = ref_render.render_rays(radiance_field=model, proposal_estimator=est, proposal_networks=props,
+                                         data_dict=data, cfg=rcfg, proposal_requires_grad=train,
+                                         return_decomposition=not train, prefix=prefix)
+    finally:
+        torch.rand_like = orig_rand_like
+    for i, j in enumerate(ref_shims.JITTER_LOG):
+        out[f"jitter/{i}"] = j.numpy()
+    for i, n in enumerate(noise_log):
+        out[f"noise/{i}"] = n[..., 0:1].numpy()
+    _flat("out/", {k: v for k, v in results.items() if k != "extras"}, out)
+    _flat("extras/", results["extras"], out)
+
+    if train:
+        # proposal-network loss and its gradients (update_every_n_steps -> compute_loss, :181-238)
+        prop_loss = est.compute_loss(results["extras"]["trans"], loss_scaler=1024)
+        for p in props:
+            p.zero_grad()
+        prop_loss.backward()
+        out["prop_loss"] = prop_loss.detach().numpy()
+        for i, p in enumerate(props):
+            # NB: render_utils.py:356-358 builds the level closures with a late-binding lambda, so every level
+            # queries the LAST proposal network; the others receive no gradient (recorded as absent).
+            for k, q in p.named_parameters():
+                out[f"prop_has_grad/{i}/{k}"] = np.array(q.grad is not None)
+                if q.grad is not None and k in ("base_mlp.0.weight", "base_mlp.2.weight", "xyz_encoder.tcnn_encoding.params"):
+                    put(out, f"prop_grad/{i}/{k}", q.grad)
+        loss = golden_loss(results, data, prefix)
+        model.zero_grad()
+        loss.backward()
+        out["loss"] = loss.detach().numpy()
+        named = dict(model.named_parameters())
+        for k in GRAD_KEYS:
+            if k in named and named[k].grad is not None:
+                put(out, "grad/" + k, named[k].grad)
+    return out
+
+
+CASES = {
+    # name: kwargs of run_case
+    "static_train": dict(kind="static", mode="train", R=40, prop_samples=(32, 16), num_samples=24, seed=100),
+    "dynamic_train": dict(kind="dynamic", mode="train", R=32, prop_samples=(24, 16), num_samples=16, seed=200),
+    "flow_train": dict(kind="flow", mode="train", R=24, prop_samples=(24, 16), num_samples=16, seed=300),
+    "flow_lidar_train": dict(kind="flow", mode="train", R=24, prop_samples=(24, 16), num_samples=16, seed=400, lidar=True),
+    "feature_eval_image": dict(kind="feature", mode="eval", R=60, prop_samples=(24, 16), num_samples=16, seed=500, image_shape=(6, 10)),
+    "feature_train": dict(kind="feature", mode="train", R=20, prop_samples=(16, 8), num_samples=12, seed=600),
+    "static_eval_chunked": dict(kind="static", mode="eval", R=240, prop_samples=(32, 16), num_samples=24, seed=700),
+}
+
+
+def main():
+    only = sys.argv[1:]
+    for name, kw in CASES.items():
+        if only and name not in only:
+            continue
+        out = run_case(**kw)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--grid", default="3,16,16,2048,19,2")
     ap.add_argument("--clustered", action="store_true", help="cluster samples near a surface (trained-like)")
+    ap.add_argument("--per-level", action="store_true", help="time each level of the grid as a 1-level grid")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     R, S = args.rays, args.samples
@@ -66,6 +67,26 @@ def main():
     times = torch.rand(R, device=dev) if D == 4 else None
     x, _ = ops.ray_points(o, d, ts, te, aabb, True, times=times)
     x = x.view(N, D)
+    if args.per_level:
+        import ctypes
+        full = desc
+        rows = []
+        for l in range(L):
+            r = int(full.res[l])
+            d1 = _lib.make_grid_desc(D, 1, F, T, r, 1.0)
+            assert int(d1.res[0]) == r, (r, int(d1.res[0]))
+            p = torch.rand(d1.n_entries * F, device=dev) - 0.5
+            dlm = torch.randn(1, N, F, device=dev)
+            g1 = torch.zeros(d1.n_entries * F, device=dev)
+            f_us, _ = timeit(lambda: ops.hashgrid_fwd_raw(d1, x, p, level_major=True), iters=10)
+            a_us, _ = timeit(lambda: _lib.call("emer_hashgrid_bwd_params", ctypes.byref(d1), ops._ptr(x), ops._ptr(dlm), F, N * F,
+                                               ops._ptr(g1), 0, N, ops._stream(x)), iters=5)
+            s_us, _ = timeit(lambda: _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(d1), ops._ptr(x), ops._ptr(dlm), F,
+                                               N * F, ops._ptr(g1), N, ops._stream(x)), iters=5)
+            rows.append({"level": l, "res": r, "entries": int(d1.n_entries), "hashed": int(d1.hashed[0]), "fwd_us": round(f_us, 1),
+                         "bwd_atomic_us": round(a_us, 1), "bwd_sliced_us": round(s_us, 1)})
+            print(rows[-1], flush=True)
+        return
     res = {"shape": [R, S], "grid": [D, L, base, mx, T, F], "n_params": desc.n_entries * F, "clustered": args.clustered}
     inside = float((x[:, :3] != 0).any(-1).float().mean())
     res["frac_inside"] = inside
@@ -91,6 +112,16 @@ def main():
             res[f"bwd_params_{dt_name}_us"] = med
             res[f"bwd_params_{dt_name}_algGBps"] = b_bwd * N / med / 1e3
         if dt == torch.float32:
+            g2 = torch.empty(desc.n_entries * F, device=dev)
+
+            def bwd_sl():
+                _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F,
+                          ops._ptr(g2), N, ops._stream(x))
+            med, best = timeit(bwd_sl)
+            res["bwd_params_sliced_f32_us"] = med
+            res["bwd_params_sliced_f32_algGBps"] = (4 * D + L * F * 4 + 2 * (2 ** D) * L * F * 4) * N / med / 1e3
+            grad.zero_(); bwd(); torch.cuda.synchronize()
+            res["sliced_vs_atomic_maxrel"] = float((g2 - grad).abs().max() / grad.abs().max())
             dx = torch.empty_like(x)
 
             def bwd_in():
