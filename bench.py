@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train rays/s of the EmerNeRF hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 24 --warmup 6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimizer step on one synthetic ray batch per rank (BASELINE.json configs[1]: static-only
+RadianceField, HashEncoder defaults D3/L16/F2/T2^19, 8192 rays x 128 samples, proposal rounds of 128 and 64):
+proposal sampling -> field -> compositing -> losses -> backward -> (one RCCL all-reduce of the flat grad
+buffer) -> fused Adam.  Inputs (rays, parameters) are resident in HBM before the timed region.  Weak scaling:
+every rank draws its own 8192 rays; value = world * rays * steps / max-over-ranks(time).
+
+Prints ONE JSON line on rank 0 (fields per the driver contract + "roofline" + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
+    """Algorithmic bytes per sample: fwd, bwd_params."""
+    fwd = 4 * D + (2 ** D) * L * F * sp + L * F * so
+    bwd = 4 * D + L * F * so + 2 * (2 ** D) * L * F * sg
+    return fwd, bwd
+
+
+def cpu_baseline(trainer, rays: int, samples: int, steps: int = 2):
+    """Oracle port (oracle/ref_path.py on the C oracle) timed on this box's host cores, bounded sample."""
+    from oracle import oracle as O
+    from oracle.ref_path import RefPath
+    from emernerf_amd.trainer import AABB, PROP_KW, synthetic_rays
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    c = trainer.cfg
+    grids = {"model/xyz_encoder": O.grid_meta_from_encoder_args(3, c.xyz_encoder.n_levels, c.xyz_encoder.base_resolution,
+                                                                 c.xyz_encoder.max_resolution, c.xyz_encoder.log2_hashmap_size,
+                                                                 c.xyz_encoder.n_features_per_level)}
+    for i, kw in enumerate(PROP_KW):
+        grids[f"prop{i}/xyz_encoder"] = O.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
+                                                                      kw["log2_hashmap_size"], kw["n_features_per_level"])
+    ms = {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}
+    ps = [{k: v.detach().cpu() for k, v in p.state_dict().items()} for p in trainer.props]
+    ref = RefPath(ms, ps, grids, AABB)
+    opt_main = torch.optim.Adam(ref.trainable("model/"), lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
+    opt_prop = torch.optim.Adam(ref.trainable("prop"), lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
+    data = synthetic_rays(rays, "cpu", seed=123)
+    g = torch.Generator().manual_seed(7)
+    prop_samples = trainer.rcfg.nerf.propnet.num_samples_per_prop
+
+    def one(prop_grad):
+        jit = [torch.rand(rays, generator=g) for _ in range(len(prop_samples) + 1)]
+        ref.train_step(data, opt_main, opt_prop, samples, prop_samples, jitters=jit, prop_grad=prop_grad)
+
+    one(True)  # warm-up (allocations, OpenMP pool)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i % 6 == 0)
+    dt = time.perf_counter() - t0
+    return {"value": rays * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full optimizer steps of {rays} rays x {samples} samples (same model/config, 1 in 6 steps "
+                      f"trains the proposal nets), oracle/ref_path.py on oracle/emer_oracle.c, torch {torch.get_num_threads()} "
+                      f"threads + OpenMP; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--rays", type=int, default=8192)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--kind", default="static", choices=["static", "dynamic", "flow"])
+    ap.add_argument("--table-init", type=float, default=None, help="U(-a,a) tables instead of tcnn's +-1e-4 init")
+    ap.add_argument("--start-step", type=int, default=1000, help="training step the run starts at (1000 = steady-state "
+                    "proposal schedule: 1 step in 6 trains the proposal nets, nerfacc_prop_net.py:280-296)")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    from emernerf_amd import _build, _lib
+    if rank == 0 or not os.path.exists(_build.LIB_PATH):
+        _build.build()
+    if world > 1:
+        dist.barrier()
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+
+    trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init)
+    trainer.step_count = args.start_step
+    # advance the proposal schedule to its state at start_step
+    fn = trainer.requires_grad_fn
+    for s in range(args.start_step):
+        fn(s)
+    data = synthetic_rays(args.rays, dev, seed=1000 + rank)  # each rank its own rays (weak scaling)
+
+    for _ in range(args.warmup):
+        trainer.train_step(data)
+
+    timed = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params", "emer_hashgrid_bwd_input",
+             "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose", "emer_render_weights_fwd", "emer_render_weights_bwd",
+             "emer_accumulate_fwd", "emer_accumulate_bwd", "emer_importance_sample", "emer_ray_points", "emer_adam_step",
+             "emer_dir_encode", "emer_contract_fwd"]
+    timer = _lib.KernelTimer(timed) if rank == 0 else None
+    _lib.TIMER = timer
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        N = args.rays * args.samples
+        c = trainer.cfg.xyz_encoder
+        D, L, F = c.n_input_dims, c.n_levels, c.n_features_per_level
+        us = timer.elapsed_us()
+        tags = timer.tags
+
+        def main_grid(name):  # launches on the main (L-level, F-feature) grid only, not the proposal grids
+            return [u for u, tg in zip(us[name], tags[name]) if tg == (L, F)]
+
+        fwd_b, bwd_b = grid_alg_bytes(D, L, F)
+        f_us, b_us = main_grid("emer_hashgrid_fwd"), main_grid("emer_hashgrid_bwd_params_sliced")
+        f_avg = sum(f_us) / max(len(f_us), 1)
+        b_avg = sum(b_us) / max(len(b_us), 1)
+        per_kernel = {n: {"launches": len(v), "total_ms": sum(v) / 1e3, "avg_us": (sum(v) / len(v)) if v else 0.0}
+                      for n, v in us.items() if v}
+        dominant = "emer_hashgrid_bwd_params_sliced" if b_avg >= f_avg else "emer_hashgrid_fwd"
+        dom_us, dom_bytes = (b_avg, bwd_b * N) if dominant.endswith("sliced") else (f_avg, fwd_b * N)
+        ach = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+        both = (fwd_b + bwd_b) * N / ((f_avg + b_avg) * 1e-6) / 1e9 if (f_avg + b_avg) > 0 else 0.0
+        out = {
+            "metric": "train rays/sec (8192-ray batch, 128 samples)",
+            "value": world * args.rays * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: static-only RadianceField, hash grid D{D}/L{L}/F{F}/T2^{c.log2_hashmap_size} "
+                                   f"(fp32 tables, the reference's precision) + base MLP {L * F}->64->64 + rgb head 113->64->[177]->64->3 "
+                                   f"+ sky head, 2 proposal nets (L8/F1/T2^20), {args.rays} rays x {args.samples} samples per GPU, "
+                                   "proposal rounds 128+64, full optimizer step (Adam)",
+                       "kind": args.kind, "rays_per_gpu": args.rays, "samples": args.samples,
+                       "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
+                       "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
+                         "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
+                                                  "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
+            "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, args.samples)
+            except Exception as e:  # the baseline is reporting only; never lose the GPU number over it
+                out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,9 +85,42 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+class KernelTimer:
+    """Opt-in per-entry-point timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py to measure kernel durations live inside the timed region."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in self.names}
+        self.tags = {n: [] for n in self.names}
+        self.tag = None
+
+    def elapsed_us(self):
+        import torch
+        torch.cuda.synchronize()
+        return {n: [a.elapsed_time(b) * 1e3 for a, b in ev] for n, ev in self.events.items()}
+
+
+TIMER = None  # set to a KernelTimer to enable
+
+
 def call(name: str, *args) -> None:
     lib = load()
-    rc = getattr(lib, name)(*args)
+    t = TIMER
+    if t is not None and name in t.names:
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*args)
+        b.record()
+        t.events[name].append((a, b))
+        tag = None
+        if name.startswith("emer_hashgrid"):  # distinguish the main grid from the proposal grids
+            d = args[0]._obj
+            tag = (d.n_levels, d.n_features)
+        t.tags[name].append(tag)
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise EmerError(f"{name} failed (rc={rc}): {lib.emer_last_error().decode()}")
 

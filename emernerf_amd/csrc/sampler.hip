@@ -24,7 +24,8 @@ __host__ __device__ __forceinline__ float stot_fwd_map(int type, float t) {
     return t;
 }
 __device__ __forceinline__ float stot_inv_map(int type, float s) {
-    if (type == EMER_STOT_UNIFORM_LINDISP) return s < 0.5f ? s * 400.0f : 200.0f / (2.0f - 2.0f * s);
+    // torch evaluates `200 / (2 - 2*x)` (nerfacc_prop_net.py:308) as (2 - 2*x).reciprocal() * 200
+    if (type == EMER_STOT_UNIFORM_LINDISP) return s < 0.5f ? s * 400.0f : (1.0f / (2.0f - 2.0f * s)) * 200.0f;
     if (type == EMER_STOT_LINDISP) return 1.0f / s;
     return s;
 }

@@ -1,0 +1,212 @@
+"""One optimizer step of the hot path, data-parallel over ray batches.
+
+Shape of a step (train_emernerf.py:634-745, pixel rays): proposal_requires_grad schedule -> render_rays
+(2 proposal rounds + final resample -> field -> compositing) -> proposal loss -> rgb + sky losses ->
+backward -> optimizer step.  What is new relative to the reference (which is single-GPU):
+
+  * every trainable tensor (hash tables, MLPs, embeddings; main model AND proposal nets) is a view into
+    ONE contiguous fp32 buffer, and so is every gradient, so data parallelism costs exactly one RCCL
+    all-reduce of one flat buffer per step (``torch.distributed`` backend "nccl" = RCCL over xGMI);
+  * Adam runs as one fused HIP kernel per optimizer group over that buffer (torch.optim.Adam semantics of
+    builders.py:50-60,114-120, including the reference's never-unscaled GradScaler(2**10) quirk,
+    train_emernerf.py:475-476,742-745: gradients enter Adam multiplied by 1024);
+  * the proposal-net update and the main update are applied after the single all-reduce; neither backward
+    depends on the other's updated weights (samples are detached, nerfacc_prop_net.py:89), so this is
+    numerically the reference's order.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import ops
+from .prop_net import PropNetEstimator, get_proposal_requires_grad_fn
+from .radiance_field import DensityField, RadianceField, build_density_field, build_radiance_field_from_cfg
+from .render_utils import render_rays
+
+
+def ns(**kw):
+    return SimpleNamespace(**{k: ns(**v) if isinstance(v, dict) else v for k, v in kw.items()})
+
+
+AABB = [-20.0, -40.0, 0.0, 80.0, 40.0, 20.0]  # configs/default_config.yaml:42
+
+
+def model_config(kind: str = "static", num_train_timesteps: int = 50, num_cams: int = 1):
+    """Model configs named by BASELINE.json.
+
+    static  (configs[1]): HashEncoder defaults D3/L16/F2/T2^19 (encodings.py:110-118), base_mlp 32->64->64,
+             rgb head 113->64->[64+113]->64->3, sky head, per-image appearance embedding.
+    dynamic (configs[2]): configs/default_dynamic.yaml on top of default_config.yaml:60-105.
+    flow    (configs[3]): configs/default_flow.yaml.
+    """
+    if kind == "static":
+        xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=16, n_features_per_level=2, base_resolution=16,
+                   max_resolution=2048, log2_hashmap_size=19)
+    else:
+        xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=10, n_features_per_level=4, base_resolution=16,
+                   max_resolution=8192, log2_hashmap_size=20)
+    dyn = kind in ("dynamic", "flow")
+    return ns(
+        xyz_encoder=xyz,
+        dynamic_xyz_encoder=dict(type="HashEncoder", n_input_dims=4, n_levels=10, n_features_per_level=4, base_resolution=32,
+                                 max_resolution=8192, log2_hashmap_size=18),
+        neck=dict(base_mlp_layer_width=64, geometry_feature_dim=64, semantic_feature_dim=64),
+        head=dict(head_mlp_layer_width=64, enable_cam_embedding=False, enable_img_embedding=True, appearance_embedding_dim=16,
+                  enable_sky_head=True, enable_feature_head=False, feature_embedding_dim=64, feature_mlp_layer_width=64,
+                  enable_learnable_pe=True, enable_dynamic_branch=dyn, enable_shadow_head=dyn,
+                  interpolate_xyz_encoding=True, enable_temporal_interpolation=False, enable_flow_branch=kind == "flow"),
+        unbounded=True, num_cams=num_cams, num_train_timesteps=num_train_timesteps)
+
+
+def render_config(num_samples: int = 128, prop_samples=(128, 64), chunk: int = 16384):
+    return ns(nerf=dict(sampling=dict(num_samples=num_samples),
+                        propnet=dict(num_samples_per_prop=list(prop_samples), near_plane=0.1, far_plane=1000.0,
+                                     sampling_type="uniform_lindisp")),
+              render=dict(render_chunk_size=chunk))
+
+
+# default_config.yaml:51-58 / builders.py:99-108 (base_resolutions_per_prop is ignored by the reference)
+PROP_KW = [dict(n_levels=8, max_resolution=512, log2_hashmap_size=20, n_features_per_level=1),
+           dict(n_levels=8, max_resolution=2048, log2_hashmap_size=20, n_features_per_level=1)]
+
+
+def synthetic_rays(R: int, device, seed: int = 0, n_timesteps: int = 50, num_cams: int = 1) -> Dict[str, Tensor]:
+    """Seeded synthetic ray batch of SURVEY.md section 8d / BASELINE.md 2.2 (no dataset on the box)."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.stack([torch.rand(R, generator=g) * 60, torch.rand(R, generator=g) * 4 - 2, torch.rand(R, generator=g) + 1.5], -1)
+    d = F.normalize(torch.tensor([1.0, 0.0, 0.0]) + 0.6 * torch.randn(R, 3, generator=g), dim=-1)
+    img_idx = torch.randint(0, n_timesteps * num_cams, (R,), generator=g)
+    data = {"origins": o, "viewdirs": d, "direction_norms": torch.ones(R, 1), "pixel_coords": torch.rand(R, 2, generator=g),
+            "normed_timestamps": torch.randint(0, n_timesteps, (R,), generator=g).float() / (n_timesteps - 1),
+            "img_idx": img_idx, "cam_idx": img_idx % num_cams, "pixels": torch.rand(R, 3, generator=g),
+            "sky_masks": (torch.rand(R, generator=g) < 0.15).float()}
+    return {k: v.to(device) for k, v in data.items()}
+
+
+class FlatParams:
+    """Re-home every parameter (and gradient) of a list of modules into one contiguous fp32 buffer.
+
+    groups: {name: [modules]} -> contiguous [start, end) ranges, e.g. "main" and "prop".
+    """
+
+    def __init__(self, groups: Dict[str, List[torch.nn.Module]], device):
+        plist, self.ranges = [], {}
+        off = 0
+        for gname, mods in groups.items():
+            start = off
+            for m in mods:
+                for p in m.parameters():
+                    plist.append((p, off))
+                    off += p.numel()
+            self.ranges[gname] = (start, off)
+        self.numel = off
+        self.params = torch.empty(off, device=device, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=device, dtype=torch.float32)
+        for p, o in plist:
+            n = p.numel()
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+        self._plist = plist
+
+    def zero_grad(self):
+        self.grads.zero_()
+        for p, o in self._plist:  # autograd may have replaced .grad; re-pin the views
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+
+
+def lr_factor(step: int, num_iters: int) -> float:
+    """ChainedScheduler(LinearLR(0.01 -> 1 over num_iters//10), MultiStepLR(gamma 0.33)) of builders.py:64-89."""
+    warm = num_iters // 10
+    f = 0.01 + (1.0 - 0.01) * min(step, warm) / max(warm, 1)
+    milestones = [num_iters // 2, num_iters * 3 // 4, num_iters * 9 // 10]
+    if num_iters >= 10000:
+        milestones.insert(0, num_iters // 4)
+    return f * (0.33 ** sum(step >= m for m in milestones))
+
+
+class Trainer:
+    """Owns the model, proposal nets, estimator, flat buffers and optimizer state of one rank."""
+
+    def __init__(self, kind: str = "static", device="cuda:0", num_samples: int = 128, prop_samples=(128, 64), lr: float = 0.01,
+                 weight_decay: float = 1e-5, num_iters: int = 25000, loss_scale: float = 1024.0, seed: int = 0,
+                 world_size: int = 1, table_init: Optional[float] = None):
+        self.device = torch.device(device)
+        torch.manual_seed(seed)  # identical initial parameters on every rank
+        self.cfg = model_config(kind)
+        self.rcfg = render_config(num_samples, prop_samples)
+        self.model: RadianceField = build_radiance_field_from_cfg(self.cfg, verbose=False)
+        self.model.set_aabb(AABB)
+        if self.model.dynamic_xyz_encoder is not None:
+            self.model.register_normalized_training_timesteps(torch.linspace(0, 1, self.cfg.num_train_timesteps),
+                                                              time_diff=1 / self.cfg.num_train_timesteps)
+        self.props: List[DensityField] = [build_density_field(aabb=AABB, unbounded=True, **kw) for kw in PROP_KW]
+        if table_init is not None:  # "trained-like" tables instead of tcnn's +-1e-4 init
+            g = torch.Generator().manual_seed(seed + 1)
+            with torch.no_grad():
+                for m in [self.model] + self.props:
+                    for n, p in m.named_parameters():
+                        if n.endswith("tcnn_encoding.params"):
+                            p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * table_init)
+        self.model.to(self.device)
+        for p in self.props:
+            p.to(self.device)
+        self.estimator = PropNetEstimator(None, None).to(self.device)
+        self.flat = FlatParams({"main": [self.model], "prop": self.props}, self.device)
+        self.m = torch.zeros_like(self.flat.params)
+        self.v = torch.zeros_like(self.flat.params)
+        self.opt_steps = {"main": 0, "prop": 0}
+        self.lr, self.wd, self.num_iters, self.loss_scale = lr, weight_decay, num_iters, loss_scale
+        self.world_size = world_size
+        self.requires_grad_fn = get_proposal_requires_grad_fn()
+        self.step_count = 0
+        self.model.train(); self.estimator.train()
+        for p in self.props:
+            p.train()
+
+    def losses(self, results, data) -> Tensor:
+        """rgb L2 (loss/base.py:83-146, coef 1) + opacity-based sky BCE (loss/base.py:149-185, coef 0.001)."""
+        loss = F.mse_loss(results["rgb"].squeeze(), data["pixels"].squeeze())
+        loss = loss + 0.001 * F.binary_cross_entropy(results["opacity"].squeeze(), 1 - data["sky_masks"].float().squeeze())
+        if "dynamic_density" in results["extras"]:
+            loss = loss + 0.01 * results["extras"]["dynamic_density"].mean()
+        if "shadow_ratio" in results:
+            loss = loss + 0.01 * results["shadow_ratio"].mean()
+        if "forward_flow" in results["extras"]:
+            ex = results["extras"]
+            loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
+                                        + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
+        return loss
+
+    def _adam(self, group: str, lr: float):
+        a, b = self.flat.ranges[group]
+        self.opt_steps[group] += 1
+        ops.adam_step(self.flat.params[a:b], self.flat.grads[a:b], self.m[a:b], self.v[a:b], lr, 0.9, 0.99, 1e-15, self.wd,
+                      1.0 / self.world_size, self.opt_steps[group])
+
+    def train_step(self, data: Dict[str, Tensor]) -> Dict[str, float]:
+        step = self.step_count
+        prop_grad = self.requires_grad_fn(step)
+        self.flat.zero_grad()
+        results = render_rays(radiance_field=self.model, proposal_estimator=self.estimator, proposal_networks=self.props,
+                              data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad)
+        if prop_grad:
+            prop_loss = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
+            prop_loss.backward()
+        loss = self.losses(results, data)
+        (loss * self.loss_scale).backward()
+        if self.world_size > 1:
+            dist.all_reduce(self.flat.grads)  # the single RCCL collective of the step (sum; 1/W folded into Adam)
+        lr = self.lr * lr_factor(step, self.num_iters)
+        if prop_grad:
+            self._adam("prop", lr)
+        self._adam("main", lr)
+        self.step_count += 1
+        return {"loss": loss.detach(), "prop_grad": prop_grad}

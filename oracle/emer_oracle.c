@@ -270,7 +270,7 @@ static inline float orc_fwd_map(int type, float t) {
     return t;
 }
 static inline float orc_inv_map(int type, float s) {
-    if (type == 1) return s < 0.5f ? s * 400.0f : 200.0f / (2.0f - 2.0f * s);
+    if (type == 1) return s < 0.5f ? s * 400.0f : (1.0f / (2.0f - 2.0f * s)) * 200.0f; /* torch: scalar / tensor == tensor.reciprocal() * scalar */
     if (type == 2) return 1.0f / s;
     return s;
 }
