@@ -35,13 +35,14 @@ def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
     return fwd, bwd
 
 
-def cpu_baseline(trainer, rays: int, samples: int, steps: int = 2):
+def cpu_baseline(trainer, rays: int, samples: int, steps: int = 6):
     """Oracle port (oracle/ref_path.py on the C oracle) timed on this box's host cores, bounded sample."""
     from oracle import oracle as O
     from oracle.ref_path import RefPath
     from emernerf_amd.trainer import AABB, PROP_KW, synthetic_rays
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # more threads only add torch/OpenMP overhead at this sample size
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     c = trainer.cfg
     grids = {"model/xyz_encoder": O.grid_meta_from_encoder_args(3, c.xyz_encoder.n_levels, c.xyz_encoder.base_resolution,
                                                                  c.xyz_encoder.max_resolution, c.xyz_encoder.log2_hashmap_size,
@@ -62,7 +63,7 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 2):
         jit = [torch.rand(rays, generator=g) for _ in range(len(prop_samples) + 1)]
         ref.train_step(data, opt_main, opt_prop, samples, prop_samples, jitters=jit, prop_grad=prop_grad)
 
-    one(True)  # warm-up (allocations, OpenMP pool)
+    one(False)  # warm-up (allocations, OpenMP pool)
     t0 = time.perf_counter()
     for i in range(steps):
         one(i % 6 == 0)
@@ -84,7 +85,7 @@ def main():
     ap.add_argument("--table-init", type=float, default=None, help="U(-a,a) tables instead of tcnn's +-1e-4 init")
     ap.add_argument("--start-step", type=int, default=1000, help="training step the run starts at (1000 = steady-state "
                     "proposal schedule: 1 step in 6 trains the proposal nets, nerfacc_prop_net.py:280-296)")
-    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

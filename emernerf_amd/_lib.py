@@ -39,9 +39,11 @@ _GP = ctypes.POINTER(GridDesc)
 # name -> argtypes; every entry must be declared in include/emernerf_hip.h (tests check both ways)
 SIGNATURES = {
     "emer_grid_desc_init": [_GP, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_float],
-    "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, c_int64, _P],
+    "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_hashgrid_bwd_params": [_GP, _P, _P, c_int64, c_int64, _P, c_int, c_int64, _P],
-    "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, c_int64, _P],
+    "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
+    "emer_hashgrid_slice_masks": [_GP, _P, _P, c_int64, _P],
+    "emer_hashgrid_sliced_supported": [_GP],
     "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],

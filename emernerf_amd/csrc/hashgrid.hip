@@ -64,6 +64,8 @@ __device__ __forceinline__ void atomic_add_feats(__half *p, const float (&v)[F])
     for (int f = 0; f < F; f += 2) unsafeAtomicAdd(reinterpret_cast<__half2 *>(p + f), __floats2half2_rn(v[f], v[f + 1]));
 }
 
+__device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 struct LevelInfo {
     float scale;
     uint32_t res, size, offset, hashed;
@@ -142,11 +144,55 @@ __device__ __forceinline__ void cell_of(const LevelInfo &li, const float (&xv)[D
     }
 }
 
+// slice plan of the owner-computes backward (described further down); the forward kernel emits the masks
+struct SlicePlan {
+    uint32_t shift[EMER_MAX_LEVELS];     // slice = idx >> shift (contiguous index ranges)
+    uint32_t n_slices[EMER_MAX_LEVELS];  // <= 64
+    uint32_t n_ranges[EMER_MAX_LEVELS];  // dense levels: the sample stream is also cut in ranges (2-D decomposition)
+    uint32_t max_local;                  // largest slice (entries)
+    uint32_t ok;                         // 0 when some level would need more than 64 slices
+};
+
+static SlicePlan make_slice_plan(const emer_grid_desc *g) {
+    SlicePlan p;
+    const uint32_t F = g->n_features;
+    const uint32_t max_entries = (128u * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
+    p.max_local = 0; p.ok = 1;
+    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) { p.shift[l] = 0; p.n_slices[l] = 0; p.n_ranges[l] = 1; }
+    for (uint32_t l = 0; l < g->n_levels; ++l) {
+        const uint32_t size = g->size[l];
+        uint32_t k = 6;
+        if (g->hashed[l]) {
+            // the hash spreads samples evenly: 64 slices, one pass over all samples each
+            while ((1ull << k) * 64ull < size) ++k;
+            p.n_ranges[l] = 1;
+        } else {
+            // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
+            // use as FEW slices as the LDS allows and cut the sample stream instead (~64 workgroups per level)
+            while ((1u << (k + 1)) <= max_entries && (1u << k) < size) ++k;
+            const uint32_t ns = (uint32_t)ceil_div(size, 1ll << k);
+            uint32_t nr = 64u / (ns ? ns : 1u);
+            p.n_ranges[l] = nr < 1u ? 1u : nr;
+        }
+        p.shift[l] = k;
+        p.n_slices[l] = (uint32_t)ceil_div(size, 1ll << k);
+        const uint32_t local = 1u << k;
+        if (local > max_entries || p.n_slices[l] > 64) p.ok = 0;
+        if (local > p.max_local) p.max_local = local;
+    }
+    return p;
+}
+
+__device__ __forceinline__ uint32_t slice_of(const SlicePlan &p, uint32_t level, uint32_t idx) {
+    return idx >> p.shift[level];
+}
+
 // ------------------------------------------------------------------------------------ forward
 template <int D, int F, typename PT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc g, const float *__restrict__ x,
                                                            const PT *__restrict__ params, float *__restrict__ out,
-                                                           int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks) {
+                                                           int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks,
+                                                           const SlicePlan plan, uint64_t *__restrict__ masks) {
     uint32_t level, chunk;
     if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
@@ -160,6 +206,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
     cell_of<D>(li, xv, gi, w);
 
     float acc[F];
+    uint64_t mask = 0;
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.0f;
 #pragma unroll
@@ -172,10 +219,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
         }
         float v[F];
-        load_feats<F, PT>(table + (size_t)grid_index<D>(li, c) * F, v);
+        const uint32_t idx = grid_index<D>(li, c);
+        load_feats<F, PT>(table + (size_t)idx * F, v);
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
+        if (masks) mask |= 1ull << slice_of(plan, level, idx);  // by-product for the owner-computes backward
     }
+    if (masks) masks[(int64_t)level * N + n] = mask;
     float *o = out + n * sn + (int64_t)level * sl;
     if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
     else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
@@ -230,77 +280,218 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // no matter the table size, dtype (f32 = pk_f16 = f64) or scope, so the tcnn-style global scatter
 // (2^D * L * F * N = 268 M requests at the metric shape) costs 13-20 ms.  LDS atomics are an order
 // of magnitude faster and need no L2 round trip, so the scatter is turned inside out:
-//   * the table of a level is cut into slices of E = 2^k entries that fit the CU's LDS
-//     (T = 2^19, F = 2, fp32: 32 slices x 128 KiB = one slice per CU of an XCD);
-//   * a workgroup OWNS one (level, slice): it streams every sample of that level (coalesced reads
-//     of x and the level-major dOut, shared by the XCD's 32 CUs through its L2), recomputes the
-//     2^D corner indices with integer VALU, and ds_add_f32's the corners that fall in its slice;
-//   * at the end it writes its slice with plain coalesced stores -- every table entry is written by
-//     exactly one workgroup, so there are no global atomics and the gradient buffer needs no memset.
+//   * LDS fp32 atomics are themselves slow on gfx950 (tools/lds_probe.hip: ds_add_f32 0.37 lane-ops/clk/CU
+//     regardless of conflicts, ds_add_f64 2.6, ds_add_u32 3.6), so slices accumulate in DOUBLE -- 7x
+//     faster and more accurate than the fp32 atomics of the upstream kernel;
+//   * the table of a level is cut into <= 64 slices that fit the CU's LDS (T = 2^19, F = 2: 64 slices
+//     x 8192 entries x 2 x 8 B = 128 KiB each).  Hashed levels are cut by the HIGH index
+//     bits (the hash already spreads samples evenly); dense levels are cut by the LOW index bits
+//     (interleaved), otherwise a slice is a z-slab and a flat driving scene lands in two or three
+//     of them;
+//   * the FORWARD kernel, which has every sample's cell in registers anyway, also emits a 64-bit
+//     slice-membership mask per (level, sample): bit s is set iff one of the 2^D corners lives in
+//     slice s.  8 B per (level, sample), level-major, coalesced;
+//   * a backward workgroup OWNS one (level, slice).  It streams the masks of its level (coalesced,
+//     shared by the XCD's 32 CUs through L2): test one bit -> wave-private compaction of the hit
+//     sample ids into LDS (ballot + popcount prefix: no atomics, no workgroup barrier).  Whenever a
+//     wave has 64 hits queued it reprocesses them on DENSE lanes: recompute cell + weights,
+//     ds_add_f32 the corners that fall in the slice;
+//   * at the end the slice is written with plain coalesced stores -- every table entry is written
+//     by exactly one workgroup: no global atomics, and the gradient buffer needs no memset.
 // Work items are dealt XCD-aware (block b -> XCD b % 8): an XCD finishes all slices of one level
 // before starting its next level, so the streamed inputs of that level stay L2-resident.
 // Placement only affects speed, never results.
-struct SlicePlan {
-    uint32_t log2_e[EMER_MAX_LEVELS];    // slice = idx >> log2_e
-    uint32_t n_slices[EMER_MAX_LEVELS];
-};
+constexpr int kSliceThreads = 1024;
+constexpr int kSliceWaves = kSliceThreads / 64;
+constexpr int kSliceUnroll = 4;                       // masks per thread per loop trip (loads issued together)
+constexpr int kWaveQueue = 64 + 64 * kSliceUnroll;    // wave-private hit queue (sample ids)
+
+// Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
+// they form RUNS that share one cell (and therefore all 2^D corner entries).  Values are reduced per run
+// with a segmented wave scan; only the last lane of each run touches the LDS (one ds_add_f64 per run and
+// corner instead of a same-address serialisation across the run).
+template <int NV>
+__device__ __forceinline__ void run_reduce(float (&v)[NV], int run_start, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const bool take = lane - off >= run_start;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float t = __shfl_up(v[i], off, kWave);
+            if (take) v[i] += t;
+        }
+    }
+}
 
 template <int D, int F>
-__global__ __launch_bounds__(1024) void hashgrid_bwd_params_sliced_kernel(const emer_grid_desc g, const SlicePlan plan,
-                                                                          const float *__restrict__ x,
-                                                                          const float *__restrict__ dout, int64_t sn, int64_t sl,
-                                                                          float *__restrict__ grad, int64_t N) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];
+__global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kernel(const emer_grid_desc g, const SlicePlan plan,
+                                                                                   const float *__restrict__ x,
+                                                                                   const float *__restrict__ dout, int64_t sn, int64_t sl,
+                                                                                   const uint64_t *__restrict__ masks,
+                                                                                   float *__restrict__ grad, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     // XCD-aware work lookup: XCD xcd walks levels xcd, xcd+8, ... ; j-th block of that XCD
     const uint32_t xcd = blockIdx.x & 7u;
     uint32_t j = blockIdx.x >> 3;
-    uint32_t level = xcd, slice = 0;
+    uint32_t level = xcd, slice = 0, range = 0;
     bool have = false;
     for (; level < g.n_levels; level += 8u) {
-        const uint32_t ns = plan.n_slices[level];
-        if (j < ns) { slice = j; have = true; break; }
-        j -= ns;
+        const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
+        if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; have = true; break; }
+        j -= nb;
     }
     if (!have) return;
     const LevelInfo li = level_info(g, level);
-    const uint32_t log2_e = plan.log2_e[level], E = 1u << log2_e;
-    const uint32_t first = slice << log2_e;
-    const uint32_t count = (li.size - first) < E ? (li.size - first) : E;  // entries this slice really has
+    const bool dense = !li.hashed;
+    const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
+    const uint32_t first = slice << shift;
+    const uint32_t n_local = ((li.size - first) < (1u << shift)) ? (li.size - first) : (1u << shift);
+    // sample range of this workgroup (whole stream for hashed levels), aligned to the trip size
+    const int64_t trip = (int64_t)kSliceThreads * kSliceUnroll;
+    const int64_t per_range = ceil_div_dev(ceil_div_dev(N, (int64_t)n_ranges), trip) * trip;
+    const int64_t n_begin = (int64_t)range * per_range;
+    const int64_t n_end = (n_begin + per_range < N) ? n_begin + per_range : N;
 
-    for (uint32_t i = threadIdx.x; i < E * F; i += 1024) acc[i] = 0.0f;
+    double *acc = smem;                                                                // [max_local * F] (ds_add_f64)
+    uint32_t *queue = reinterpret_cast<uint32_t *>(smem + (size_t)plan.max_local * F); // [waves][kWaveQueue]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *wq = queue + (size_t)wave * kWaveQueue;
+    uint32_t qn = 0;  // wave-uniform fill level of this wave's queue
+
+    for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
-    for (int64_t n = threadIdx.x; n < N; n += 1024) {
-        float xv[D], w[D], go[F];
-        uint32_t gi[D];
-        load_x<D>(x, n, xv);
-        if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; }
-        else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; go[2 < F ? 2 : 0] = t.z; go[3 < F ? 3 : 0] = t.w; }
-        else {
+    const uint64_t *__restrict__ ml = masks + (int64_t)level * N;
+    const uint64_t my_bit = 1ull << slice;
+
+    for (int64_t base = n_begin; base < n_end + trip; base += trip) {
+        if (base < n_end) {
+            uint64_t mk[kSliceUnroll];
 #pragma unroll
-            for (int f = 0; f < F; ++f) go[f] = dl[n * sn + f];
-        }
-        cell_of<D>(li, xv, gi, w);
-#pragma unroll
-        for (uint32_t m = 0; m < (1u << D); ++m) {
-            uint32_t c[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
-            const uint32_t idx = grid_index<D>(li, c);
-            if ((idx >> log2_e) == slice) {
-                float wt = 1.0f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
-                float *a = acc + (size_t)(idx - first) * F;
-#pragma unroll
-                for (int f = 0; f < F; ++f) atomicAdd(a + f, wt * go[f]);  // ds_add_f32 (no return)
+            for (int u = 0; u < kSliceUnroll; ++u) {  // all loads of the trip issued before any use
+                const int64_t n = base + u * kSliceThreads + threadIdx.x;
+                mk[u] = (n < n_end) ? ml[n] : 0ull;
             }
+#pragma unroll
+            for (int u = 0; u < kSliceUnroll; ++u) {
+                const bool hit = (mk[u] & my_bit) != 0ull;
+                const unsigned long long m = __ballot(hit);
+                if (hit) wq[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(base + u * kSliceThreads + threadIdx.x);
+                qn += (uint32_t)__popcll(m);  // wave-private push: prefix by popcount, no atomics, no barrier
+            }
+        }
+        // single drain site: 64 queued hits at a time on dense lanes (the tail after the last trip drains the rest)
+        while (qn >= 64u || (base >= n_end && qn > 0u)) {
+            const uint32_t take = qn < 64u ? qn : 64u;
+            const bool valid = (uint32_t)lane < take;
+            const uint32_t n = wq[qn - take + (valid ? (uint32_t)lane : 0u)];
+            float xs[D], w[D], go[F];
+            uint32_t gi[D];
+            load_x<D>(x, (int64_t)n, xs);
+            if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; }
+            else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; go[2 < F ? 2 : 0] = t.z; go[3 < F ? 3 : 0] = t.w; }
+            else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) go[f] = dl[(int64_t)n * sn + f];
+            }
+            cell_of<D>(li, xs, gi, w);
+            if (!valid) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) go[f] = 0.0f;
+            }
+            if (dense) {
+                // ---- run-segmented reduction: lanes with the same cell as their predecessor join its run
+                uint32_t cell = 0, mul = 1;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
+                if (!valid) cell = 0xFFFFFFFFu;
+                const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
+                const bool head = lane == 0 || cell != prev;
+                int run_start = head ? lane : 0;
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
+                    const int t = __shfl_up(run_start, off, kWave);
+                    if (lane >= off) run_start = run_start > t ? run_start : t;
+                }
+                const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
+                const bool tail = valid && (lane == 63 || next_head);
+#pragma unroll
+                for (uint32_t m = 0; m < (1u << D); ++m) {
+                    uint32_t c[D];
+                    float wt = 1.0f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        c[d] = gi[d] + ((m >> d) & 1u);
+                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                    }
+                    float v[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) v[f] = wt * go[f];
+                    run_reduce<F>(v, run_start, lane);
+                    const uint32_t idx = grid_index<D>(li, c);
+                    if (tail && (idx >> shift) == slice) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t m = 0; m < (1u << D); ++m) {
+                    uint32_t c[D];
+                    float wt = 1.0f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        c[d] = gi[d] + ((m >> d) & 1u);
+                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                    }
+                    const uint32_t idx = grid_index<D>(li, c);
+                    if (valid && (idx >> shift) == slice) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)(wt * go[f]));  // ds_add_f64
+                    }
+                }
+            }
+            qn -= take;
         }
     }
     __syncthreads();
+    // write the slice.  One range: every entry is owned by exactly this workgroup -> plain coalesced stores.
+    // Several ranges (dense levels): the host zeroed the level; merge the non-zero entries with L2 atomics.
     float *__restrict__ out = grad + ((size_t)li.offset + first) * F;
-    for (uint32_t i = threadIdx.x; i < count * F; i += 1024) out[i] = acc[i];
+    if (n_ranges == 1u) {
+        for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) out[i] = (float)acc[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) {
+            const float v = (float)acc[i];
+            if (v != 0.0f) __hip_atomic_fetch_add(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Slice-membership masks for callers that did not get them from the forward pass.
+template <int D>
+__global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_grid_desc g, const SlicePlan plan,
+                                                                   const float *__restrict__ x, uint64_t *__restrict__ masks,
+                                                                   int64_t N, uint32_t n_chunks) {
+    uint32_t level, chunk;
+    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
+    if (n >= N) return;
+    const LevelInfo li = level_info(g, level);
+    float xv[D], w[D];
+    uint32_t gi[D];
+    load_x<D>(x, n, xv);
+    cell_of<D>(li, xv, gi, w);
+    uint64_t mask = 0;
+#pragma unroll
+    for (uint32_t m = 0; m < (1u << D); ++m) {
+        uint32_t c[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
+        mask |= 1ull << slice_of(plan, level, grid_index<D>(li, c));
+    }
+    masks[(int64_t)level * N + n] = mask;
 }
 
 // ------------------------------------------------------------------------- backward (input)
@@ -384,7 +575,7 @@ static int check_desc(const emer_grid_desc *g) {
 using namespace emer;
 
 extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const void *params, int param_dtype,
-                                 float *out, int64_t sn, int64_t sl, int64_t n, void *stream) {
+                                 float *out, int64_t sn, int64_t sl, uint64_t *slice_masks, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
     EMER_REQUIRE(n >= 0, "hashgrid_fwd: negative n");
     if (n == 0) return EMER_OK;
@@ -392,14 +583,16 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     EMER_REQUIRE(param_dtype == EMER_F32 || param_dtype == EMER_F16, "hashgrid_fwd: bad param_dtype %d", param_dtype);
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
     const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    const SlicePlan plan = make_slice_plan(g);
+    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice masks requested but a level needs more than 64 LDS slices");
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
         if (param_dtype == EMER_F32)
             hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const float *)params, out, sn, sl, n, n_chunks);
+                               (const float *)params, out, sn, sl, n, n_chunks, plan, slice_masks);
         else
             hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const __half *)params, out, sn, sl, n, n_chunks);
+                               (const __half *)params, out, sn, sl, n, n_chunks, plan, slice_masks);
         return check_launch("hashgrid_fwd");
     });
 }
@@ -429,31 +622,51 @@ extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x,
 }
 
 
-// Owner-computes variant: OVERWRITES grad (f32) -- every entry of every level is written exactly
-// once, so the caller does not zero the buffer.  max_lds_bytes bounds the slice size.
-extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
-                                               int64_t sl, float *grad, int64_t n, void *stream) {
+// 1 if the owner-computes backward supports this grid (every level fits <= 32 LDS slices), else 0.
+extern "C" int emer_hashgrid_sliced_supported(const emer_grid_desc *g) {
+    if (check_desc(g)) return 0;
+    return make_slice_plan(g).ok ? 1 : 0;
+}
+
+// Slice-membership masks [L][N] (u32) for emer_hashgrid_bwd_params_sliced when the forward did not emit them.
+extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x, uint64_t *slice_masks, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
-    EMER_REQUIRE(n >= 0, "hashgrid_bwd_params_sliced: negative n");
-    EMER_REQUIRE(x && dout && grad, "hashgrid_bwd_params_sliced: null pointer");
+    EMER_REQUIRE(n >= 0, "hashgrid_slice_masks: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && slice_masks, "hashgrid_slice_masks: null pointer");
+    const SlicePlan plan = make_slice_plan(g);
+    EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 64 LDS slices");
+    const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
+    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto) {
+        constexpr int D = decltype(d)::value;
+        hipLaunchKernelGGL((hashgrid_slice_masks_kernel<D>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, plan, x, slice_masks, n,
+                           n_chunks);
+        return check_launch("hashgrid_slice_masks");
+    });
+}
+
+// Owner-computes variant: OVERWRITES grad (f32) -- every entry of every level is written exactly
+// once, so the caller does not zero the buffer.  slice_masks [L][N] come from emer_hashgrid_fwd (or
+// emer_hashgrid_slice_masks) for the SAME x.
+extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
+                                               int64_t sl, const uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0 && n < (1ll << 31), "hashgrid_bwd_params_sliced: n out of range (sample ids are queued as 32-bit)");
+    EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
-    const uint32_t max_entries = (128u * 1024u) / (F * 4u);  // 128 KiB of the CU's 160 KiB LDS
-    SlicePlan plan;
-    uint32_t max_e = 0, per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const SlicePlan plan = make_slice_plan(g);
+    EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 LDS slices; use emer_hashgrid_bwd_params");
+    uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, max_blocks = 0;
     for (uint32_t l = 0; l < g->n_levels; ++l) {
-        // aim for 32 slices per level (one per CU of an XCD), capped by the LDS budget
-        uint32_t k = 0;
-        while ((1ull << k) * 32ull < g->size[l]) ++k;
-        while ((1u << k) > max_entries) --k;
-        if (k < 6) k = 6;
-        plan.log2_e[l] = k;
-        plan.n_slices[l] = (uint32_t)ceil_div(g->size[l], 1ll << k);
-        if ((1u << k) > max_e) max_e = 1u << k;
-        per_xcd[l & 7u] += plan.n_slices[l];
+        per_xcd[l & 7u] += plan.n_slices[l] * plan.n_ranges[l];
+        if (plan.n_ranges[l] > 1u) {  // levels merged with atomics start from zero (async memset node on the same stream)
+            hipError_t e = hipMemsetAsync(grad + (size_t)g->offset[l] * F, 0, (size_t)g->size[l] * F * sizeof(float), as_stream(stream));
+            if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
+        }
     }
-    uint32_t max_blocks = 0;
     for (int i = 0; i < 8; ++i) max_blocks = per_xcd[i] > max_blocks ? per_xcd[i] : max_blocks;
-    const size_t lds = (size_t)max_e * F * sizeof(float);
+    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kWaveQueue * sizeof(uint32_t);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
@@ -461,7 +674,8 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
         }
-        hipLaunchKernelGGL(kern, dim3(max_blocks * 8u), dim3(1024), lds, as_stream(stream), *g, plan, x, dout, sn, sl, grad, n);
+        hipLaunchKernelGGL(kern, dim3(max_blocks * 8u), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
+                           slice_masks, grad, n);
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }

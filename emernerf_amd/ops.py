@@ -43,8 +43,13 @@ def _dtype_tag(t: Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------ hash grid
-def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True) -> Tensor:
-    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32."""
+def sliced_supported(desc: GridDesc) -> bool:
+    """True when the owner-computes LDS backward handles this grid (every level <= 64 LDS slices)."""
+    return bool(_lib.load().emer_hashgrid_sliced_supported(ctypes.byref(desc)))
+
+
+def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True, want_masks: bool = False):
+    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32 (and the [L, N] int64 slice masks if asked)."""
     _check_cuda(x, params)
     N, L, F = x.shape[0], desc.n_levels, desc.n_features
     assert x.shape[1] == desc.n_dims and params.numel() == desc.n_entries * F
@@ -55,9 +60,18 @@ def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: boo
         else:
             out = torch.empty((N, L * F), device=x.device, dtype=torch.float32)
             sn, sl = L * F, F
-        _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl, N,
-                  _stream(x))
-    return out
+        masks = torch.empty((L, N), device=x.device, dtype=torch.int64) if want_masks else None
+        _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl,
+                  _ptr(masks), N, _stream(x))
+    return (out, masks) if want_masks else out
+
+
+def slice_masks(desc: GridDesc, x: Tensor) -> Tensor:
+    _check_cuda(x)
+    with torch.cuda.device(x.device):
+        masks = torch.empty((desc.n_levels, x.shape[0]), device=x.device, dtype=torch.int64)
+        _lib.call("emer_hashgrid_slice_masks", ctypes.byref(desc), _ptr(x), _ptr(masks), x.shape[0], _stream(x))
+    return masks
 
 
 def layout_transpose(src: Tensor, L: int, N: int, F: int, to_row_major: bool) -> Tensor:
@@ -79,15 +93,21 @@ class _HashGridFn(torch.autograd.Function):
     def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype):
         xc, pc = _f32c(x), params.detach().contiguous()
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
-        lm = hashgrid_fwd_raw(desc, xc, pc, level_major=True)
+        gdt = grad_dtype or torch.float32
+        # the forward emits the slice masks of the owner-computes backward when it will be used
+        ctx.sliced = bool(params.requires_grad and gdt == torch.float32 and torch.is_grad_enabled() and sliced_supported(desc))
+        if ctx.sliced:
+            lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=True)
+        else:
+            lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
         out = layout_transpose(lm, L, N, F, to_row_major=True)
         ctx.desc, ctx.grad_dtype = desc, grad_dtype
-        ctx.save_for_backward(xc, pc)
+        ctx.save_for_backward(xc, pc, masks)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
-        xc, pc = ctx.saved_tensors
+        xc, pc, masks = ctx.saved_tensors
         desc = ctx.desc
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         dx = dp = None
@@ -96,12 +116,12 @@ class _HashGridFn(torch.autograd.Function):
             st = _stream(xc)
             if ctx.needs_input_grad[1]:
                 gdt = ctx.grad_dtype or torch.float32
-                if gdt == torch.float32:
+                if gdt == torch.float32 and masks is not None:
                     # owner-computes LDS scatter: writes every entry once (no memset, no global atomics)
                     grad = torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
-                    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
-                              N, st)
-                else:  # tcnn-style packed-half atomics (kept for the fp16-gradient mode)
+                    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
+                              _ptr(grad), N, st)
+                else:  # tcnn-style global atomics: fp16-gradient mode, or tables too large for 32 LDS slices
                     grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)

@@ -74,10 +74,12 @@ int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_l
  * out element (n, l, f) is written at out[n*out_stride_n + l*out_stride_l + f] (f32):
  *   row-major [N, L*F] (the reference's layout): stride_n = L*F, stride_l = F;
  *   level-major [L][N][F] (coalesced, what the fused heads read): stride_n = F, stride_l = N*F.
+ * slice_masks (may be NULL): [L][N] u64 by-product consumed by emer_hashgrid_bwd_params_sliced
+ *   (bit s of (l, n) set iff a corner of sample n lives in LDS slice s of level l).
  * Replaces native.fwd (tcnn_modules.py:122). */
 int emer_hashgrid_fwd(const emer_grid_desc *host_desc, const float *x, const void *params,
                       int param_dtype, float *out, int64_t out_stride_n, int64_t out_stride_l,
-                      int64_t n, void *stream);
+                      uint64_t *slice_masks, int64_t n, void *stream);
 
 /* dParams[l, idx, f] += w_corner * dOut[n, l, f]  (atomic scatter; grad is NOT zeroed here).
  * grad dtype: EMER_F32 (f32 atomics) or EMER_F16 (packed half2 atomics, F even).
@@ -87,11 +89,17 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
                              int grad_dtype, int64_t n, void *stream);
 
 /* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
- * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice and
- * streams the samples ("owner computes"; see csrc/hashgrid.hip).  This is the training path. */
+ * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice (accumulated in double) and
+ * streams the per-sample slice masks ("owner computes"; see csrc/hashgrid.hip).  The training path.
+ * slice_masks [L][N]: from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
 int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
                                     const float *dout, int64_t dout_stride_n,
-                                    int64_t dout_stride_l, float *grad, int64_t n, void *stream);
+                                    int64_t dout_stride_l, const uint64_t *slice_masks,
+                                    float *grad, int64_t n, void *stream);
+int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
+                              uint64_t *slice_masks, int64_t n, void *stream);
+/* 1 when every level of the grid fits <= 64 LDS slices (128 KiB of double accumulators each) (else use emer_hashgrid_bwd_params). */
+int emer_hashgrid_sliced_supported(const emer_grid_desc *host_desc);
 
 /* dX[n, d] = sum_l scale_l sum_f dOut * d(interp)/dx.  Replaces the input path of native.bwd
  * (needed by the flow configs, radiance_fields/radiance_field.py:572-608). */

@@ -81,8 +81,9 @@ def main():
             f_us, _ = timeit(lambda: ops.hashgrid_fwd_raw(d1, x, p, level_major=True), iters=10)
             a_us, _ = timeit(lambda: _lib.call("emer_hashgrid_bwd_params", ctypes.byref(d1), ops._ptr(x), ops._ptr(dlm), F, N * F,
                                                ops._ptr(g1), 0, N, ops._stream(x)), iters=5)
+            mk = ops.slice_masks(d1, x)
             s_us, _ = timeit(lambda: _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(d1), ops._ptr(x), ops._ptr(dlm), F,
-                                               N * F, ops._ptr(g1), N, ops._stream(x)), iters=5)
+                                               N * F, ops._ptr(mk), ops._ptr(g1), N, ops._stream(x)), iters=5)
             rows.append({"level": l, "res": r, "entries": int(d1.n_entries), "hashed": int(d1.hashed[0]), "fwd_us": round(f_us, 1),
                          "bwd_atomic_us": round(a_us, 1), "bwd_sliced_us": round(s_us, 1)})
             print(rows[-1], flush=True)
@@ -113,10 +114,13 @@ def main():
             res[f"bwd_params_{dt_name}_algGBps"] = b_bwd * N / med / 1e3
         if dt == torch.float32:
             g2 = torch.empty(desc.n_entries * F, device=dev)
+            _, mk = ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=True)
+            med_m, _ = timeit(lambda: ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=True))
+            res["fwd_with_masks_f32_us"] = med_m
 
             def bwd_sl():
                 _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F,
-                          ops._ptr(g2), N, ops._stream(x))
+                          ops._ptr(mk), ops._ptr(g2), N, ops._stream(x))
             med, best = timeit(bwd_sl)
             res["bwd_params_sliced_f32_us"] = med
             res["bwd_params_sliced_f32_algGBps"] = (4 * D + L * F * 4 + 2 * (2 ** D) * L * F * 4) * N / med / 1e3
