@@ -95,7 +95,7 @@ class _HashGridFn(torch.autograd.Function):
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         gdt = grad_dtype or torch.float32
         # the forward emits the slice masks of the owner-computes backward when it will be used
-        ctx.sliced = bool(params.requires_grad and gdt == torch.float32 and torch.is_grad_enabled() and sliced_supported(desc))
+        ctx.sliced = bool(ctx.needs_input_grad[1] and gdt == torch.float32 and sliced_supported(desc))
         if ctx.sliced:
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=True)
         else:
