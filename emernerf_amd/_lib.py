@@ -81,6 +81,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.emer_linear_bwd_workspace.argtypes = [c_int64, c_int32, c_int32]
+    lib.emer_linear_bwd_workspace.restype = c_int64
     lib.emer_last_error.restype = ctypes.c_char_p
     lib.emer_version.restype = c_int
     _lib = lib

@@ -329,7 +329,9 @@ class _LinearFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         with torch.cuda.device(x2.device):
-            ws = torch.empty((M, N), device=x2.device, dtype=torch.float32)
+            want_w = need_w or need_b
+            n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, K)) if want_w else 0
+            ws = torch.empty((n_ws,), device=x2.device, dtype=torch.float32) if want_w else None
             dx = torch.empty((M, K), device=x2.device, dtype=torch.float32) if need_x else None
             dw = torch.zeros((N, K), device=x2.device, dtype=torch.float32) if (need_w or need_b) else None
             db = torch.zeros((N,), device=x2.device, dtype=torch.float32) if need_b else None

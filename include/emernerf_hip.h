@@ -180,13 +180,16 @@ int emer_accumulate_bwd(const float *weights, const float *values, const float *
 int emer_linear_fwd(const float *x, int64_t ldx, const float *w, const float *bias, float *y,
                     int64_t ldy, int64_t m, int32_t n, int32_t k, int act, float *aux_density,
                     void *stream);
-/* Backward of the above.  dy [M,N] (ld ldy), y [M,N] = saved forward output (for act').
- *   dpre = dy * act'(y)                     (written to dpre_ws [M,N], contiguous workspace)
- *   dpre[:,0] += d_aux_density * min(aux_density, e^15)   (when d_aux_density != NULL; dy may then be NULL)
- *   dx [M,K] = dpre @ W                     (skipped when dx == NULL)
- *   dw [N,K] += dpre^T @ X ; dbias [N] += column sums of dpre   (skipped when dw == NULL) */
+/* Backward of the above.  dy [M,N] (ld lddy), y [M,N] = saved forward output (for act').
+ *   dpre = dy * act'(y)  [+ on column 0: d_aux_density * min(aux_density, e^15)]  is formed on the fly while
+ *          operand tiles are staged -- it is never written to HBM (dy may be NULL when only d_aux_density flows);
+ *   dx [M,K] = dpre @ W                                       (skipped when dx == NULL)
+ *   dw [N,K] += dpre^T @ X ; dbias [N] += column sums of dpre (skipped when dw == NULL)
+ * workspace: emer_linear_bwd_workspace(m, n, k) floats (per-row-block partial sums of dw/dbias; a second
+ * kernel reduces them -- no global atomics). */
+int64_t emer_linear_bwd_workspace(int64_t m, int32_t n, int32_t k);
 int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x,
-                    int64_t ldx, const float *w, float *dpre_ws, float *dx, int64_t lddx,
+                    int64_t ldx, const float *w, float *workspace, float *dx, int64_t lddx,
                     float *dw, float *dbias, int64_t m, int32_t n, int32_t k, int act,
                     const float *d_aux_density, const float *aux_density, void *stream);
 
