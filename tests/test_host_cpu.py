@@ -1,0 +1,188 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports exactly what include/emernerf_hip.h declares,
+host-side logic (level tables, schedules, flat buffers, proposal-loss restatement) and the N>1 data-parallel
+plumbing over gloo (world_size 2).  No kernel is launched here."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------- C ABI
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "emernerf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(emer_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from emernerf_amd import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(hip_lib, name), f"{name} declared in include/emernerf_hip.h but not exported"
+    bound = set(_lib.SIGNATURES) | {"emer_last_error", "emer_version", "emer_linear_bwd_workspace"}
+    assert bound <= declared, f"bound but undeclared: {bound - declared}"
+    assert declared <= bound, f"declared but not bound by the host layer: {declared - bound}"
+
+
+def test_error_reporting_without_gpu(hip_lib):
+    from emernerf_amd import _lib
+    with pytest.raises(_lib.EmerError, match="n_dims"):
+        _lib.make_grid_desc(7, 4, 2, 19, 16, 1.5)
+    with pytest.raises(_lib.EmerError, match="n_features"):
+        _lib.make_grid_desc(3, 4, 3, 19, 16, 1.5)
+    assert hip_lib.emer_version() >= 1
+
+
+def test_product_rejects_cpu_tensors(hip_lib):
+    """No CPU fallback anywhere on the product path."""
+    from emernerf_amd import _lib, ops
+    from emernerf_amd.encodings import HashEncoder
+    enc = HashEncoder(3, 4, 16, 64, 12, 2, verbose=False)
+    with pytest.raises(_lib.EmerError):
+        enc(torch.rand(8, 3))
+    with pytest.raises(_lib.EmerError):
+        ops.render_weights(torch.rand(2, 4), torch.rand(2, 4), torch.rand(2, 4))
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from emernerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EmerError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+@pytest.mark.parametrize("args", [(3, 16, 16, 2048, 19, 2), (3, 10, 16, 8192, 20, 4), (4, 10, 32, 8192, 18, 4),
+                                  (4, 10, 16, 4096, 18, 4), (3, 8, 16, 512, 20, 1), (3, 8, 16, 2048, 20, 1), (2, 5, 8, 256, 12, 2)])
+def test_level_table_host_equals_oracle(hip_lib, oracle, args):
+    """emer_grid_desc_init (product, host C++) and orc_grid_init (oracle, C) agree bit for bit."""
+    from emernerf_amd import _lib
+    D, L, base, mx, T, F = args
+    meta = oracle.grid_meta_from_encoder_args(*args)
+    desc = _lib.make_grid_desc(D, L, F, T, base, meta.per_level_scale)
+    assert desc.n_entries == meta.n_entries
+    assert np.array_equal(np.array(desc.scale[:L], np.float32).view(np.uint32), meta.scale.view(np.uint32))
+    for fld in ("res", "size", "offset", "hashed"):
+        assert np.array_equal(np.array(getattr(desc, fld)[:L], np.uint32), getattr(meta, fld))
+
+
+def test_encoder_state_dict_layout(hip_lib):
+    from emernerf_amd.encodings import HashEncoder
+    enc = HashEncoder(verbose=False)  # defaults = BASELINE configs[1] grid (encodings.py:110-118)
+    assert list(enc.state_dict()) == ["tcnn_encoding.params"]
+    assert enc.tcnn_encoding.params.shape == (12196240,) and enc.n_output_dims == 32
+    assert float(enc.tcnn_encoding.params.abs().max()) <= 1e-4  # tcnn init range
+
+
+# ------------------------------------------------------------------------------- host logic
+def test_proposal_requires_grad_schedule():
+    from emernerf_amd.prop_net import get_proposal_requires_grad_fn
+    fn = get_proposal_requires_grad_fn()
+    seq = [fn(s) for s in range(3000)]
+    assert seq[0] is False and seq[1] is True
+    tail = seq[2000:]
+    assert abs(sum(tail) / len(tail) - 1 / 6) < 0.01  # steady state: every 6th call (target 5 steps between updates)
+
+
+def test_lr_factor_matches_torch_schedulers():
+    from emernerf_amd.trainer import lr_factor
+    for num_iters in (25000, 2000):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1.0)
+        ms = [num_iters // 2, num_iters * 3 // 4, num_iters * 9 // 10]
+        if num_iters >= 10000:
+            ms.insert(0, num_iters // 4)
+        sched = torch.optim.lr_scheduler.ChainedScheduler([  # builders.py:75-88
+            torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, total_iters=num_iters // 10),
+            torch.optim.lr_scheduler.MultiStepLR(opt, milestones=ms, gamma=0.33)])
+        for step in range(num_iters):
+            if step % 997 == 0 or step in ms or step == num_iters // 10:
+                assert abs(opt.param_groups[0]["lr"] - lr_factor(step, num_iters)) < 1e-9, step
+            opt.step(); sched.step()
+
+
+def test_sorted_interp_quad_restatement_equals_reference_form():
+    """prop_net.sorted_interp_quad (searchsorted) == the reference's masked max/min form (oracle.ref_path)."""
+    from emernerf_amd.prop_net import blur_stepfun, sorted_interp_quad
+    from oracle.ref_path import blur_stepfun as ref_blur, sorted_interp_quad as ref_interp
+    g = torch.Generator().manual_seed(0)
+    R, S, m = 64, 24, 33
+    s = torch.sort(torch.rand(R, S + 1, generator=g), -1).values
+    w = torch.rand(R, S, generator=g)
+    c, wb = blur_stepfun(s, w, 0.03)
+    c2, wb2 = ref_blur(s, w, 0.03)
+    assert torch.equal(c, c2) and torch.equal(wb, wb2)
+    area = 0.5 * (wb[..., 1:] + wb[..., :-1]) * (c[..., 1:] - c[..., :-1])
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(area, -1)], -1)
+    xq = torch.sort(torch.rand(R, m, generator=g) * 1.2 - 0.1, -1).values  # includes queries outside the knots
+    a, b = sorted_interp_quad(xq, c, wb, cdf), ref_interp(xq, c, wb, cdf)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_flat_params_views_and_grad_accumulation():
+    from emernerf_amd.trainer import FlatParams
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)
+    ref = [p.detach().clone() for p in list(a.parameters()) + list(b.parameters())]
+    flat = FlatParams({"main": [a], "prop": [b]}, "cpu")
+    assert flat.numel == sum(p.numel() for p in ref) and flat.ranges == {"main": (0, 18), "prop": (18, 26)}
+    for p, r in zip(list(a.parameters()) + list(b.parameters()), ref):
+        assert torch.equal(p.detach(), r)
+    y = b(a(torch.ones(4, 5))).sum()
+    y.backward()
+    assert flat.grads.abs().sum() > 0 and a.weight.grad.data_ptr() == flat.grads.data_ptr()  # grads land in the flat buffer
+    flat.params.mul_(2.0)
+    assert torch.allclose(a.weight.detach(), ref[0] * 2)  # parameters are views of the flat buffer
+    flat.zero_grad()
+    assert float(flat.grads.abs().sum()) == 0.0 and float(a.weight.grad.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------- data parallel (gloo, world 2)
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from emernerf_amd.trainer import FlatParams
+    torch.manual_seed(0)  # identical parameters on every rank, as Trainer does
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    prop = torch.nn.Linear(6, 1)
+    flat = FlatParams({"main": [net], "prop": [prop]}, "cpu")
+    g = torch.Generator().manual_seed(100)
+    xs, ys = torch.randn(world * 16, 6, generator=g), torch.randn(world * 16, 3, generator=g)
+    x, y = xs[rank * 16:(rank + 1) * 16], ys[rank * 16:(rank + 1) * 16]  # each rank its own rays
+    flat.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    (prop(x) ** 2).mean().backward()
+    dist.all_reduce(flat.grads)  # THE one collective of a step: sum of the flat gradient buffer
+    flat.grads.div_(world)       # (folded into the fused Adam's grad_scale on the GPU path)
+    # single-process reference on the concatenated batch
+    torch.manual_seed(0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    prop2 = torch.nn.Linear(6, 1)
+    ((net2(xs) - ys) ** 2).mean().backward()
+    (prop2(xs) ** 2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in list(net2.parameters()) + list(prop2.parameters())])
+    ret[rank] = float((flat.grads - want).abs().max())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_flat_allreduce_gloo():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert len(ret) == world and all(v < 1e-6 for v in ret.values()), dict(ret)
