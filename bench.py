@@ -124,7 +124,7 @@ def main():
     timed = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params", "emer_hashgrid_bwd_input",
              "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose", "emer_render_weights_fwd", "emer_render_weights_bwd",
              "emer_accumulate_fwd", "emer_accumulate_bwd", "emer_importance_sample", "emer_ray_points", "emer_adam_step",
-             "emer_dir_encode", "emer_contract_fwd"]
+             "emer_dir_encode", "emer_contract_fwd", "emer_mlp_chain", "emer_wgrad_segmented"]
     timer = _lib.KernelTimer(timed) if rank == 0 else None
     _lib.TIMER = timer
 

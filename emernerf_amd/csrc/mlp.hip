@@ -325,3 +325,368 @@ extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, in
     }
     return EMER_OK;
 }
+
+// ================================================================================ fused MLP chains
+// Row-split design for gfx950: a wave owns 16-row tiles end to end, so there is NO workgroup barrier inside
+// the tile loop; all layer weights of the chain sit in LDS (loaded once per persistent workgroup, zero-padded
+// to K%4 == 0 / N%16 == 0); activations live in a wave-private LDS row buffer whose pitch P satisfies
+// (P/2) odd, which makes the mfma_16x16x4 A-fragment read (lanes 0-15: 16 rows of one k, lanes 16-31: k+1)
+// hit 32 distinct banks.  Column groups of 64 outputs give 4 independent accumulators per k-step, enough to
+// keep the 32-cycle fp32 MFMA pipe issuing back to back (dependent latency 40 cycles).
+namespace emer {
+
+struct ChainLds {
+    int32_t w_off[EMER_CHAIN_MAX_LAYERS], b_off[EMER_CHAIN_MAX_LAYERS], w_pitch[EMER_CHAIN_MAX_LAYERS];
+    int32_t kpad[EMER_CHAIN_MAX_LAYERS], npad[EMER_CHAIN_MAX_LAYERS];
+    int32_t w_total, P;
+};
+
+static inline int32_t round_up_i(int32_t a, int32_t b) { return (a + b - 1) / b * b; }
+
+static ChainLds chain_lds_plan(const emer_chain_desc *d) {
+    ChainLds p;
+    int32_t off = 0;
+    for (int l = 0; l < EMER_CHAIN_MAX_LAYERS; ++l) { p.w_off[l] = p.b_off[l] = p.w_pitch[l] = p.kpad[l] = p.npad[l] = 0; }
+    for (int l = 0; l < d->n_layers; ++l) {
+        p.kpad[l] = round_up_i(d->layers[l].K, 8);   // 4 lane groups x an even number of k each (ds_read_b64 pairs)
+        p.npad[l] = round_up_i(d->layers[l].N, 16);
+        p.w_pitch[l] = p.kpad[l] + 2;  // kpad % 4 == 0  ->  (pitch / 2) odd
+        p.w_off[l] = off; off += p.npad[l] * p.w_pitch[l];
+        p.b_off[l] = off; off += p.npad[l];
+    }
+    p.w_total = round_up_i(off, 4);
+    p.P = round_up_i(d->buf_cols + 8, 4) + 2;
+    return p;
+}
+
+constexpr int kChainWaves = 4;
+
+// One column group (NT tiles of 16 outputs) of one layer for a 16-row tile.
+// The reduction index is PERMUTED: lane group g = lane >> 4 owns the contiguous range k in [g*kq, (g+1)*kq),
+// kq = kpad / 4, and MFMA step s uses k = g*kq + s for both operands (any bijection of k is a valid GEMM).
+// Each lane therefore reads CONSECUTIVE floats of its activation row / weight row: one ds_read_b64 feeds
+// two MFMA steps, and with the 4-step unroll ten 8-byte reads are in flight behind sixteen MFMAs.
+template <int NT>
+__device__ __forceinline__ void chain_gemm(const float *__restrict__ ap, const float *__restrict__ bp, int wp, int kq,
+                                           f32x4 (&acc)[4]) {
+    const float2 *a2 = reinterpret_cast<const float2 *>(ap);
+    const float2 *b2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b2[t] = reinterpret_cast<const float2 *>(bp + t * 16 * wp);
+    const int n2 = kq >> 1;
+    float2 a = a2[0], b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = b2[t][0];
+    for (int s2 = 0; s2 < n2; ++s2) {  // software pipelined: the next pair's LDS reads are issued before this pair's MFMAs
+        const int nx = (s2 + 1 < n2) ? s2 + 1 : s2;
+        const float2 an = a2[nx];
+        float2 bn[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn[t] = b2[t][nx];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+        a = an;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = bn[t];
+    }
+}
+
+__global__ __launch_bounds__(1024) void mlp_chain_kernel(const emer_chain_desc d, const ChainLds lp, int64_t n_rows, int64_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // ---- stage every layer's weights (zero padded) and bias once per workgroup
+    for (int l = 0; l < d.n_layers; ++l) {
+        const emer_chain_layer &L = d.layers[l];
+        const int32_t kp = lp.kpad[l], np = lp.npad[l];
+        for (int idx = tid; idx < np * kp; idx += (int)blockDim.x) {
+            const int n = idx / kp, k = idx - n * kp;
+            smem[lp.w_off[l] + n * lp.w_pitch[l] + k] = (n < L.N && k < L.K) ? L.w[n * L.w_sn + k * L.w_sk] : 0.0f;
+        }
+        for (int n = tid; n < np; n += (int)blockDim.x) smem[lp.b_off[l] + n] = (L.bias && n < L.N) ? L.bias[n] : 0.0f;
+    }
+    const int32_t P = lp.P;
+    float *buf = smem + lp.w_total + wave * 16 * P;
+    for (int i = lane; i < 16 * P; i += 64) buf[i] = 0.0f;  // padding columns must stay finite (they meet zero weights)
+    __syncthreads();
+
+    const int n_waves = (int)blockDim.x >> 6;
+    for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * n_waves) {
+        const int64_t row0 = tile * 16;
+        // ---- fill the input segments: rows outer, lanes walk columns (coalesced rows, no integer divisions)
+        for (int s = 0; s < d.n_segs; ++s) {
+            const emer_chain_seg S = d.segs[s];
+            if (S.mode == 1) {
+                // level-major [L][N][f]: lane = (row, level group) so 16 lanes read 16 consecutive rows of ONE level
+                // (16*f*4 contiguous bytes); four levels per load instruction
+                const int r = lane & 15, nl = S.width / S.f;
+                const bool ok = row0 + r < n_rows;
+                for (int lv = lane >> 4; lv < nl; lv += 4) {
+                    const float *src = S.ptr + ((int64_t)lv * S.n_total + row0 + r) * S.f;
+                    float *dst = buf + r * P + S.col + lv * S.f;
+                    if (S.f == 2) { const float2 v = ok ? *reinterpret_cast<const float2 *>(src) : make_float2(0.f, 0.f); dst[0] = v.x; dst[1] = v.y; }
+                    else if (S.f == 4) { const float4 v = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+                    else { for (int f = 0; f < S.f; ++f) dst[f] = ok ? src[f] : 0.0f; }
+                }
+            } else if (S.row_div == 1) {
+                for (int c = lane; c < S.width; c += 64) {
+                    const float *src = S.ptr + row0 * S.ld + c;
+#pragma unroll 4
+                    for (int r = 0; r < 16; ++r) buf[r * P + S.col + c] = (row0 + r < n_rows) ? src[(int64_t)r * S.ld] : 0.0f;
+                }
+            } else {  // per-ray data: one division per tile; the 16 rows usually share one source row
+                const int64_t ray0 = row0 / S.row_div;
+                const int32_t rem0 = (int32_t)(row0 - ray0 * S.row_div);
+                for (int c = lane; c < S.width; c += 64) {
+                    if (rem0 + 15 < S.row_div) {
+                        const float v = S.ptr[ray0 * S.ld + c];
+#pragma unroll 4
+                        for (int r = 0; r < 16; ++r) buf[r * P + S.col + c] = (row0 + r < n_rows) ? v : 0.0f;
+                    } else {
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t ray = ray0 + (rem0 + r) / S.row_div;
+                            buf[r * P + S.col + c] = (row0 + r < n_rows) ? S.ptr[ray * S.ld + c] : 0.0f;
+                        }
+                    }
+                }
+            }
+            if (S.fix_a && lane < 16 && row0 + lane < n_rows)
+                buf[lane * P + S.col] += S.fix_a[row0 + lane] * fminf(S.fix_b[row0 + lane], 3269017.3724721107f);
+        }
+        // ---- layers
+        for (int l = 0; l < d.n_layers; ++l) {
+            const emer_chain_layer L = d.layers[l];
+            const float *wl = smem + lp.w_off[l];
+            const float *bl = smem + lp.b_off[l];
+            const int32_t wp = lp.w_pitch[l], kq = lp.kpad[l] >> 2, ntiles = lp.npad[l] >> 4;
+            const float *ap = buf + (lane & 15) * P + L.in_col + (lane >> 4) * kq;
+            for (int cg = 0; cg * 4 < ntiles; ++cg) {
+                const int nt = (ntiles - cg * 4) < 4 ? (ntiles - cg * 4) : 4;  // wave-uniform
+                const float *bp = wl + (cg * 64 + (lane & 15)) * wp + (lane >> 4) * kq;
+                // relu' masks of this column group are fetched ahead of the MFMA loop
+                float mk[4][4];
+                if (L.mask) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int col = cg * 64 + t * 16 + (lane & 15);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int64_t row = row0 + (lane >> 4) * 4 + i;
+                            mk[t][i] = (t < nt && col < L.N && row < n_rows) ? L.mask[row * L.mask_ld + col] : 0.0f;
+                        }
+                    }
+                }
+                f32x4 acc[4] = {f32x4{0}, f32x4{0}, f32x4{0}, f32x4{0}};
+                if (nt == 4) chain_gemm<4>(ap, bp, wp, kq, acc);
+                else if (nt == 3) chain_gemm<3>(ap, bp, wp, kq, acc);
+                else if (nt == 2) chain_gemm<2>(ap, bp, wp, kq, acc);
+                else chain_gemm<1>(ap, bp, wp, kq, acc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int col = cg * 64 + t * 16 + (lane & 15);
+                    if (t < nt && col < L.N) {
+                        const float bv = bl[col];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int r = (lane >> 4) * 4 + i;
+                            float v = apply_act(L.act, acc[t][i] + bv);
+                            float *o = buf + r * P + L.out_col + col;
+                            if (L.accumulate) v += *o;
+                            if (L.mask) v = mk[t][i] > 0.0f ? v : 0.0f;
+                            *o = v;
+                        }
+                    }
+                }
+            }
+            // ---- coalesced copy-out of (part of) the layer output
+            if (L.store) {
+                const float *ob = buf + L.out_col + L.store_col;
+                if (L.store_mode == 1) {  // level-major: 16 lanes write 16 consecutive rows of one level
+                    const int r = lane & 15, nl = L.store_n / L.store_f;
+                    if (row0 + r < n_rows) {
+                        for (int lv = lane >> 4; lv < nl; lv += 4) {
+                            float *dst = L.store + ((int64_t)lv * L.store_ntotal + row0 + r) * L.store_f;
+                            const float *src = ob + r * P + lv * L.store_f;
+                            if (L.store_f == 2) *reinterpret_cast<float2 *>(dst) = make_float2(src[0], src[1]);
+                            else if (L.store_f == 4) *reinterpret_cast<float4 *>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+                            else { for (int f = 0; f < L.store_f; ++f) dst[f] = src[f]; }
+                        }
+                    }
+                } else {
+                    for (int c = lane; c < L.store_n; c += 64) {
+                        float *dst = L.store + row0 * L.store_ld + c;
+#pragma unroll 4
+                        for (int r = 0; r < 16; ++r) if (row0 + r < n_rows) dst[(int64_t)r * L.store_ld] = ob[r * P + c];
+                    }
+                }
+            }
+            if (L.store_exp0 && lane < 16 && row0 + lane < n_rows) L.store_exp0[row0 + lane] = expf(buf[lane * P + L.out_col] - 1.0f);
+        }
+    }
+}
+
+// dW kernel with a segmented (virtual concat) X operand; dPre is given materialised.
+struct SegX { emer_chain_seg s[EMER_CHAIN_MAX_SEGS]; int32_t n; };
+
+template <int NGT, int KGT>
+__global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
+                                                        float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
+                                                        int32_t rows_per_block, int want_bias) {
+    constexpr int NG = 32 * NGT, KG = 32 * KGT, TILES = NGT * KGT, TPW = (TILES + 3) / 4;
+    constexpr int ND = (32 * NG) / 256, NX = (32 * KG) / 256;
+    __shared__ float ds[32 * NG];
+    __shared__ float xs[32 * KG];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int32_t n_base = blockIdx.z * NG, k_base = blockIdx.y * KG;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < M) ? r_begin + rows_per_block : M;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = f32x16{0};
+    float bsum = 0.0f;
+    float dreg[ND], xreg[NX];
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx / NG, c = idx % NG;
+            const int64_t gr = r0 + r;
+            const int32_t gn = n_base + c;
+            dreg[i] = (gr < r_end && gn < N) ? dpre[gr * ldd + gn] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx / KG, c = idx % KG;
+            const int64_t gr = r0 + r;
+            const int32_t gk = k_base + c;
+            float v = 0.0f;
+            if (gr < r_end && gk < K) {
+#pragma unroll
+                for (int s = 0; s < EMER_CHAIN_MAX_SEGS; ++s) {
+                    if (s < sx.n && gk >= sx.s[s].col && gk < sx.s[s].col + sx.s[s].width) {
+                        const int32_t c = gk - sx.s[s].col;
+                        if (sx.s[s].mode == 1) v = sx.s[s].ptr[((int64_t)(c / sx.s[s].f) * sx.s[s].n_total + gr) * sx.s[s].f + (c % sx.s[s].f)];
+                        else v = sx.s[s].ptr[(gr / sx.s[s].row_div) * sx.s[s].ld + c];
+                    }
+                }
+            }
+            xreg[i] = v;
+        }
+    };
+    fetch(r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) ds[tid + i * 256] = dreg[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[tid + i * 256] = xreg[i];
+        __syncthreads();
+        if (r0 + 32 < r_end) fetch(r0 + 32);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int t = wave + 4 * j;
+            if (t < TILES) {
+                const int nt = t / KGT, kt = t % KGT;
+                const float *ap = ds + (lane >> 5) * NG + nt * 32 + (lane & 31);
+                const float *bp = xs + (lane >> 5) * KG + kt * 32 + (lane & 31);
+#pragma unroll 4
+                for (int s = 0; s < 16; ++s)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * NG], bp[2 * s * KG], acc[j], 0, 0, 0);
+            }
+        }
+        if (want_bias && blockIdx.y == 0 && wave == 0 && lane < NG) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) bsum += ds[r * NG + lane];
+        }
+        __syncthreads();
+    }
+    float *__restrict__ part = partials + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = wave + 4 * j;
+        if (t >= TILES) continue;
+        const int nt = t / KGT, kt = t % KGT;
+        const int32_t k = k_base + kt * 32 + (lane & 31);
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int32_t n = n_base + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < N) part[(int64_t)n * K + k] = acc[j][r];
+        }
+    }
+    if (want_bias && blockIdx.y == 0 && wave == 0 && lane < NG && n_base + lane < N) part[(int64_t)N * K + n_base + lane] = bsum;
+}
+
+}  // namespace emer
+
+extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *stream) {
+    EMER_REQUIRE(d != nullptr && n_rows >= 0, "mlp_chain: bad arguments");
+    if (n_rows == 0) return EMER_OK;
+    EMER_REQUIRE(d->n_layers >= 1 && d->n_layers <= EMER_CHAIN_MAX_LAYERS && d->n_segs >= 1 && d->n_segs <= EMER_CHAIN_MAX_SEGS,
+                 "mlp_chain: n_layers=%d / n_segs=%d out of range", d->n_layers, d->n_segs);
+    EMER_REQUIRE(d->buf_cols >= 4 && d->buf_cols <= 512, "mlp_chain: buf_cols=%d out of range", d->buf_cols);
+    for (int s = 0; s < d->n_segs; ++s) {
+        const emer_chain_seg &S = d->segs[s];
+        EMER_REQUIRE(S.ptr && S.width >= 1 && S.col >= 0 && S.col + S.width <= d->buf_cols, "mlp_chain: bad segment %d", s);
+        EMER_REQUIRE((S.mode == 0 && S.row_div >= 1) || (S.mode == 1 && S.f >= 1 && S.width % S.f == 0), "mlp_chain: bad segment mode %d", s);
+        EMER_REQUIRE(!S.fix_a || S.fix_b, "mlp_chain: fix_a needs fix_b");
+    }
+    for (int l = 0; l < d->n_layers; ++l) {
+        const emer_chain_layer &L = d->layers[l];
+        EMER_REQUIRE(L.w && L.K >= 1 && L.N >= 1 && L.in_col >= 0 && L.out_col >= 0, "mlp_chain: bad layer %d", l);
+        EMER_REQUIRE((L.in_col & 1) == 0, "mlp_chain: layer %d: in_col must be even (8-byte LDS reads)", l);
+        EMER_REQUIRE(L.in_col + ((L.K + 7) / 8) * 8 <= d->buf_cols + 8 && L.out_col + L.N <= d->buf_cols, "mlp_chain: layer %d leaves the row buffer", l);
+        EMER_REQUIRE(L.act >= EMER_ACT_NONE && L.act <= EMER_ACT_TRUNC_EXP, "mlp_chain: layer %d: unknown activation", l);
+        EMER_REQUIRE(!L.store || (L.store_n >= 1 && L.store_col + L.store_n <= L.N && (L.store_mode == 0 || (L.store_mode == 1 && L.store_f >= 1))),
+                     "mlp_chain: layer %d: bad store", l);
+    }
+    const ChainLds lp = chain_lds_plan(d);
+    // as many waves per workgroup as the LDS allows (each owns a 16-row buffer), at least 4, at most 16:
+    // with small weight sets this gives 2-4 waves per SIMD to hide LDS / HBM latency
+    int n_waves = 16;
+    while (n_waves > 4 && ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float) > 160 * 1024) n_waves -= 4;
+    const size_t lds = ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float);
+    EMER_REQUIRE(lds <= 160 * 1024, "mlp_chain: chain needs %zu B of LDS (> 160 KiB); split it", lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("mlp_chain: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
+    }
+    const int64_t n_tiles = ceil_div(n_rows, 16);
+    int64_t grid = 256;  // persistent: one workgroup per CU
+    if (grid > ceil_div(n_tiles, n_waves)) grid = ceil_div(n_tiles, n_waves);
+    hipLaunchKernelGGL(mlp_chain_kernel, dim3((uint32_t)grid), dim3(64 * n_waves), lds, as_stream(stream), *d, lp, n_rows, n_tiles);
+    return check_launch("mlp_chain");
+}
+
+extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const emer_chain_seg *segs, int32_t n_segs, float *workspace,
+                                    float *dw, float *dbias, int64_t m, int32_t n, int32_t k, void *stream) {
+    EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "wgrad_segmented: bad sizes");
+    if (m == 0) return EMER_OK;
+    EMER_REQUIRE(dpre && segs && workspace && dw && n_segs >= 1 && n_segs <= EMER_CHAIN_MAX_SEGS, "wgrad_segmented: bad arguments");
+    SegX sx;
+    sx.n = n_segs;
+    int32_t covered = 0;
+    for (int s = 0; s < n_segs; ++s) {
+        EMER_REQUIRE(segs[s].ptr && segs[s].col == covered && ((segs[s].mode == 0 && segs[s].row_div >= 1) || (segs[s].mode == 1 && segs[s].f >= 1)),
+                     "wgrad_segmented: segments must be contiguous, mode 0 or 1");
+        sx.s[s] = segs[s];
+        covered += segs[s].width;
+    }
+    for (int s = n_segs; s < EMER_CHAIN_MAX_SEGS; ++s) sx.s[s] = segs[0];
+    EMER_REQUIRE(covered == k, "wgrad_segmented: segments cover %d columns, k = %d", covered, k);
+    hipStream_t st = as_stream(stream);
+    const int32_t NG = n <= 32 ? 32 : 64;
+    const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
+    const int32_t n_row_blocks = (int32_t)ceil_div(m, kDwRowsPerBlock);
+    const dim3 grid((uint32_t)n_row_blocks, (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
+#define EMER_WG(A, B) hipLaunchKernelGGL((wgrad_seg_kernel<A, B>), grid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, kDwRowsPerBlock, dbias ? 1 : 0)
+    if (NG == 32) { if (KG == 32) EMER_WG(1, 1); else if (KG == 64) EMER_WG(1, 2); else if (KG == 128) EMER_WG(1, 4); else EMER_WG(1, 8); }
+    else          { if (KG == 32) EMER_WG(2, 1); else if (KG == 64) EMER_WG(2, 2); else if (KG == 128) EMER_WG(2, 4); else EMER_WG(2, 8); }
+#undef EMER_WG
+    if (int rc = check_launch("wgrad_segmented")) return rc;
+    const int64_t stride = (int64_t)n * k + n;
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256)), dim3(256), 0, st, workspace, n_row_blocks, stride,
+                       (int64_t)n * k, dw, dbias);
+    return check_launch("wgrad_reduce");
+}

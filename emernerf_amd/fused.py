@@ -1,0 +1,292 @@
+"""Fused MLP heads: forward chains, dgrad chains and segmented weight gradients on ``emer_mlp_chain`` /
+``emer_wgrad_segmented`` (csrc/mlp.hip).
+
+Three autograd Functions cover the hot heads of the reference:
+  * ``base_mlp``     -- nn.Sequential(Linear(K0,H), ReLU, Linear(H,NG)) + density trunc_exp(out[:,0]-1)
+                        (radiance_field.py:74-80,89-96,315,422) fed straight from the LEVEL-MAJOR grid encoding;
+  * ``rgb_head``     -- mlp.MLP(3 layers, skip at layer 1) + sigmoid on [dir-PE | appearance emb | geo]
+                        (radiance_field.py:130-143,622-658); the per-ray part stays per ray, nothing is concatenated;
+  * ``density_mlp``  -- proposal net Linear(K0,H) ReLU Linear(H,1) trunc_exp (radiance_field.py:808-812,836-840).
+Activations never leave LDS inside a chain; what the backward needs (post-ReLU hidden activations) is written
+once by the forward and read once as relu' masks / wgrad operands.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int32, c_int64, c_void_p
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TRUNC_EXP
+
+MAX_LAYERS, MAX_SEGS = 6, 3
+E15 = 3269017.3724721107
+
+
+class ChainSeg(ctypes.Structure):
+    _fields_ = [("ptr", c_void_p), ("ld", c_int64), ("n_total", c_int64), ("fix_a", c_void_p), ("fix_b", c_void_p),
+                ("col", c_int32), ("width", c_int32), ("row_div", c_int32), ("mode", c_int32), ("f", c_int32), ("_pad", c_int32)]
+
+
+class ChainLayer(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("w_sn", c_int64), ("w_sk", c_int64), ("bias", c_void_p), ("mask", c_void_p),
+                ("mask_ld", c_int64), ("store", c_void_p), ("store_ld", c_int64), ("store_ntotal", c_int64),
+                ("store_exp0", c_void_p), ("in_col", c_int32), ("K", c_int32), ("out_col", c_int32), ("N", c_int32),
+                ("act", c_int32), ("accumulate", c_int32), ("store_col", c_int32), ("store_n", c_int32),
+                ("store_mode", c_int32), ("store_f", c_int32)]
+
+
+class ChainDesc(ctypes.Structure):
+    _fields_ = [("segs", ChainSeg * MAX_SEGS), ("layers", ChainLayer * MAX_LAYERS), ("n_segs", c_int32),
+                ("n_layers", c_int32), ("buf_cols", c_int32), ("_pad", c_int32)]
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def seg(t: Tensor, col: int, width: int, ld: Optional[int] = None, row_div: int = 1) -> ChainSeg:
+    """Row-major segment: value(row, c) = t[(row // row_div), c]."""
+    return ChainSeg(ptr=_p(t), ld=ld if ld is not None else t.stride(-2), n_total=0, fix_a=None, fix_b=None, col=col,
+                    width=width, row_div=row_div, mode=0, f=1)
+
+
+def seg_lm(t: Tensor, col: int) -> ChainSeg:
+    """Level-major grid encoding [L, N, F] as L*F columns."""
+    L, N, F = t.shape
+    return ChainSeg(ptr=_p(t), ld=0, n_total=N, fix_a=None, fix_b=None, col=col, width=L * F, row_div=1, mode=1, f=F)
+
+
+def layer(w: Tensor, bias: Optional[Tensor], in_col: int, out_col: int, act: int = ACT_NONE, transposed: bool = False,
+          n_slice: Optional[Tuple[int, int]] = None, mask: Optional[Tensor] = None, store: Optional[Tensor] = None,
+          store_cols: Optional[Tuple[int, int]] = None, store_lm: bool = False, store_exp0: Optional[Tensor] = None,
+          accumulate: bool = False) -> ChainLayer:
+    """w is a torch Linear weight [out, in].  transposed=True uses W^T (dgrad): output index runs over `in`.
+    n_slice=(a, b) restricts the chain layer's outputs to [a, b) of that output index."""
+    out_f, in_f = w.shape
+    if not transposed:
+        K, n_tot, sn, sk = in_f, out_f, w.stride(0), w.stride(1)
+    else:
+        K, n_tot, sn, sk = out_f, in_f, w.stride(1), w.stride(0)
+    a, b = n_slice if n_slice is not None else (0, n_tot)
+    ptr = w.data_ptr() + 4 * a * sn
+    N = b - a
+    L = ChainLayer(w=ptr, w_sn=sn, w_sk=sk, bias=None if bias is None else bias.data_ptr() + 4 * a, mask=_p(mask),
+                   mask_ld=0 if mask is None else mask.stride(0), store=None, store_ld=0, store_ntotal=0,
+                   store_exp0=_p(store_exp0), in_col=in_col, K=K, out_col=out_col, N=N, act=act, accumulate=int(accumulate),
+                   store_col=0, store_n=0, store_mode=0, store_f=1)
+    if store is not None:
+        L.store = store.data_ptr()
+        c0, c1 = store_cols if store_cols is not None else (0, N)
+        L.store_col, L.store_n = c0, c1 - c0
+        if store_lm:
+            Lv, Nt, F = store.shape
+            L.store_mode, L.store_f, L.store_ntotal = 1, F, Nt
+            assert Lv * F == L.store_n
+        else:
+            L.store_ld = store.stride(0)
+            assert store.shape[1] >= L.store_n
+    return L
+
+
+def run_chain(segs, layers, buf_cols: int, n_rows: int, ref: Tensor) -> None:
+    d = ChainDesc()
+    for i, s in enumerate(segs):
+        d.segs[i] = s
+    for i, l in enumerate(layers):
+        d.layers[i] = l
+    d.n_segs, d.n_layers, d.buf_cols = len(segs), len(layers), buf_cols
+    with torch.cuda.device(ref.device):
+        _lib.call("emer_mlp_chain", ctypes.byref(d), n_rows, _stream(ref))
+
+
+def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True):
+    """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments."""
+    M, N = dpre.shape
+    dev = dpre.device
+    with torch.cuda.device(dev):
+        n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, k_total))
+        ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
+        dw = torch.zeros((N, k_total), device=dev, dtype=torch.float32)
+        db = torch.zeros((N,), device=dev, dtype=torch.float32) if want_bias else None
+        arr = (ChainSeg * MAX_SEGS)()
+        for i, s in enumerate(segs):
+            arr[i] = s
+        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), arr, len(segs), _p(ws), _p(dw), _p(db), M, N, k_total,
+                  _stream(dpre))
+    return dw, db
+
+
+def _r4(x: int) -> int:
+    return (x + 3) // 4 * 4
+
+
+def _c(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ base MLP
+class _BaseMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+        ctx.set_materialize_grads(False)
+        enc, W0, B0, W1, B1 = _c(enc_lm), _c(w0), _c(b0), _c(w1), _c(b1)
+        L, N, F = enc.shape
+        K0, H, NG = L * F, W0.shape[0], W1.shape[0]
+        dev = enc.device
+        h1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        g = torch.empty((N, NG), device=dev, dtype=torch.float32)
+        dens = torch.empty((N,), device=dev, dtype=torch.float32)
+        c_h = _r4(K0)
+        c_g = c_h + _r4(H)
+        run_chain([seg_lm(enc, 0)],
+                  [layer(W0, B0, 0, c_h, ACT_RELU, store=h1), layer(W1, B1, c_h, c_g, ACT_NONE, store=g, store_exp0=dens)],
+                  c_g + NG, N, enc)
+        ctx.save_for_backward(enc, W0, W1, h1, dens)
+        return g, dens
+
+    @staticmethod
+    def backward(ctx, dg: Optional[Tensor], ddens: Optional[Tensor]):
+        enc, W0, W1, h1, dens = ctx.saved_tensors
+        L, N, F = enc.shape
+        K0, H, NG = L * F, W0.shape[0], W1.shape[0]
+        dev = enc.device
+        if dg is None and ddens is None:
+            return None, None, None, None, None
+        dgt = torch.zeros((N, NG), device=dev, dtype=torch.float32) if dg is None else _c(dg).clone()
+        if ddens is not None:  # trunc_exp backward merged into geometry feature 0 (nerf_utils.py:69-72)
+            dgt[:, 0] += _c(ddens) * dens.clamp(max=E15)
+        dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+        c_h, c_e = _r4(NG), _r4(NG) + _r4(H)
+        run_chain([seg(dgt, 0, NG)],
+                  [layer(W1, None, 0, c_h, transposed=True, mask=h1, store=dpre0),
+                   layer(W0, None, c_h, c_e, transposed=True, store=denc, store_lm=True)],
+                  c_e + K0, N, enc)
+        dw1, db1 = wgrad(dgt, [seg(h1, 0, H)], H)
+        dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
+        return denc, dw0, db0, dw1, db1
+
+
+def base_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tuple[Tensor, Tensor]:
+    """(feats [N, NG], density [N]) from the level-major grid encoding [L, N, F]."""
+    return _BaseMLPFn.apply(enc_lm, w0, b0, w1, b1)
+
+
+# -------------------------------------------------------------------------------------- density MLP
+class _DensityMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+        ctx.set_materialize_grads(False)
+        enc, W0, B0, W1, B1 = _c(enc_lm), _c(w0), _c(b0), _c(w1), _c(b1)
+        L, N, F = enc.shape
+        K0, H = L * F, W0.shape[0]
+        dev = enc.device
+        need_grad = any(ctx.needs_input_grad)
+        h = torch.empty((N, H), device=dev, dtype=torch.float32) if need_grad else None
+        dens = torch.empty((N, 1), device=dev, dtype=torch.float32)
+        c_h = _r4(K0)
+        c_o = c_h + _r4(H)
+        run_chain([seg_lm(enc, 0)],
+                  [layer(W0, B0, 0, c_h, ACT_RELU, store=h), layer(W1, B1, c_h, c_o, ACT_TRUNC_EXP, store=dens)],
+                  c_o + 4, N, enc)
+        ctx.save_for_backward(enc, W0, W1, h, dens)
+        return dens.view(N)
+
+    @staticmethod
+    def backward(ctx, ddens: Optional[Tensor]):
+        enc, W0, W1, h, dens = ctx.saved_tensors
+        if ddens is None:
+            return None, None, None, None, None
+        L, N, F = enc.shape
+        K0, H = L * F, W0.shape[0]
+        dev = enc.device
+        dpre1 = (_c(ddens).view(N, 1) * dens.clamp(max=E15)).contiguous()
+        dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+        c_h, c_e = 4, 4 + _r4(H)
+        run_chain([seg(dpre1, 0, 1)],
+                  [layer(W1, None, 0, c_h, transposed=True, mask=h, store=dpre0),
+                   layer(W0, None, c_h, c_e, transposed=True, store=denc, store_lm=True)],
+                  c_e + K0, N, enc)
+        dw1, db1 = wgrad(dpre1, [seg(h, 0, H)], H)
+        dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
+        return denc, dw0, db0, dw1, db1
+
+
+def density_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
+    """trunc_exp(Linear(ReLU(Linear(enc))) - 1) -> [N]."""
+    return _DensityMLPFn.apply(enc_lm, w0, b0, w1, b1)
+
+
+# ------------------------------------------------------------------------------------------ rgb head
+class _RgbHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hray: Tensor, geo: Tensor, S: int, w0, b0, w1, b1, w2, b2):
+        ctx.set_materialize_grads(False)
+        hr, W0, B0, W1, B1, W2, B2 = _c(hray), _c(w0), _c(b0), _c(w1), _c(b1), _c(w2), _c(b2)
+        g = geo.detach()
+        assert g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1
+        N, NG = g.shape
+        R, Kh = hr.shape
+        assert R * S == N
+        H, K0, C = W0.shape[0], Kh + NG, W2.shape[0]
+        assert W0.shape[1] == K0 and W1.shape[1] == H + K0 and W2.shape[1] == H
+        dev = g.device
+        a1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        out = torch.empty((N, C), device=dev, dtype=torch.float32)
+        c_x = _r4(H)               # [A1 | hray | geo] laid out exactly like torch.cat([x, input]) of mlp.py:42
+        c_a2 = c_x + _r4(K0)
+        c_o = c_a2 + _r4(H)
+        run_chain([seg(hr, c_x, Kh, row_div=S), seg(g, c_x + Kh, NG, ld=g.stride(0))],
+                  [layer(W0, B0, c_x, 0, ACT_RELU, store=a1),
+                   layer(W1, B1, 0, c_a2, ACT_RELU, store=a2),
+                   layer(W2, B2, c_a2, c_o, ACT_SIGMOID, store=out)],
+                  c_o + 4, N, g)
+        ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Optional[Tensor]):
+        hr, g, W0, W1, W2, a1, a2, out = ctx.saved_tensors
+        if dout is None:
+            return (None,) * 9
+        S = ctx.S
+        N, NG = g.shape
+        R, Kh = hr.shape
+        H, K0, C = W0.shape[0], Kh + NG, W2.shape[0]
+        assert H == _r4(H)
+        dev = g.device
+        dpre2 = (_c(dout) * out * (1.0 - out)).contiguous()            # sigmoid'
+        dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dh = torch.empty((N, Kh), device=dev, dtype=torch.float32)
+        dgeo = torch.empty((N, NG), device=dev, dtype=torch.float32)
+        c1 = _r4(C)                 # dA2 -> dPre1
+        cx = c1 + H                 # d[A1 | hray | geo]; dA1 -> dPre0 in place
+        run_chain([seg(dpre2, 0, C)],
+                  [layer(W2, None, 0, c1, transposed=True, mask=a2, store=dpre1),
+                   layer(W1, None, c1, cx, transposed=True, n_slice=(0, H), mask=a1, store=dpre0),
+                   layer(W1, None, c1, cx + H, transposed=True, n_slice=(H, H + K0)),
+                   layer(W0, None, cx, cx + H, transposed=True, n_slice=(0, Kh), accumulate=True, store=dh),
+                   layer(W0, None, cx, cx + H + Kh, transposed=True, n_slice=(Kh, K0), accumulate=True, store=dgeo)],
+                  cx + H + K0, N, g)
+        dw2, db2 = wgrad(dpre2, [seg(a2, 0, H)], H)
+        dw1, db1 = wgrad(dpre1, [seg(a1, 0, H), seg(hr, H, Kh, row_div=S), seg(g, H + Kh, NG, ld=g.stride(0))], H + K0)
+        dw0, db0 = wgrad(dpre0, [seg(hr, 0, Kh, row_div=S), seg(g, Kh, NG, ld=g.stride(0))], K0)
+        dhray = dh.view(R, S, Kh).sum(dim=1)
+        return dhray, dgeo, None, dw0, db0, dw1, db1, dw2, db2
+
+
+def rgb_head(hray: Tensor, geo: Tensor, samples_per_ray: int, w0, b0, w1, b1, w2, b2) -> Tensor:
+    """sigmoid(MLP3-skip1([hray[ray] | geo])) -> [N, 3]; hray [R, Kh] per ray, geo [N, NG] per sample."""
+    return _RgbHeadFn.apply(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2)

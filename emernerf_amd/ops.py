@@ -133,6 +133,55 @@ class _HashGridFn(torch.autograd.Function):
         return dx, dp, None, None
 
 
+class _HashGridLMFn(torch.autograd.Function):
+    """Same as _HashGridFn but exchanges the LEVEL-MAJOR [L, N, F] tensors the grid kernels use natively
+    (no transpose kernels): what the fused MLP chains read and write."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype):
+        xc, pc = _f32c(x), params.detach().contiguous()
+        gdt = grad_dtype or torch.float32
+        ctx.sliced = bool(ctx.needs_input_grad[1] and gdt == torch.float32 and sliced_supported(desc))
+        if ctx.sliced:
+            lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=True)
+        else:
+            lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
+        ctx.desc, ctx.grad_dtype = desc, grad_dtype
+        ctx.save_for_backward(xc, pc, masks)
+        return lm
+
+    @staticmethod
+    def backward(ctx, dlm: Tensor):
+        xc, pc, masks = ctx.saved_tensors
+        desc = ctx.desc
+        N, L, F = xc.shape[0], desc.n_levels, desc.n_features
+        dx = dp = None
+        with torch.cuda.device(xc.device):
+            dlm = _f32c(dlm)
+            st = _stream(xc)
+            if ctx.needs_input_grad[1]:
+                gdt = ctx.grad_dtype or torch.float32
+                if gdt == torch.float32 and masks is not None:
+                    grad = torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
+                    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
+                              _ptr(grad), N, st)
+                else:
+                    grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
+                    _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
+                              _dtype_tag(grad), N, st)
+                dp = grad.to(pc.dtype) if grad.dtype != pc.dtype else grad
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(xc)
+                _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,
+                          N * F, _ptr(dx), N, st)
+        return dx, dp, None, None
+
+
+def hashgrid_encode_lm(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:
+    """x [N,D] in [0,1] -> level-major [L, N, F] fp32, differentiable w.r.t. params and x."""
+    return _HashGridLMFn.apply(x, params, desc, grad_dtype)
+
+
 def hashgrid_encode(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:
     """x [N,D] in [0,1] -> [N, L*F] fp32, differentiable w.r.t. params and x."""
     return _HashGridFn.apply(x, params, desc, grad_dtype)

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import ops
+from . import fused, ops
 from .encodings import HashEncoder, SinusoidalEncoder, build_xyz_encoder_from_cfg
 
 logger = logging.getLogger()
@@ -222,9 +222,13 @@ class RadianceField(nn.Module):
         """:278-300 (contraction + selector zeroing), one fused kernel, differentiable."""
         return ops.contract_points(positions, self.aabb, self.unbounded)
 
+    def _base(self, encoder: HashEncoder, mlp: nn.Sequential, x: Tensor):
+        """grid -> Linear-ReLU-Linear (+ density of feature 0): one level-major grid kernel + one fused chain."""
+        enc_lm = encoder.tcnn_encoding.forward_level_major(x)
+        return fused.base_mlp(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+
     def _static_from_normed(self, normed_positions: Tensor):
-        enc = self.xyz_encoder(normed_positions.reshape(-1, self.num_dims))
-        feats, density = _run_sequential(self.base_mlp, enc, density_from_col0=True)
+        feats, density = self._base(self.xyz_encoder, self.base_mlp, normed_positions.reshape(-1, self.num_dims))
         lead = normed_positions.shape[:-1]
         return feats.view(*lead, -1), density.view(*lead)
 
@@ -234,12 +238,18 @@ class RadianceField(nn.Module):
         feats, _ = self._static_from_normed(normed_positions)
         return feats, normed_positions
 
-    def _dynamic(self, normed_positions: Tensor, normed_timestamps: Tensor, want_density: bool):
+    def _dynamic(self, normed_positions: Tensor, normed_timestamps: Tensor, want_density: bool, want_hash: bool = True):
+        """want_hash=False: the row-major hash encodings (a "to be studied" output of the reference, :457-459,
+        615-617) are not needed, so the fused level-major path is used."""
         if normed_timestamps.shape[-1] != 1:
             normed_timestamps = normed_timestamps.unsqueeze(-1)
         temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
-        enc = self.dynamic_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
         lead = temporal_positions.shape[:-1]
+        if not want_hash:
+            feats, density = self._base(self.dynamic_xyz_encoder, self.dynamic_base_mlp,
+                                        temporal_positions.reshape(-1, self.num_dims + 1))
+            return feats.view(*lead, -1), None, (density.view(*lead) if want_density else None)
+        enc = self.dynamic_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
         if want_density:
             feats, density = _run_sequential(self.dynamic_base_mlp, enc, density_from_col0=True)
             return feats.view(*lead, -1), enc.view(*lead, -1), density.view(*lead)
@@ -289,21 +299,76 @@ class RadianceField(nn.Module):
             "backward_dynamic_hash_encodings": bwd_enc,
         }
 
+    @staticmethod
+    def _per_ray(t: Tensor) -> bool:
+        """True for a (R, S[, C]) tensor that is a stride-0 broadcast of per-ray values along S (what
+        render_rays passes instead of the reference's repeat_interleave copies)."""
+        return t.dim() >= 2 and t.shape[1] > 1 and t.stride(1) == 0
+
+    def _embed(self, idx: Tensor) -> Tensor:
+        if self._per_ray(idx):  # look up once per ray, broadcast along the samples (same values, 1/S of the work)
+            return self.appearance_embedding(idx[:, 0])[:, None, :].expand(-1, idx.shape[1], -1)
+        return self.appearance_embedding(idx)
+
+    def _encode_dirs(self, directions: Tensor, remap: bool) -> Tensor:
+        if self._per_ray(directions):
+            enc = self.direction_encoding(directions[:, 0].contiguous(), remap=remap)
+            return enc[:, None, :].expand(-1, directions.shape[1], -1)
+        return self.direction_encoding(directions, remap=remap)
+
     def _appearance(self, directions: Tensor, data_dict: Optional[Dict[str, Tensor]]):
         if not (self.enable_cam_embedding or self.enable_img_embedding):
             return None
         data_dict = data_dict or {}
         if "cam_idx" in data_dict and self.enable_cam_embedding:
-            return self.appearance_embedding(data_dict["cam_idx"])
+            return self._embed(data_dict["cam_idx"])
         if "img_idx" in data_dict and self.enable_img_embedding:
-            return self.appearance_embedding(data_dict["img_idx"])
+            return self._embed(data_dict["img_idx"])
         return torch.ones((*directions.shape[:-1], self.appearance_embedding_dim), device=directions.device) \
             * self.appearance_embedding.weight.mean(dim=0)
+
+    def _query_rgb_fused(self, directions, geo_feats, dynamic_geo_feats, data_dict):
+        """Fused rgb head: per-ray [dir-PE | appearance emb] stays per ray, geo stays per sample, the whole
+        3-layer skip MLP + sigmoid is one chain.  Applies when render_rays hands in stride-0 per-ray views."""
+        head = self.rgb_head
+        if not (directions.dim() == 3 and self._per_ray(directions) and len(head.layers) == 3
+                and list(head.skip_connections) == [1] and head.hidden_dims % 4 == 0):
+            return None
+        R, S = directions.shape[:2]
+        data_dict = data_dict or {}
+        emb = None
+        if self.enable_cam_embedding or self.enable_img_embedding:
+            key = "cam_idx" if ("cam_idx" in data_dict and self.enable_cam_embedding) else \
+                ("img_idx" if ("img_idx" in data_dict and self.enable_img_embedding) else None)
+            if key is None:
+                emb = self.appearance_embedding.weight.mean(dim=0)[None, :].expand(R, -1)
+            elif self._per_ray(data_dict[key]):
+                emb = self.appearance_embedding(data_dict[key][:, 0])
+            else:
+                return None
+        pe = self.direction_encoding(directions[:, 0].contiguous(), remap=True)
+        hray = pe if emb is None else torch.cat([pe, emb], dim=-1)
+        lw = [p for l in head.layers for p in (l.weight, l.bias)]
+
+        def run(geo):
+            g2 = geo.reshape(R * S, geo.shape[-1])
+            if g2.stride(-1) != 1:
+                g2 = g2.contiguous()
+            return fused.rgb_head(hray, g2, S, *lw).view(R, S, -1)
+
+        results = {"rgb": run(geo_feats)}
+        if self.dynamic_xyz_encoder is not None:
+            assert dynamic_geo_feats is not None, "Dynamic geometry features are not provided."
+            results["dynamic_rgb"] = run(dynamic_geo_feats)
+        return results
 
     def query_rgb(self, directions: Tensor, geo_feats: Tensor, dynamic_geo_feats: Tensor = None,
                   data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
         """:622-658."""
-        h = self.direction_encoding(directions, remap=True)  # (d + 1) / 2 folded into the kernel
+        fused_out = self._query_rgb_fused(directions, geo_feats, dynamic_geo_feats, data_dict)
+        if fused_out is not None:
+            return fused_out
+        h = self._encode_dirs(directions, remap=True)  # (d + 1) / 2 folded into the kernel
         emb = self._appearance(directions, data_dict)
         if emb is not None:
             h = torch.cat([h, emb], dim=-1)
@@ -341,7 +406,7 @@ class RadianceField(nn.Module):
                 else data_dict["lidar_normed_timestamps"]
             use_flow = self.flow_xyz_encoder is not None
             dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
-                normed_positions, normed_timestamps, want_density=not use_flow)
+                normed_positions, normed_timestamps, want_density=not use_flow, want_hash=use_flow)
             if use_flow:
                 flow = self.forward_flow_hash(normed_positions, normed_timestamps)
                 forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
@@ -411,7 +476,7 @@ class RadianceField(nn.Module):
         flow = self.forward_flow_hash(normed_positions, normed_timestamps)
         results = {"forward_flow": flow[..., :3], "backward_flow": flow[..., 3:]}
         if query_density:
-            _, _, density = self._dynamic(normed_positions, normed_timestamps, want_density=True)
+            _, _, density = self._dynamic(normed_positions, normed_timestamps, want_density=True, want_hash=False)
             results["dynamic_density"] = density
         return results
 
@@ -457,10 +522,9 @@ class DensityField(nn.Module):
 
     def density_from_normed(self, normed: Tensor) -> Tensor:
         """normed [..., 3] already contracted -> density [..., 1]."""
-        enc = self.xyz_encoder(normed.reshape(-1, self.num_dims))
+        enc_lm = self.xyz_encoder.tcnn_encoding.forward_level_major(normed.reshape(-1, self.num_dims))
         lin0, lin1 = self.base_mlp[0], self.base_mlp[2]
-        h = ops.linear(enc, lin0.weight, lin0.bias, "relu")
-        d = ops.linear(h, lin1.weight, lin1.bias, "trunc_exp")
+        d = fused.density_mlp(enc_lm, lin0.weight, lin0.bias, lin1.weight, lin1.bias)  # grid -> 64 -> 1 -> trunc_exp, one chain
         return d.view(*normed.shape[:-1], 1)
 
     def forward(self, positions: Tensor, data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:

@@ -74,5 +74,13 @@ class Encoding(torch.nn.Module):
                                   grad_dtype=None if self.dtype == torch.float32 else torch.float16)
         return out.view(*lead, self.n_output_dims)
 
+    def forward_level_major(self, x: Tensor) -> Tensor:
+        """[N, D] -> [L, N, F]: the grid kernels' native layout, consumed directly by the fused MLP chains."""
+        if not x.is_cuda:
+            raise _lib.EmerError("Encoding.forward needs a GPU tensor (no CPU fallback)")
+        params = self.params if self.dtype == torch.float32 else self.params.to(torch.float16)
+        return ops.hashgrid_encode_lm(x.reshape(-1, self.n_input_dims), params, self.desc,
+                                      grad_dtype=None if self.dtype == torch.float32 else torch.float16)
+
     def extra_repr(self):
         return f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, dtype={self.dtype}, {self.encoding_config}"

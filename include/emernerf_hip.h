@@ -193,6 +193,63 @@ int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, 
                     float *dw, float *dbias, int64_t m, int32_t n, int32_t k, int act,
                     const float *d_aux_density, const float *aux_density, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused MLP chains.  One launch evaluates up to EMER_CHAIN_MAX_LAYERS dense layers on 16-row tiles with
+ * every activation kept in LDS between layers (replaces the per-layer nn.Linear / ReLU / cat / Sigmoid
+ * launches of radiance_field.py:74-198,315,622-658 and mlp.py:38-46, and their autograd).  The same entry
+ * point runs the dgrad chains of the backward: weights are addressed through (w_sn, w_sk) strides, so
+ * W^T needs no copy, and `mask` applies relu' from a saved activation.
+ * ---------------------------------------------------------------------------------------------- */
+#define EMER_CHAIN_MAX_LAYERS 6
+#define EMER_CHAIN_MAX_SEGS 3
+
+/* A column segment [col, col+width) of the per-row working buffer, filled from global memory before the
+ * layers run (several segments = a virtual torch.cat).
+ *   mode 0: value(row, c) = ptr[(row / row_div) * ld + c]         (row_div = samples per ray for per-ray data)
+ *   mode 1: level-major grid encoding [L][n_total][f]: ptr[((c / f) * n_total + row) * f + c % f]
+ * fix_a/fix_b (may be NULL): buffer[row][col] += fix_a[row] * min(fix_b[row], e^15)   (density gradient merge) */
+typedef struct emer_chain_seg {
+    const float *ptr;
+    int64_t ld;
+    int64_t n_total;
+    const float *fix_a;
+    const float *fix_b;
+    int32_t col, width, row_div, mode, f, _pad;
+} emer_chain_seg;
+
+/* out[:, out_col:out_col+N] (op)= act(in[:, in_col:in_col+K] @ W^T + bias), W element (n,k) = w[n*w_sn + k*w_sk].
+ * accumulate != 0: out += result.  mask (may be NULL): out *= (mask[row*mask_ld + col] > 0) after act.
+ * store (may be NULL): copy out[:, store_col:store_col+store_n] to global; store_mode 0 row-major (store_ld),
+ *   1 level-major [L][store_ntotal][store_f].  store_exp0 (may be NULL): exp(out[row][0] - 1) per row. */
+typedef struct emer_chain_layer {
+    const float *w;
+    int64_t w_sn, w_sk;
+    const float *bias;
+    const float *mask;
+    int64_t mask_ld;
+    float *store;
+    int64_t store_ld, store_ntotal;
+    float *store_exp0;
+    int32_t in_col, K, out_col, N, act, accumulate;
+    int32_t store_col, store_n, store_mode, store_f;
+} emer_chain_layer;
+
+typedef struct emer_chain_desc {
+    emer_chain_seg segs[EMER_CHAIN_MAX_SEGS];
+    emer_chain_layer layers[EMER_CHAIN_MAX_LAYERS];
+    int32_t n_segs, n_layers;
+    int32_t buf_cols; /* columns of the per-row working buffer (<= 512) */
+    int32_t _pad;
+} emer_chain_desc;
+
+int emer_mlp_chain(const emer_chain_desc *host_desc, int64_t n_rows, void *stream);
+
+/* dW[N,K] += dpre[M,N]^T @ X[M,K], dbias[N] += colsum(dpre), with X given as up to EMER_CHAIN_MAX_SEGS
+ * column segments (modes 0 and 1; a virtual concat).  workspace: emer_linear_bwd_workspace(m, n, k) floats. */
+int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const emer_chain_seg *host_segs, int32_t n_segs,
+                         float *workspace, float *dw, float *dbias, int64_t m, int32_t n, int32_t k,
+                         void *stream);
+
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */
 int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, void *stream);

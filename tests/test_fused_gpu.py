@@ -1,0 +1,94 @@
+"""Fused MLP chains (emer_mlp_chain / emer_wgrad_segmented) vs fp64 torch references of the reference's heads."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(name, got, want, rtol=1e-4, scale_atol=2e-5):
+    got, want = got.detach().double().cpu().numpy(), want.detach().double().cpu().numpy()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=scale_atol * max(np.abs(want).max(), 1e-30), err_msg=name)
+
+
+@pytest.mark.parametrize("L,Fe,NG,N", [(16, 2, 64, 1000), (10, 4, 128, 777), (4, 2, 64, 16), (8, 1, 64, 33)])
+def test_base_mlp(hip_lib, L, Fe, NG, N):
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L + NG + N)
+    K0, H = L * Fe, 64
+    enc = torch.randn(L, N, Fe, generator=g)
+    W0, b0 = torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g) * 0.1
+    W1, b1 = torch.randn(NG, H, generator=g) / H ** 0.5, torch.randn(NG, generator=g) * 0.1
+    t = [v.to(dev).requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    feats, dens = fused.base_mlp(*t)
+    r = [v.double().requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    x = r[0].permute(1, 0, 2).reshape(N, K0)  # row-major view of the level-major encoding
+    f_ref = F.linear(torch.relu(F.linear(x, r[1], r[2])), r[3], r[4])
+    d_ref = torch.exp(f_ref[:, 0] - 1)
+    _close("feats", feats, f_ref); _close("density", dens, d_ref)
+    gf, gd = torch.randn(N, NG, generator=g), torch.randn(N, generator=g)
+    (feats * gf.to(dev)).sum().add((dens * gd.to(dev)).sum()).backward()
+    ((f_ref * gf.double()).sum() + (d_ref * gd.double()).sum()).backward()
+    for name, a, b in zip(("denc", "dW0", "db0", "dW1", "db1"), t, r):
+        _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+    # only one of the two outputs carries gradient
+    t2 = [v.detach().clone().requires_grad_(True) for v in t]
+    _, dens2 = fused.base_mlp(*t2)
+    dens2.sum().backward()
+    assert t2[1].grad is not None and torch.isfinite(t2[0].grad).all()
+
+
+@pytest.mark.parametrize("L,N", [(8, 1000), (8, 17), (4, 256)])
+def test_density_mlp(hip_lib, L, N):
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L + N)
+    enc = torch.randn(L, N, 1, generator=g)
+    W0, b0 = torch.randn(64, L, generator=g) / L ** 0.5, torch.randn(64, generator=g) * 0.1
+    W1, b1 = torch.randn(1, 64, generator=g) / 8, torch.randn(1, generator=g) * 0.1
+    t = [v.to(dev).requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    dens = fused.density_mlp(*t)
+    r = [v.double().requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    d_ref = torch.exp(F.linear(torch.relu(F.linear(r[0].permute(1, 0, 2).reshape(N, L), r[1], r[2])), r[3], r[4])[:, 0] - 1)
+    _close("density", dens, d_ref)
+    gd = torch.randn(N, generator=g)
+    (dens * gd.to(dev)).sum().backward()
+    (d_ref * gd.double()).sum().backward()
+    for name, a, b in zip(("denc", "dW0", "db0", "dW1", "db1"), t, r):
+        _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+    with torch.no_grad():  # inference path: no activations saved
+        _close("density_nograd", fused.density_mlp(*[v.detach() for v in t]), d_ref)
+
+
+@pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64)])
+def test_rgb_head(hip_lib, R, S, Kh, NG, ld):
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(R * S + Kh)
+    N, H, K0 = R * S, 64, Kh + NG
+    hray = torch.randn(R, Kh, generator=g)
+    feats = torch.randn(N, ld, generator=g)  # geo is the first NG columns of a wider feature tensor when ld > NG
+    Ws = [torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g) * 0.1,
+          torch.randn(H, H + K0, generator=g) / (H + K0) ** 0.5, torch.randn(H, generator=g) * 0.1,
+          torch.randn(3, H, generator=g) / H ** 0.5, torch.randn(3, generator=g) * 0.1]
+    hd = hray.to(dev).requires_grad_(True)
+    fd = feats.to(dev).requires_grad_(True)
+    wd = [w.to(dev).requires_grad_(True) for w in Ws]
+    rgb = fused.rgb_head(hd, fd[:, :NG], S, *wd)
+    h64, f64 = hray.double().requires_grad_(True), feats.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in Ws]
+    inp = torch.cat([h64.repeat_interleave(S, dim=0), f64[:, :NG]], -1)  # [dir-PE | emb | geo], radiance_field.py:644
+    x = torch.relu(F.linear(inp, w64[0], w64[1]))
+    x = torch.relu(F.linear(torch.cat([x, inp], -1), w64[2], w64[3]))   # mlp.py:41-42 skip connection
+    ref = torch.sigmoid(F.linear(x, w64[4], w64[5]))
+    _close("rgb", rgb, ref)
+    go = torch.randn(N, 3, generator=g)
+    (rgb * go.to(dev)).sum().backward()
+    (ref * go.double()).sum().backward()
+    _close("dhray", hd.grad, h64.grad, rtol=2e-4, scale_atol=5e-5)
+    _close("dfeats", fd.grad, f64.grad, rtol=2e-4, scale_atol=5e-5)
+    for i, (a, b) in enumerate(zip(wd, w64)):
+        _close(f"dW{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
