@@ -527,7 +527,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_kernel(const emer_chain_desc d
 }
 
 // dW kernel with a segmented (virtual concat) X operand; dPre is given materialised.
-struct SegX { emer_chain_seg s[EMER_CHAIN_MAX_SEGS]; int32_t n; };
+struct SegX { emer_chain_seg s[EMER_CHAIN_MAX_SEGS]; int32_t n; const float *fix_a; const float *fix_b; };
 
 template <int NGT, int KGT>
 __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
@@ -546,14 +546,27 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
     for (int j = 0; j < TPW; ++j) acc[j] = f32x16{0};
     float bsum = 0.0f;
     float dreg[ND], xreg[NX];
+    int fl[EMER_CHAIN_MAX_SEGS];
+#pragma unroll
+    for (int s = 0; s < EMER_CHAIN_MAX_SEGS; ++s) fl[s] = __ffs(sx.s[s].f > 0 ? sx.s[s].f : 1) - 1;
     auto fetch = [&](int64_t r0) {
+        int64_t ray0[EMER_CHAIN_MAX_SEGS];
+        int32_t rem0[EMER_CHAIN_MAX_SEGS];
+#pragma unroll
+        for (int s = 0; s < EMER_CHAIN_MAX_SEGS; ++s) {  // per-ray operands: ONE scalar division per segment per 32-row tile
+            const int32_t rd = sx.s[s].row_div > 0 ? sx.s[s].row_div : 1;
+            ray0[s] = (rd == 1) ? r0 : r0 / rd;
+            rem0[s] = (int32_t)(r0 - ray0[s] * rd);
+        }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int idx = tid + i * 256;
             const int r = idx / NG, c = idx % NG;
             const int64_t gr = r0 + r;
             const int32_t gn = n_base + c;
-            dreg[i] = (gr < r_end && gn < N) ? dpre[gr * ldd + gn] : 0.0f;
+            float dv = (gr < r_end && gn < N) ? dpre[gr * ldd + gn] : 0.0f;
+            if (sx.fix_a && gn == 0 && gr < r_end) dv += sx.fix_a[gr] * fminf(sx.fix_b[gr], 3269017.3724721107f);
+            dreg[i] = dv;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -567,8 +580,15 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
                 for (int s = 0; s < EMER_CHAIN_MAX_SEGS; ++s) {
                     if (s < sx.n && gk >= sx.s[s].col && gk < sx.s[s].col + sx.s[s].width) {
                         const int32_t c = gk - sx.s[s].col;
-                        if (sx.s[s].mode == 1) v = sx.s[s].ptr[((int64_t)(c / sx.s[s].f) * sx.s[s].n_total + gr) * sx.s[s].f + (c % sx.s[s].f)];
-                        else v = sx.s[s].ptr[(gr / sx.s[s].row_div) * sx.s[s].ld + c];
+                        if (sx.s[s].mode == 1) {
+                            v = sx.s[s].ptr[((int64_t)(c >> fl[s]) * sx.s[s].n_total + gr) * sx.s[s].f + (c & (sx.s[s].f - 1))];
+                        } else if (sx.s[s].row_div == 1) {
+                            v = sx.s[s].ptr[gr * sx.s[s].ld + c];
+                        } else {  // per-ray operand (32 <= row_div in practice: at most one ray boundary inside a tile)
+                            const int32_t rem = rem0[s] + r;
+                            const int64_t ray = rem < sx.s[s].row_div ? ray0[s] : ray0[s] + rem / sx.s[s].row_div;
+                            v = sx.s[s].ptr[ray * sx.s[s].ld + c];
+                        }
                     }
                 }
             }
@@ -645,7 +665,7 @@ extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *st
     // as many waves per workgroup as the LDS allows (each owns a 16-row buffer), at least 4, at most 16:
     // with small weight sets this gives 2-4 waves per SIMD to hide LDS / HBM latency
     int n_waves = 16;
-    while (n_waves > 4 && ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float) > 160 * 1024) n_waves -= 4;
+    while (n_waves > 4 && ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float) > 160 * 1024) n_waves -= 2;
     const size_t lds = ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float);
     EMER_REQUIRE(lds <= 160 * 1024, "mlp_chain: chain needs %zu B of LDS (> 160 KiB); split it", lds);
     if (lds > 48 * 1024) {
@@ -659,13 +679,15 @@ extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *st
     return check_launch("mlp_chain");
 }
 
-extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const emer_chain_seg *segs, int32_t n_segs, float *workspace,
-                                    float *dw, float *dbias, int64_t m, int32_t n, int32_t k, void *stream) {
+extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float *fix_a, const float *fix_b, const emer_chain_seg *segs,
+                                    int32_t n_segs, float *workspace, float *dw, float *dbias, int64_t m, int32_t n, int32_t k,
+                                    void *stream) {
     EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "wgrad_segmented: bad sizes");
     if (m == 0) return EMER_OK;
     EMER_REQUIRE(dpre && segs && workspace && dw && n_segs >= 1 && n_segs <= EMER_CHAIN_MAX_SEGS, "wgrad_segmented: bad arguments");
     SegX sx;
-    sx.n = n_segs;
+    sx.n = n_segs; sx.fix_a = fix_a; sx.fix_b = fix_b;
+    EMER_REQUIRE(!fix_a || fix_b, "wgrad_segmented: fix_a needs fix_b");
     int32_t covered = 0;
     for (int s = 0; s < n_segs; ++s) {
         EMER_REQUIRE(segs[s].ptr && segs[s].col == covered && ((segs[s].mode == 0 && segs[s].row_div >= 1) || (segs[s].mode == 1 && segs[s].f >= 1)),

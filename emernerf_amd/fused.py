@@ -107,7 +107,7 @@ def run_chain(segs, layers, buf_cols: int, n_rows: int, ref: Tensor) -> None:
         _lib.call("emer_mlp_chain", ctypes.byref(d), n_rows, _stream(ref))
 
 
-def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True):
+def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, fix_a: Optional[Tensor] = None, fix_b: Optional[Tensor] = None):
     """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments."""
     M, N = dpre.shape
     dev = dpre.device
@@ -119,8 +119,8 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True):
         arr = (ChainSeg * MAX_SEGS)()
         for i, s in enumerate(segs):
             arr[i] = s
-        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), arr, len(segs), _p(ws), _p(dw), _p(db), M, N, k_total,
-                  _stream(dpre))
+        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(fix_a), _p(fix_b), arr, len(segs), _p(ws), _p(dw), _p(db),
+                  M, N, k_total, _stream(dpre))
     return dw, db
 
 
@@ -160,17 +160,21 @@ class _BaseMLPFn(torch.autograd.Function):
         dev = enc.device
         if dg is None and ddens is None:
             return None, None, None, None, None
-        dgt = torch.zeros((N, NG), device=dev, dtype=torch.float32) if dg is None else _c(dg).clone()
-        if ddens is not None:  # trunc_exp backward merged into geometry feature 0 (nerf_utils.py:69-72)
-            dgt[:, 0] += _c(ddens) * dens.clamp(max=E15)
+        dgt = torch.zeros((N, NG), device=dev, dtype=torch.float32) if dg is None else _c(dg)
+        # trunc_exp backward (nerf_utils.py:69-72) is merged into geometry feature 0 INSIDE the kernels:
+        # column 0 += ddens * min(dens, e^15) while the operand is staged (no 268 MB clone / strided add)
+        fa = None if ddens is None else _c(ddens)
+        fb = None if ddens is None else dens
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
         denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
         c_h, c_e = _r4(NG), _r4(NG) + _r4(H)
-        run_chain([seg(dgt, 0, NG)],
+        s0 = seg(dgt, 0, NG)
+        s0.fix_a, s0.fix_b = _p(fa), _p(fb)
+        run_chain([s0],
                   [layer(W1, None, 0, c_h, transposed=True, mask=h1, store=dpre0),
                    layer(W0, None, c_h, c_e, transposed=True, store=denc, store_lm=True)],
                   c_e + K0, N, enc)
-        dw1, db1 = wgrad(dgt, [seg(h1, 0, H)], H)
+        dw1, db1 = wgrad(dgt, [seg(h1, 0, H)], H, fix_a=fa, fix_b=fb)
         dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
         return denc, dw0, db0, dw1, db1
 
@@ -244,12 +248,13 @@ class _RgbHeadFn(torch.autograd.Function):
         a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
         c_x = _r4(H)               # [A1 | hray | geo] laid out exactly like torch.cat([x, input]) of mlp.py:42
-        c_a2 = c_x + _r4(K0)
-        c_o = c_a2 + _r4(H)
+        # A2 overwrites A1 in place: a <= 64-wide layer is one column group, so every input column has been
+        # consumed by the MFMAs before the epilogue writes.  The smaller row buffer buys more waves per CU.
+        c_o = c_x + _r4(K0)
         run_chain([seg(hr, c_x, Kh, row_div=S), seg(g, c_x + Kh, NG, ld=g.stride(0))],
                   [layer(W0, B0, c_x, 0, ACT_RELU, store=a1),
-                   layer(W1, B1, 0, c_a2, ACT_RELU, store=a2),
-                   layer(W2, B2, c_a2, c_o, ACT_SIGMOID, store=out)],
+                   layer(W1, B1, 0, 0, ACT_RELU, store=a2),
+                   layer(W2, B2, 0, c_o, ACT_SIGMOID, store=out)],
                   c_o + 4, N, g)
         ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
         ctx.S = S

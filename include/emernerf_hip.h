@@ -245,10 +245,11 @@ typedef struct emer_chain_desc {
 int emer_mlp_chain(const emer_chain_desc *host_desc, int64_t n_rows, void *stream);
 
 /* dW[N,K] += dpre[M,N]^T @ X[M,K], dbias[N] += colsum(dpre), with X given as up to EMER_CHAIN_MAX_SEGS
- * column segments (modes 0 and 1; a virtual concat).  workspace: emer_linear_bwd_workspace(m, n, k) floats. */
-int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const emer_chain_seg *host_segs, int32_t n_segs,
-                         float *workspace, float *dw, float *dbias, int64_t m, int32_t n, int32_t k,
-                         void *stream);
+ * column segments (modes 0 and 1; a virtual concat).  fix_a/fix_b (may be NULL): dpre[row][0] += fix_a[row] *
+ * min(fix_b[row], e^15) on the fly (density gradient merged into geometry feature 0).  workspace: emer_linear_bwd_workspace(m, n, k) floats. */
+int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const float *fix_a, const float *fix_b,
+                         const emer_chain_seg *host_segs, int32_t n_segs, float *workspace, float *dw,
+                         float *dbias, int64_t m, int32_t n, int32_t k, void *stream);
 
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */

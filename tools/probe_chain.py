@@ -34,3 +34,21 @@ macs = {"base_fwd_us": 32 * 64 + 64 * 64, "rgb_fwd_us": 113 * 64 + 177 * 64 + 64
 for k, m in macs.items():
     if k in res: res[k.replace("_us", "_TF")] = 2.0 * m * N / res[k] / 1e6
 print(json.dumps(res, indent=1))
+
+if which in ("all", "detail"):
+    # per-entry-point breakdown of one rgb-head backward and one base backward
+    from emernerf_amd import _lib as L_
+    import torch
+    hray, geo = P(R, 49), P(N, 64)
+    Ws = [P(64, 113, s=0.1), P(64, s=0.1), P(64, 177, s=0.08), P(64, s=0.1), P(3, 64, s=0.12), P(3, s=0.1)]
+    rgb = fused.rgb_head(hray, geo, S, *Ws); go = torch.randn_like(rgb)
+    enc, W0, b0, W1, b1 = P(16, N, 2), P(64, 32, s=0.2), P(64, s=0.1), P(64, 64, s=0.12), P(64, s=0.1)
+    f, dn = fused.base_mlp(enc, W0, b0, W1, b1); gf, gd = torch.randn_like(f), torch.randn_like(dn)
+    for _ in range(2):
+        rgb.backward(go, retain_graph=True); torch.autograd.backward([f, dn], [gf, gd], retain_graph=True)
+    for name, fn in (("rgb_bwd", lambda: rgb.backward(go, retain_graph=True)),
+                     ("base_bwd", lambda: torch.autograd.backward([f, dn], [gf, gd], retain_graph=True))):
+        t = L_.KernelTimer(["emer_mlp_chain", "emer_wgrad_segmented"]); L_.TIMER = t
+        torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); L_.TIMER = None
+        print(name, "total_us", round(e0.elapsed_time(e1) * 1e3), {k: [round(x) for x in v] for k, v in t.elapsed_us().items()})
