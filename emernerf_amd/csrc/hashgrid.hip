@@ -151,7 +151,16 @@ struct SlicePlan {
     uint32_t n_ranges[EMER_MAX_LEVELS];  // dense levels: the sample stream is also cut in ranges (2-D decomposition)
     uint32_t max_local;                  // largest slice (entries)
     uint32_t ok;                         // 0 when some level would need more than 64 slices
+    uint8_t xcd_of[EMER_MAX_LEVELS];     // backward: the XCD (0..7) that owns each level (cost-balanced)
+    uint32_t blocks_per_xcd;             // backward grid = 8 * blocks_per_xcd
 };
+
+static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
+    // fitted to tools/kbench.py --per-level on MI355X (1M samples, ms on one XCD): coarse levels pay for
+    // same-address LDS adds (many samples per cell), dense levels for the ordered scan + run reduction
+    if (g->hashed[l]) return 0.28f + 36.0f / (float)g->res[l];
+    return 0.22f + 0.13f * log2f(1.0f + (float)p.n_slices[l]);
+}
 
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     SlicePlan p;
@@ -168,10 +177,10 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             p.n_ranges[l] = 1;
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
-            // use as FEW slices as the LDS allows and cut the sample stream instead (~64 workgroups per level)
+            // use as FEW slices as the LDS allows and cut the sample stream instead (~128 workgroups per level)
             while ((1u << (k + 1)) <= max_entries && (1u << k) < size) ++k;
             const uint32_t ns = (uint32_t)ceil_div(size, 1ll << k);
-            uint32_t nr = 64u / (ns ? ns : 1u);
+            uint32_t nr = 128u / (ns ? ns : 1u);
             p.n_ranges[l] = nr < 1u ? 1u : nr;
         }
         p.shift[l] = k;
@@ -180,11 +189,56 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         if (local > max_entries || p.n_slices[l] > 64) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
     }
+    // Levels -> XCDs, longest-processing-time first.  A level stays on ONE XCD so that its streamed inputs
+    // (x, dout, bitmaps) are fetched into a single L2.  Relative costs measured on MI355X at 1M samples
+    // (tools/probe_bwd.py): hashed level ~1, dense levels between 0.4 and 1.9 growing with the slab count.
+    float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool placed[EMER_MAX_LEVELS] = {};
+    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.xcd_of[l] = 0xFF;
+    for (uint32_t it = 0; it < g->n_levels; ++it) {
+        int best = -1; float best_cost = -1.0f;
+        for (uint32_t l = 0; l < g->n_levels; ++l) {
+            if (placed[l]) continue;
+            const float c = level_cost(g, p, l);
+            if (c > best_cost) { best_cost = c; best = (int)l; }
+        }
+        int x = 0;
+        for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
+        placed[best] = true; p.xcd_of[best] = (uint8_t)x; load[x] += best_cost; nblk[x] += p.n_slices[best] * p.n_ranges[best];
+    }
+    p.blocks_per_xcd = 0;
+    for (int i = 0; i < 8; ++i) p.blocks_per_xcd = nblk[i] > p.blocks_per_xcd ? nblk[i] : p.blocks_per_xcd;
     return p;
 }
 
 __device__ __forceinline__ uint32_t slice_of(const SlicePlan &p, uint32_t level, uint32_t idx) {
     return idx >> p.shift[level];
+}
+
+
+// 64x64 bit-matrix transpose across the 64 lanes of a wave (lane r holds row r; afterwards lane c holds
+// column c): six butterfly stages, each swapping the off-diagonal blocks with lane ^ j.
+__device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x, int lane) {
+    const uint64_t lowmask[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                                 0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int j = 32 >> st;
+        const uint64_t lm = lowmask[st];
+        const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)x, j, kWave);
+        x = (lane & j) ? (((y & ~lm) >> j) | (x & ~lm)) : ((x & lm) | ((y & lm) << j));
+    }
+    return x;
+}
+
+// The owner-computes backward reads ONE bit per sample for each (level, slice).  A wave holding the 64-bit
+// slice masks of 64 consecutive samples transposes them, so lane s holds the membership bits of slice s,
+// and writes word (n0 / 64) of that slice's bitmap.  Layout: bitmaps[(level * 64 + s) * n_words + word].
+__device__ __forceinline__ void store_slice_bitmaps(uint64_t *__restrict__ bitmaps, uint64_t mask, uint32_t level, uint32_t n_slices,
+                                                    int64_t n0_wave, int64_t n_words, int lane) {
+    const uint64_t col = wave_bit_transpose(mask, lane);
+    if ((uint32_t)lane < n_slices && (n0_wave >> 6) < n_words) bitmaps[((int64_t)level * 64 + lane) * n_words + (n0_wave >> 6)] = col;
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -196,42 +250,48 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
     uint32_t level, chunk;
     if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
-    if (n >= N) return;
+    const bool valid = n < N;
+    if (!valid && !masks) return;
     const LevelInfo li = level_info(g, level);
     const PT *__restrict__ table = params + (size_t)li.offset * F;
 
-    float xv[D], w[D];
-    uint32_t gi[D];
-    load_x<D>(x, n, xv);
-    cell_of<D>(li, xv, gi, w);
-
-    float acc[F];
     uint64_t mask = 0;
+    if (valid) {
+        float xv[D], w[D];
+        uint32_t gi[D];
+        load_x<D>(x, n, xv);
+        cell_of<D>(li, xv, gi, w);
+
+        float acc[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+        for (int f = 0; f < F; ++f) acc[f] = 0.0f;
 #pragma unroll
-    for (uint32_t m = 0; m < (1u << D); ++m) {
-        float wt = 1.0f;
-        uint32_t c[D];
+        for (uint32_t m = 0; m < (1u << D); ++m) {
+            float wt = 1.0f;
+            uint32_t c[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
-            else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
+            for (int d = 0; d < D; ++d) {
+                if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
+                else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
+            }
+            float v[F];
+            const uint32_t idx = grid_index<D>(li, c);
+            load_feats<F, PT>(table + (size_t)idx * F, v);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
+            if (masks) mask |= 1ull << slice_of(plan, level, idx);  // by-product for the owner-computes backward
         }
-        float v[F];
-        const uint32_t idx = grid_index<D>(li, c);
-        load_feats<F, PT>(table + (size_t)idx * F, v);
+        float *o = out + n * sn + (int64_t)level * sl;
+        if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
+        else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
+        else {
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
-        if (masks) mask |= 1ull << slice_of(plan, level, idx);  // by-product for the owner-computes backward
+            for (int f = 0; f < F; ++f) o[f] = acc[f];
+        }
     }
-    if (masks) masks[(int64_t)level * N + n] = mask;
-    float *o = out + n * sn + (int64_t)level * sl;
-    if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
-    else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
-    else {
-#pragma unroll
-        for (int f = 0; f < F; ++f) o[f] = acc[f];
+    if (masks) {  // the whole wave takes part in the transpose (tail lanes carry an empty mask)
+        const int lane = threadIdx.x & 63;
+        store_slice_bitmaps(masks, mask, level, plan.n_slices[level], n - lane, (N + 63) >> 6, lane);
     }
 }
 
@@ -303,8 +363,8 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // Placement only affects speed, never results.
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
-constexpr int kSliceUnroll = 4;                       // masks per thread per loop trip (loads issued together)
-constexpr int kWaveQueue = 64 + 64 * kSliceUnroll;    // wave-private hit queue (sample ids)
+constexpr int kDrainK = 4;                            // hits per lane per drain (loads in flight)
+constexpr int kWaveQueue = 64 * kDrainK + 64;         // wave-private hit queue (sample ids): < 64*K left over + <= 64 pushed
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
 // they form RUNS that share one cell (and therefore all 2^D corner entries).  Values are reduced per run
@@ -330,12 +390,13 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                                                                                    const uint64_t *__restrict__ masks,
                                                                                    float *__restrict__ grad, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // XCD-aware work lookup: XCD xcd walks levels xcd, xcd+8, ... ; j-th block of that XCD
+    // XCD-aware work lookup: XCD xcd walks the levels assigned to it; j-th block of that XCD
     const uint32_t xcd = blockIdx.x & 7u;
     uint32_t j = blockIdx.x >> 3;
-    uint32_t level = xcd, slice = 0, range = 0;
+    uint32_t level = 0, slice = 0, range = 0;
     bool have = false;
-    for (; level < g.n_levels; level += 8u) {
+    for (; level < g.n_levels; ++level) {
+        if (plan.xcd_of[level] != xcd) continue;
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
         if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; have = true; break; }
         j -= nb;
@@ -343,14 +404,15 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     if (!have) return;
     const LevelInfo li = level_info(g, level);
     const bool dense = !li.hashed;
+    const bool pairable = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
     const uint32_t first = slice << shift;
     const uint32_t n_local = ((li.size - first) < (1u << shift)) ? (li.size - first) : (1u << shift);
-    // sample range of this workgroup (whole stream for hashed levels), aligned to the trip size
-    const int64_t trip = (int64_t)kSliceThreads * kSliceUnroll;
-    const int64_t per_range = ceil_div_dev(ceil_div_dev(N, (int64_t)n_ranges), trip) * trip;
-    const int64_t n_begin = (int64_t)range * per_range;
-    const int64_t n_end = (n_begin + per_range < N) ? n_begin + per_range : N;
+    // sample range of this workgroup (whole stream for hashed levels), in 64-sample bitmap words
+    const int64_t n_words = (N + 63) >> 6;
+    const int64_t words_per_range = ceil_div_dev(n_words, (int64_t)n_ranges);
+    const int64_t w_begin = (int64_t)range * words_per_range;
+    const int64_t w_end = (w_begin + words_per_range < n_words) ? w_begin + words_per_range : n_words;
 
     double *acc = smem;                                                                // [max_local * F] (ds_add_f64)
     uint32_t *queue = reinterpret_cast<uint32_t *>(smem + (size_t)plan.max_local * F); // [waves][kWaveQueue]
@@ -362,93 +424,152 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     __syncthreads();
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
-    const uint64_t *__restrict__ ml = masks + (int64_t)level * N;
-    const uint64_t my_bit = 1ull << slice;
+    const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + slice) * n_words;  // this slice: 1 bit per sample
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    for (int64_t base = n_begin; base < n_end + trip; base += trip) {
-        if (base < n_end) {
-            uint64_t mk[kSliceUnroll];
-#pragma unroll
-            for (int u = 0; u < kSliceUnroll; ++u) {  // all loads of the trip issued before any use
-                const int64_t n = base + u * kSliceThreads + threadIdx.x;
-                mk[u] = (n < n_end) ? ml[n] : 0ull;
+    // Every lane holds one 64-sample word of the bitmap; a trip of the workgroup covers 1024 words.  The next
+    // trip's word is loaded while the current one is consumed.
+    //   hashed levels: order is irrelevant -> all lanes peel the lowest set bit of their word together;
+    //   dense levels: the queue must stay in SAMPLE ORDER (runs of one ray share a cell, see run_reduce) ->
+    //                 the wave walks its non-empty words one at a time, lane i testing bit i.
+    int64_t wbase = w_begin;       // first word of the NEXT trip
+    int64_t wi = 0;                // this lane's current word index
+    uint64_t wv = 0;               // this lane's current word (remaining bits)
+    unsigned long long nz = 0;     // dense: lanes of this wave whose word is still to be walked
+    // word of a trip held by this lane: hashed = thread id; dense = interleaved over the waves so that short ranges
+    // still occupy all 16 waves (lane t of wave w holds word t * 16 + w; words of a wave stay in increasing order)
+    const int64_t my_word = dense ? (int64_t)lane * kSliceWaves + wave : (int64_t)threadIdx.x;
+    uint64_t pre = (wbase + my_word < w_end) ? bm[wbase + my_word] : 0ull;
+    bool done = false;
+    while (!done) {
+        const unsigned long long live = dense ? nz : __ballot(wv != 0ull);
+        if (!live) {
+            if (wbase < w_end) {
+                wv = pre; wi = wbase + my_word; wbase += kSliceThreads;
+                pre = (wbase + my_word < w_end) ? bm[wbase + my_word] : 0ull;
+                nz = __ballot(wv != 0ull);
+                continue;
             }
-#pragma unroll
-            for (int u = 0; u < kSliceUnroll; ++u) {
-                const bool hit = (mk[u] & my_bit) != 0ull;
-                const unsigned long long m = __ballot(hit);
-                if (hit) wq[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(base + u * kSliceThreads + threadIdx.x);
-                qn += (uint32_t)__popcll(m);  // wave-private push: prefix by popcount, no atomics, no barrier
-            }
+            done = true;
+        } else if (dense) {
+            const int t = __ffsll((long long)nz) - 1;
+            nz &= nz - 1ull;
+            const uint64_t wt = (uint64_t)__shfl((unsigned long long)wv, t, kWave);  // wave-uniform
+            const int64_t n0 = (wi + (int64_t)(t - lane) * kSliceWaves) << 6;
+            if ((wt >> lane) & 1ull) wq[qn + (uint32_t)__popcll(wt & lt_mask)] = (uint32_t)(n0 + lane);
+            qn += (uint32_t)__popcll(wt);
+        } else {
+            const bool hit = wv != 0ull;
+            if (hit) wq[qn + (uint32_t)__popcll(live & lt_mask)] = (uint32_t)((wi << 6) + (__ffsll((long long)wv) - 1));
+            wv &= wv - 1ull;
+            qn += (uint32_t)__popcll(live);  // wave-private push: prefix by popcount, no atomics, no barrier
         }
-        // single drain site: 64 queued hits at a time on dense lanes (the tail after the last trip drains the rest)
-        while (qn >= 64u || (base >= n_end && qn > 0u)) {
-            const uint32_t take = qn < 64u ? qn : 64u;
-            const bool valid = (uint32_t)lane < take;
-            const uint32_t n = wq[qn - take + (valid ? (uint32_t)lane : 0u)];
-            float xs[D], w[D], go[F];
-            uint32_t gi[D];
-            load_x<D>(x, (int64_t)n, xs);
-            if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; }
-            else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[0] = t.x; go[1 < F ? 1 : 0] = t.y; go[2 < F ? 2 : 0] = t.z; go[3 < F ? 3 : 0] = t.w; }
-            else {
+        // single drain site: kDrainK * 64 queued hits at a time on dense lanes (everything that is left once the
+        // scan is done).  The x / dout loads of all kDrainK groups are issued before any is consumed: a wave's
+        // drains form a serial latency chain, so the loads in flight per drain set the speed.
+        while (qn >= 64u * kDrainK || (done && qn > 0u)) {
+            const uint32_t take = qn < 64u * kDrainK ? qn : 64u * kDrainK;
+            const uint32_t qbase = qn - take;
+            float xs[kDrainK][D], go[kDrainK][F];
 #pragma unroll
-                for (int f = 0; f < F; ++f) go[f] = dl[(int64_t)n * sn + f];
-            }
-            cell_of<D>(li, xs, gi, w);
-            if (!valid) {
+            for (int k = 0; k < kDrainK; ++k) {
+                const uint32_t e = (uint32_t)(k * 64 + lane);
+                const uint32_t n = wq[qbase + (e < take ? e : 0u)];
+                load_x<D>(x, (int64_t)n, xs[k]);
+                if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
+                else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
+                else {
 #pragma unroll
-                for (int f = 0; f < F; ++f) go[f] = 0.0f;
-            }
-            if (dense) {
-                // ---- run-segmented reduction: lanes with the same cell as their predecessor join its run
-                uint32_t cell = 0, mul = 1;
-#pragma unroll
-                for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
-                if (!valid) cell = 0xFFFFFFFFu;
-                const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
-                const bool head = lane == 0 || cell != prev;
-                int run_start = head ? lane : 0;
-#pragma unroll
-                for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
-                    const int t = __shfl_up(run_start, off, kWave);
-                    if (lane >= off) run_start = run_start > t ? run_start : t;
+                    for (int f = 0; f < F; ++f) go[k][f] = dl[(int64_t)n * sn + f];
                 }
-                const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
-                const bool tail = valid && (lane == 63 || next_head);
+            }
 #pragma unroll
-                for (uint32_t m = 0; m < (1u << D); ++m) {
-                    uint32_t c[D];
-                    float wt = 1.0f;
+            for (int k = 0; k < kDrainK; ++k) {
+                if ((uint32_t)(k * 64) >= take) break;  // wave-uniform
+                const bool valid = (uint32_t)(k * 64 + lane) < take;
+                float w[D];
+                uint32_t gi[D];
+                cell_of<D>(li, xs[k], gi, w);
+                if (!valid) {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        c[d] = gi[d] + ((m >> d) & 1u);
-                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
-                    }
-                    float v[F];
-#pragma unroll
-                    for (int f = 0; f < F; ++f) v[f] = wt * go[f];
-                    run_reduce<F>(v, run_start, lane);
-                    const uint32_t idx = grid_index<D>(li, c);
-                    if (tail && (idx >> shift) == slice) {
-#pragma unroll
-                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
-                    }
+                    for (int f = 0; f < F; ++f) go[k][f] = 0.0f;
                 }
-            } else {
+                if (dense) {
+                    // ---- run-segmented reduction: lanes with the same cell as their predecessor join its run
+                    uint32_t cell = 0, mul = 1;
 #pragma unroll
-                for (uint32_t m = 0; m < (1u << D); ++m) {
-                    uint32_t c[D];
-                    float wt = 1.0f;
+                    for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
+                    if (!valid) cell = 0xFFFFFFFFu;
+                    const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
+                    const bool head = lane == 0 || cell != prev;
+                    int run_start = head ? lane : 0;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        c[d] = gi[d] + ((m >> d) & 1u);
-                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                    for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
+                        const int t = __shfl_up(run_start, off, kWave);
+                        if (lane >= off) run_start = run_start > t ? run_start : t;
                     }
-                    const uint32_t idx = grid_index<D>(li, c);
-                    if (valid && (idx >> shift) == slice) {
+                    const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
+                    const bool tail = valid && (lane == 63 || next_head);
 #pragma unroll
-                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)(wt * go[f]));  // ds_add_f64
+                    for (uint32_t m = 0; m < (1u << D); ++m) {
+                        uint32_t c[D];
+                        float wt = 1.0f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            c[d] = gi[d] + ((m >> d) & 1u);
+                            wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                        }
+                        float v[F];
+#pragma unroll
+                        for (int f = 0; f < F; ++f) v[f] = wt * go[k][f];
+                        run_reduce<F>(v, run_start, lane);
+                        const uint32_t idx = grid_index<D>(li, c);
+                        if (tail && (idx >> shift) == slice) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
+                        }
+                    }
+                } else if (pairable) {
+                    // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
+                    // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
+                    // slice -> one test per pair, and the hash of the other dimensions is computed once per pair
+                    const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+#pragma unroll
+                    for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+                        uint32_t h = 0;
+                        float wa = 1.0f - w[0], wb = w[0];  // same product order as the generic path: ((t0*t1)*t2)*t3
+#pragma unroll
+                        for (int d = 1; d < D; ++d) {
+                            const uint32_t bit = (m >> (d - 1)) & 1u;
+                            h ^= (gi[d] + bit) * primes[d];
+                            const float t = bit ? w[d] : 1.0f - w[d];
+                            wa *= t; wb *= t;
+                        }
+                        const uint32_t idx0 = (gi[0] ^ h) & (li.size - 1u);
+                        if (valid && (idx0 >> shift) == slice) {
+                            const uint32_t idx1 = ((gi[0] + 1u) ^ h) & (li.size - 1u);
+#pragma unroll
+                            for (int f = 0; f < F; ++f) {
+                                atomicAdd(acc + (size_t)(idx0 - first) * F + f, (double)(wa * go[k][f]));  // ds_add_f64
+                                atomicAdd(acc + (size_t)(idx1 - first) * F + f, (double)(wb * go[k][f]));
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t m = 0; m < (1u << D); ++m) {
+                        uint32_t c[D];
+                        float wt = 1.0f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            c[d] = gi[d] + ((m >> d) & 1u);
+                            wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                        }
+                        const uint32_t idx = grid_index<D>(li, c);
+                        if (valid && (idx >> shift) == slice) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)(wt * go[k][f]));  // ds_add_f64
+                        }
                     }
                 }
             }
@@ -469,7 +590,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     }
 }
 
-// Slice-membership masks for callers that did not get them from the forward pass.
+// Slice bitmaps for callers that did not get them from the forward pass.
 template <int D>
 __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_grid_desc g, const SlicePlan plan,
                                                                    const float *__restrict__ x, uint64_t *__restrict__ masks,
@@ -477,21 +598,23 @@ __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_gr
     uint32_t level, chunk;
     if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
-    if (n >= N) return;
     const LevelInfo li = level_info(g, level);
-    float xv[D], w[D];
-    uint32_t gi[D];
-    load_x<D>(x, n, xv);
-    cell_of<D>(li, xv, gi, w);
     uint64_t mask = 0;
+    if (n < N) {
+        float xv[D], w[D];
+        uint32_t gi[D];
+        load_x<D>(x, n, xv);
+        cell_of<D>(li, xv, gi, w);
 #pragma unroll
-    for (uint32_t m = 0; m < (1u << D); ++m) {
-        uint32_t c[D];
+        for (uint32_t m = 0; m < (1u << D); ++m) {
+            uint32_t c[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
-        mask |= 1ull << slice_of(plan, level, grid_index<D>(li, c));
+            for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
+            mask |= 1ull << slice_of(plan, level, grid_index<D>(li, c));
+        }
     }
-    masks[(int64_t)level * N + n] = mask;
+    const int lane = threadIdx.x & 63;
+    store_slice_bitmaps(masks, mask, level, plan.n_slices[level], n - lane, (N + 63) >> 6, lane);
 }
 
 // ------------------------------------------------------------------------- backward (input)
@@ -622,13 +745,13 @@ extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x,
 }
 
 
-// 1 if the owner-computes backward supports this grid (every level fits <= 32 LDS slices), else 0.
+// 1 if the owner-computes backward supports this grid (every level fits <= 64 LDS slices), else 0.
 extern "C" int emer_hashgrid_sliced_supported(const emer_grid_desc *g) {
     if (check_desc(g)) return 0;
     return make_slice_plan(g).ok ? 1 : 0;
 }
 
-// Slice-membership masks [L][N] (u32) for emer_hashgrid_bwd_params_sliced when the forward did not emit them.
+// Slice bitmaps [L][64][ceil(N/64)] (u64) for emer_hashgrid_bwd_params_sliced when the forward did not emit them.
 extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x, uint64_t *slice_masks, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
     EMER_REQUIRE(n >= 0, "hashgrid_slice_masks: negative n");
@@ -647,7 +770,7 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
 }
 
 // Owner-computes variant: OVERWRITES grad (f32) -- every entry of every level is written exactly
-// once, so the caller does not zero the buffer.  slice_masks [L][N] come from emer_hashgrid_fwd (or
+// once, so the caller does not zero the buffer.  The slice bitmaps come from emer_hashgrid_fwd (or
 // emer_hashgrid_slice_masks) for the SAME x.
 extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
                                                int64_t sl, const uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
@@ -657,15 +780,13 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     const uint32_t F = g->n_features;
     const SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 LDS slices; use emer_hashgrid_bwd_params");
-    uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, max_blocks = 0;
+    const uint32_t max_blocks = plan.blocks_per_xcd;
     for (uint32_t l = 0; l < g->n_levels; ++l) {
-        per_xcd[l & 7u] += plan.n_slices[l] * plan.n_ranges[l];
         if (plan.n_ranges[l] > 1u) {  // levels merged with atomics start from zero (async memset node on the same stream)
             hipError_t e = hipMemsetAsync(grad + (size_t)g->offset[l] * F, 0, (size_t)g->size[l] * F * sizeof(float), as_stream(stream));
             if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
         }
     }
-    for (int i = 0; i < 8; ++i) max_blocks = per_xcd[i] > max_blocks ? per_xcd[i] : max_blocks;
     const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kWaveQueue * sizeof(uint32_t);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;

@@ -74,8 +74,9 @@ int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_l
  * out element (n, l, f) is written at out[n*out_stride_n + l*out_stride_l + f] (f32):
  *   row-major [N, L*F] (the reference's layout): stride_n = L*F, stride_l = F;
  *   level-major [L][N][F] (coalesced, what the fused heads read): stride_n = F, stride_l = N*F.
- * slice_masks (may be NULL): [L][N] u64 by-product consumed by emer_hashgrid_bwd_params_sliced
- *   (bit s of (l, n) set iff a corner of sample n lives in LDS slice s of level l).
+ * slice_masks (may be NULL): [L][64][ceil(N/64)] u64 by-product consumed by emer_hashgrid_bwd_params_sliced:
+ *   one bitmap per (level l, LDS slice s); bit (n % 64) of word n/64 is set iff a corner of sample n
+ *   lives in slice s of level l.
  * Replaces native.fwd (tcnn_modules.py:122). */
 int emer_hashgrid_fwd(const emer_grid_desc *host_desc, const float *x, const void *params,
                       int param_dtype, float *out, int64_t out_stride_n, int64_t out_stride_l,
@@ -90,8 +91,8 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
 
 /* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
  * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice (accumulated in double) and
- * streams the per-sample slice masks ("owner computes"; see csrc/hashgrid.hip).  The training path.
- * slice_masks [L][N]: from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
+ * streams its 1-bit-per-sample slice bitmap ("owner computes"; see csrc/hashgrid.hip).  The training path.
+ * slice_masks [L][64][ceil(N/64)]: from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
 int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
                                     const float *dout, int64_t dout_stride_n,
                                     int64_t dout_stride_l, const uint64_t *slice_masks,
