@@ -74,6 +74,23 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 6):
                       f"threads + OpenMP; {dt:.1f} s"}
 
 
+def pmc_traffic(dominant: str, D: int, F: int, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE
+    need separate profiler passes, tools/profile_round.sh, so they cannot be collected inside this process).  Only
+    valid for the default workload the summary was recorded on; null otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+    if not os.path.exists(path) or (args.rays, args.samples, args.kind) != (8192, 128, "static"):
+        return None, None
+    try:
+        j = json.load(open(path))
+        kern = {"emer_hashgrid_bwd_params_sliced": f"hashgrid_bwd_params_sliced_kernel<{D}, {F}>",
+                "emer_hashgrid_fwd": f"hashgrid_fwd_kernel<{D}, {F}, float>"}[dominant]
+        return j["kernels"][kern]["hbm_bytes"], ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
+                                                 f"of this command, reads x{j['read_correction']:.2f} (gfx950 correction, calibrated)")
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,11 +138,15 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(data)
 
-    timed = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params", "emer_hashgrid_bwd_input",
-             "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose", "emer_render_weights_fwd", "emer_render_weights_bwd",
-             "emer_accumulate_fwd", "emer_accumulate_bwd", "emer_importance_sample", "emer_ray_points", "emer_adam_step",
-             "emer_dir_encode", "emer_contract_fwd", "emer_mlp_chain", "emer_wgrad_segmented"]
-    timer = _lib.KernelTimer(timed) if rank == 0 else None
+    # HIP events inside the timed region only around the roofline kernels (the grid encode + its backward: five
+    # launches per step).  Timing every entry point costs ~1.4 ms/step in event records, so the full per-kernel
+    # breakdown comes from a second, separately instrumented pass after the timed region.
+    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params"]
+    all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
+                              "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
+                              "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
+                              "emer_mlp_chain", "emer_wgrad_segmented"]
+    timer = _lib.KernelTimer(grid_names) if rank == 0 else None
     _lib.TIMER = timer
 
     if world > 1:
@@ -144,6 +165,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    breakdown, breakdown_steps = None, min(args.steps, 12)
+    if rank == 0:  # untimed: per-kernel breakdown with every entry point instrumented
+        breakdown = _lib.KernelTimer(all_names)
+        _lib.TIMER = breakdown
+        for _ in range(breakdown_steps):
+            trainer.train_step(data)
+        torch.cuda.synchronize()
+        _lib.TIMER = None
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         N = args.rays * args.samples
         c = trainer.cfg.xyz_encoder
@@ -158,12 +190,14 @@ def main():
         f_us, b_us = main_grid("emer_hashgrid_fwd"), main_grid("emer_hashgrid_bwd_params_sliced")
         f_avg = sum(f_us) / max(len(f_us), 1)
         b_avg = sum(b_us) / max(len(b_us), 1)
-        per_kernel = {n: {"launches": len(v), "total_ms": sum(v) / 1e3, "avg_us": (sum(v) / len(v)) if v else 0.0}
-                      for n, v in us.items() if v}
+        per_kernel = {n: {"launches_per_step": len(v) / breakdown_steps, "ms_per_step": sum(v) / 1e3 / breakdown_steps,
+                          "avg_us": (sum(v) / len(v)) if v else 0.0}
+                      for n, v in breakdown.elapsed_us().items() if v}
         dominant = "emer_hashgrid_bwd_params_sliced" if b_avg >= f_avg else "emer_hashgrid_fwd"
         dom_us, dom_bytes = (b_avg, bwd_b * N) if dominant.endswith("sliced") else (f_avg, fwd_b * N)
         ach = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         both = (fwd_b + bwd_b) * N / ((f_avg + b_avg) * 1e-6) / 1e9 if (f_avg + b_avg) > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dominant, D, F, args)
         out = {
             "metric": "train rays/sec (8192-ray batch, 128 samples)",
             "value": world * args.rays * args.steps / elapsed,
@@ -185,10 +219,12 @@ def main():
                        "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
                        "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
             "kernels": per_kernel,
+            "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "
+                            "timed region; the roofline kernels are timed with HIP events inside the timed region itself",
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -239,15 +239,37 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict_
     if (want_bias && blockIdx.y == 0 && wave == 0 && lane < NG && n_base + lane < N) part[(int64_t)N * K + n_base + lane] = bsum;
 }
 
-// dw[i] += sum_b partials[b][i]  (i < N*K),  dbias[i - N*K] += ...  (i >= N*K)
+// dw[i] += sum_b partials[b][i]  (i < N*K),  dbias[i - N*K] += ...  (i >= N*K).
+// The partial blocks are cut into gridDim.y ranges so that the (small) N*K + N extent still fills the chip; each
+// thread sums its range with four independent accumulators (loads in flight) and merges with one f32 atomic.
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float *__restrict__ partials, int32_t n_blocks, int64_t stride,
                                                                int64_t nk, float *__restrict__ dw, float *__restrict__ dbias) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= stride) return;
-    float a = 0.0f;
-    for (int32_t b = 0; b < n_blocks; ++b) a += partials[(int64_t)b * stride + i];
-    if (i < nk) dw[i] += a;
-    else if (dbias) dbias[i - nk] += a;
+    const int32_t per = (n_blocks + (int32_t)gridDim.y - 1) / (int32_t)gridDim.y;
+    const int32_t b0 = (int32_t)blockIdx.y * per;
+    const int32_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const float *__restrict__ p = partials + i;
+    int32_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        a0 += p[(int64_t)b * stride];
+        a1 += p[(int64_t)(b + 1) * stride];
+        a2 += p[(int64_t)(b + 2) * stride];
+        a3 += p[(int64_t)(b + 3) * stride];
+    }
+    for (; b < b1; ++b) a0 += p[(int64_t)b * stride];
+    const float a = (a0 + a1) + (a2 + a3);
+    if (b0 >= b1) return;
+    if (i < nk) __hip_atomic_fetch_add(dw + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (dbias) __hip_atomic_fetch_add(dbias + (i - nk), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static inline uint32_t dw_reduce_splits(int32_t n_blocks, int64_t stride) {
+    // ~2048 workgroups in total, at least 8 partial blocks per range
+    int64_t s = 2048 / ((stride + 255) / 256);
+    if (s > n_blocks / 8) s = n_blocks / 8;
+    return (uint32_t)(s < 1 ? 1 : s);
 }
 
 constexpr int32_t kDwRowsPerBlock = 1024;
@@ -319,7 +341,7 @@ extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, in
 #undef EMER_DW
         if (int rc = check_launch("linear_dw")) return rc;
         const int64_t stride = (int64_t)n * k + n;
-        hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256)), dim3(256), 0, st, workspace, n_row_blocks,
+        hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st, workspace, n_row_blocks,
                            stride, (int64_t)n * k, dw, dbias);
         if (int rc = check_launch("linear_dw_reduce")) return rc;
     }
@@ -708,7 +730,7 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
 #undef EMER_WG
     if (int rc = check_launch("wgrad_segmented")) return rc;
     const int64_t stride = (int64_t)n * k + n;
-    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256)), dim3(256), 0, st, workspace, n_row_blocks, stride,
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st, workspace, n_row_blocks, stride,
                        (int64_t)n * k, dw, dbias);
     return check_launch("wgrad_reduce");
 }
