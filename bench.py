@@ -145,7 +145,7 @@ def main():
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
-                              "emer_mlp_chain", "emer_wgrad_segmented"]
+                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_rgb_head_fwd", "emer_rgb_head_bwd"]
     timer = _lib.KernelTimer(grid_names) if rank == 0 else None
     _lib.TIMER = timer
 

@@ -7,8 +7,12 @@ Three autograd Functions cover the hot heads of the reference:
   * ``rgb_head``     -- mlp.MLP(3 layers, skip at layer 1) + sigmoid on [dir-PE | appearance emb | geo]
                         (radiance_field.py:130-143,622-658); the per-ray part stays per ray, nothing is concatenated;
   * ``density_mlp``  -- proposal net Linear(K0,H) ReLU Linear(H,1) trunc_exp (radiance_field.py:808-812,836-840).
-Activations never leave LDS inside a chain; what the backward needs (post-ReLU hidden activations) is written
+Activations never leave the CU inside a chain; what the backward needs (post-ReLU hidden activations) is written
 once by the forward and read once as relu' masks / wgrad operands.
+
+Two implementations sit behind each Function: the register-resident kernels of csrc/mlp_fused.hip (hidden width 64,
+the shapes every shipped config uses: ``emer_neck_*``, ``emer_rgb_head_*``) and the generic LDS-staged
+``emer_mlp_chain`` for any other width.  Both are HIP; there is no torch fallback.
 """
 from __future__ import annotations
 
@@ -184,6 +188,78 @@ def base_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> 
     return _BaseMLPFn.apply(enc_lm, w0, b0, w1, b1)
 
 
+
+# ------------------------------------------------------------------------------- neck (register-resident)
+def neck_supported(n_levels: int, n_feat: int, hidden: int, n_out: int) -> bool:
+    return bool(_lib.load().emer_neck_supported(n_levels, n_feat, hidden, n_out))
+
+
+def _neck_fwd(enc: Tensor, W0, B0, W1, B1, n_out: int, want_h: bool):
+    L, N, F = enc.shape
+    dev = enc.device
+    h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if want_h else None
+    out0 = torch.empty((N, 64), device=dev, dtype=torch.float32) if n_out > 1 else None
+    out1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if n_out == 128 else None
+    dens = torch.empty((N,), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.call("emer_neck_fwd", _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), _p(B1), n_out, _p(h1), _p(out0), _p(out1), _p(dens),
+                  _stream(enc))
+    return h1, out0, out1, dens
+
+
+class _NeckFn(torch.autograd.Function):
+    """(features 0..63, features 64..127 or None, density) = neck(enc_lm); density = trunc_exp(feature 0 - 1)."""
+
+    @staticmethod
+    def forward(ctx, enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+        ctx.set_materialize_grads(False)
+        enc, W0, B0, W1, B1 = _c(enc_lm), _c(w0), _c(b0), _c(w1), _c(b1)
+        n_out = W1.shape[0]
+        h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, any(ctx.needs_input_grad))
+        ctx.save_for_backward(enc, W0, W1, h1, dens)
+        ctx.n_out = n_out
+        if out1 is None:
+            return out0, dens
+        return out0, out1, dens
+
+    @staticmethod
+    def backward(ctx, *grads):
+        enc, W0, W1, h1, dens = ctx.saved_tensors
+        n_out = ctx.n_out
+        d0, d1, ddens = (grads[0], None, grads[1]) if n_out == 64 else grads
+        if d0 is None and d1 is None and ddens is None:
+            return None, None, None, None, None
+        L, N, F = enc.shape
+        dev = enc.device
+        d0c = None if d0 is None else _c(d0)
+        d1c = None if d1 is None else _c(d1)
+        fa = None if ddens is None else _c(ddens)
+        dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
+        denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("emer_neck_bwd", _p(d0c), _p(d1c), _p(fa), _p(dens), _p(h1), L, F, N, _p(W0), _p(W1), n_out, None, _p(dpre0),
+                      _p(denc), _stream(enc))
+        # weight gradients.  Output rows whose gradient is structurally zero (an unused semantic half) cost nothing.
+        if d0c is None:
+            d0c = torch.zeros((N, 64), device=dev, dtype=torch.float32)
+        dw1, db1 = wgrad(d0c, [seg(h1, 0, 64)], 64, fix_a=fa, fix_b=None if fa is None else dens)
+        if n_out == 128:
+            if d1c is not None:
+                dw1b, db1b = wgrad(d1c, [seg(h1, 0, 64)], 64)
+            else:
+                dw1b, db1b = torch.zeros_like(dw1), torch.zeros_like(db1)
+            dw1, db1 = torch.cat([dw1, dw1b], 0), torch.cat([db1, db1b], 0)
+        dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], L * F)
+        return denc, dw0, db0, dw1, db1
+
+
+def neck(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+    """Register-resident neck: returns (feats[:, :64], feats[:, 64:128] or None, density [N]).  Requires
+    ``neck_supported(L, F, hidden, n_out)`` with n_out in (64, 128)."""
+    r = _NeckFn.apply(enc_lm, w0, b0, w1, b1)
+    return (r[0], None, r[1]) if len(r) == 2 else r
+
+
 # -------------------------------------------------------------------------------------- density MLP
 class _DensityMLPFn(torch.autograd.Function):
     @staticmethod
@@ -194,6 +270,11 @@ class _DensityMLPFn(torch.autograd.Function):
         K0, H = L * F, W0.shape[0]
         dev = enc.device
         need_grad = any(ctx.needs_input_grad)
+        ctx.fast = neck_supported(L, F, H, 1)
+        if ctx.fast:
+            h, _, _, dens = _neck_fwd(enc, W0, B0, W1, B1, 1, need_grad)
+            ctx.save_for_backward(enc, W0, W1, h, dens)
+            return dens
         h = torch.empty((N, H), device=dev, dtype=torch.float32) if need_grad else None
         dens = torch.empty((N, 1), device=dev, dtype=torch.float32)
         c_h = _r4(K0)
@@ -212,7 +293,17 @@ class _DensityMLPFn(torch.autograd.Function):
         L, N, F = enc.shape
         K0, H = L * F, W0.shape[0]
         dev = enc.device
-        dpre1 = (_c(ddens).view(N, 1) * dens.clamp(max=E15)).contiguous()
+        if ctx.fast:
+            dpre1 = torch.empty((N, 1), device=dev, dtype=torch.float32)
+            dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+            denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_neck_bwd", None, None, _p(_c(ddens)), _p(dens), _p(h), L, F, N, _p(W0), _p(W1), 1, _p(dpre1),
+                          _p(dpre0), _p(denc), _stream(enc))
+            dw1, db1 = wgrad(dpre1, [seg(h, 0, H)], H)
+            dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
+            return denc, dw0, db0, dw1, db1
+        dpre1 = (_c(ddens).view(N, 1) * dens.view(N, 1).clamp(max=E15)).contiguous()
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
         denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
         c_h, c_e = 4, 4 + _r4(H)
@@ -247,6 +338,17 @@ class _RgbHeadFn(torch.autograd.Function):
         a1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
+        ctx.S = S
+        ctx.fast = (H == 64 and NG == 64 and C == 3 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
+        if ctx.fast:
+            # per-ray part of layers 0 and 1 as per-ray pre-activations (8192-row GEMMs instead of 1M-row ones)
+            rb0 = torch.addmm(B0, hr, W0[:, :Kh].t())
+            rb1 = torch.addmm(B1, hr, W1[:, H:H + Kh].t())
+            with torch.cuda.device(dev):
+                _lib.call("emer_rgb_head_fwd", _p(g), g.stride(0), _p(rb0), _p(rb1), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(B2),
+                          _p(a1), _p(a2), _p(out), _stream(g))
+            ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
+            return out
         c_x = _r4(H)               # [A1 | hray | geo] laid out exactly like torch.cat([x, input]) of mlp.py:42
         # A2 overwrites A1 in place: a <= 64-wide layer is one column group, so every input column has been
         # consumed by the MFMAs before the epilogue writes.  The smaller row buffer buys more waves per CU.
@@ -257,7 +359,6 @@ class _RgbHeadFn(torch.autograd.Function):
                    layer(W2, B2, 0, c_o, ACT_SIGMOID, store=out)],
                   c_o + 4, N, g)
         ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
-        ctx.S = S
         return out
 
     @staticmethod
@@ -271,6 +372,24 @@ class _RgbHeadFn(torch.autograd.Function):
         H, K0, C = W0.shape[0], Kh + NG, W2.shape[0]
         assert H == _r4(H)
         dev = g.device
+        if ctx.fast:
+            dpre2 = torch.empty((N, C), device=dev, dtype=torch.float32)
+            dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+            dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+            dgeo = torch.empty((N, NG), device=dev, dtype=torch.float32)
+            s1 = torch.empty((R, H), device=dev, dtype=torch.float32)
+            s0 = torch.empty((R, H), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_rgb_head_bwd", _p(_c(dout)), _p(out), _p(a1), _p(a2), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(dpre2),
+                          _p(dpre1), _p(dpre0), _p(dgeo), _p(s1), _p(s0), _stream(g))
+            dw2, db2 = wgrad(dpre2, [seg(a2, 0, H)], H)
+            dw1ag, _ = wgrad(dpre1, [seg(a1, 0, H), seg(g, H, NG, ld=g.stride(0))], H + NG, want_bias=False)
+            dw0g, _ = wgrad(dpre0, [seg(g, 0, NG, ld=g.stride(0))], NG, want_bias=False)
+            # everything that multiplies the per-ray operand comes from the per-ray sums of dpre1 / dpre0
+            dw1 = torch.cat([dw1ag[:, :H], s1.t() @ hr, dw1ag[:, H:]], 1)
+            dw0 = torch.cat([s0.t() @ hr, dw0g], 1)
+            dhray = torch.addmm(s1 @ W1[:, H:H + Kh], s0, W0[:, :Kh])
+            return dhray, dgeo, None, dw0, s0.sum(0), dw1, s1.sum(0), dw2, db2
         dpre2 = (_c(dout) * out * (1.0 - out)).contiguous()            # sigmoid'
         dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)

@@ -227,10 +227,29 @@ class RadianceField(nn.Module):
         enc_lm = encoder.tcnn_encoding.forward_level_major(x)
         return fused.base_mlp(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
 
+    def _base_split(self, encoder: HashEncoder, mlp: nn.Sequential, x: Tensor):
+        """(geo feats, semantic feats or None, density) of the neck.  With the shipped widths (hidden 64, geometry and
+        semantic features 64 each) this is the register-resident kernel, which writes the two halves as separate
+        [N, 64] tensors -- the split of :400 costs nothing and an unused semantic half gets no backward work."""
+        enc = encoder.tcnn_encoding
+        n_out = mlp[2].out_features
+        if (self.geometry_feature_dim == 64 and n_out in (64, 128) and n_out == 64 + self.semantic_feature_dim
+                and fused.neck_supported(enc.desc.n_levels, enc.desc.n_features, mlp[0].out_features, n_out)):
+            enc_lm = enc.forward_level_major(x)
+            return fused.neck(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+        feats, density = self._base(encoder, mlp, x)
+        geo, sem = torch.split(feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
+        return geo, sem, density
+
     def _static_from_normed(self, normed_positions: Tensor):
         feats, density = self._base(self.xyz_encoder, self.base_mlp, normed_positions.reshape(-1, self.num_dims))
         lead = normed_positions.shape[:-1]
         return feats.view(*lead, -1), density.view(*lead)
+
+    def _static_split(self, normed_positions: Tensor):
+        geo, sem, density = self._base_split(self.xyz_encoder, self.base_mlp, normed_positions.reshape(-1, self.num_dims))
+        lead = normed_positions.shape[:-1]
+        return geo.view(*lead, -1), (None if sem is None else sem.view(*lead, -1)), density.view(*lead)
 
     def forward_static_hash(self, positions: Tensor) -> Tuple[Tensor, Tensor]:
         """:302-318.  Returns (encoded_features, normed_positions)."""
@@ -246,9 +265,10 @@ class RadianceField(nn.Module):
         temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
         lead = temporal_positions.shape[:-1]
         if not want_hash:
-            feats, density = self._base(self.dynamic_xyz_encoder, self.dynamic_base_mlp,
-                                        temporal_positions.reshape(-1, self.num_dims + 1))
-            return feats.view(*lead, -1), None, (density.view(*lead) if want_density else None)
+            geo, sem, density = self._base_split(self.dynamic_xyz_encoder, self.dynamic_base_mlp,
+                                                 temporal_positions.reshape(-1, self.num_dims + 1))
+            feats = (geo.view(*lead, -1), None if sem is None else sem.view(*lead, -1))  # already split (see _base_split)
+            return feats, None, (density.view(*lead) if want_density else None)
         enc = self.dynamic_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
         if want_density:
             feats, density = _run_sequential(self.dynamic_base_mlp, enc, density_from_col0=True)
@@ -396,8 +416,7 @@ class RadianceField(nn.Module):
                 query_feature_head: bool = True, query_pe_head: bool = True) -> Dict[str, Tensor]:
         results_dict = {}
         normed_positions = self.contract_points(positions)
-        encoded_features, static_density = self._static_from_normed(normed_positions)
-        geo_feats, semantic_feats = torch.split(encoded_features, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
+        geo_feats, semantic_feats, static_density = self._static_split(normed_positions)
 
         has_timestamps = "normed_timestamps" in data_dict or "lidar_normed_timestamps" in data_dict
         dynamic = self.dynamic_xyz_encoder is not None and has_timestamps
@@ -417,8 +436,11 @@ class RadianceField(nn.Module):
                 agg["current_dynamic_hash_encodings"] = dynamic_hash_encodings
                 results_dict.update(agg)
                 dynamic_density = ops.trunc_exp_column(dynamic_feats, 0)
-            dynamic_geo_feats, dynamic_semantic_feats = torch.split(
-                dynamic_feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
+            if isinstance(dynamic_feats, tuple):
+                dynamic_geo_feats, dynamic_semantic_feats = dynamic_feats
+            else:
+                dynamic_geo_feats, dynamic_semantic_feats = torch.split(
+                    dynamic_feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
             density = static_density + dynamic_density
             results_dict.update({"density": density, "static_density": static_density, "dynamic_density": dynamic_density})
             if return_density_only:

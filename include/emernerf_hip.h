@@ -252,6 +252,47 @@ int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const float *fix_a,
                          const emer_chain_seg *host_segs, int32_t n_segs, float *workspace, float *dw,
                          float *dbias, int64_t m, int32_t n, int32_t k, void *stream);
 
+/* ---- register-resident fused heads (hidden width 64; csrc/mlp_fused.hip) ------------------------------
+ * The per-sample hot heads of RadianceField / DensityField as single kernels in which a wave keeps its 16 rows
+ * in registers across all layers (fp32 MFMA, "transposed chaining").  Callers fall back to emer_mlp_chain for
+ * shapes these do not cover (emer_neck_supported == 0).
+ *
+ * Neck: base_mlp = Sequential(Linear(L*F, 64), ReLU, Linear(64, n_out)) fed by the LEVEL-MAJOR grid encoding
+ * enc_lm [L][n][F] (radiance_field.py:74-80,89-96,302-318; DensityField :808-812,836-840).
+ *   n_out 64 / 128: out0 [n][64] = features 0..63, out1 [n][64] = features 64..127 (the reference's
+ *     geo / semantic split, :400), dens [n] = exp(feature0 - 1) (trunc_exp, :28,315) when non-NULL;
+ *   n_out 1: dens [n] = exp(out - 1) only (proposal network).
+ *   h1 [n][64] receives the post-ReLU hidden activations (saved for the backward; may be NULL). */
+int emer_neck_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out);
+int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t n, const float *w0,
+                  const float *b0, const float *w1, const float *b1, int32_t n_out, float *h1,
+                  float *out0, float *out1, float *dens, void *stream);
+/* Data gradients of emer_neck_fwd.  d0 / d1 [n][64]: gradients of features 0..63 / 64..127 (NULL = zero);
+ * ddens [n] (NULL = none) enters feature 0 as ddens * min(dens, e^15) (nerf_utils.py:69-72).
+ * Writes dpre0 [n][64] (gradient at the hidden pre-activation, the wgrad operand), denc_lm [L][n][F] and,
+ * for n_out == 1, dpre1 [n] (gradient at the single output's pre-activation). */
+int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const float *dens, const float *h1,
+                  int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1,
+                  int32_t n_out, float *dpre1, float *dpre0, float *denc_lm, void *stream);
+
+/* rgb head: mlp.MLP(in = kh + 64, hidden 64, 3 layers, skip connection at layer 1) + sigmoid
+ * (radiance_field.py:130-143,622-658, mlp.py:20-46) on input [hray[ray] | geo[sample]], where hray
+ * (dir-PE | appearance embedding, kh columns) is constant along a ray.  The per-ray part arrives as
+ * pre-activations rb0 = hray W0[:, :kh]^T + b0 and rb1 = hray W1[:, 64:64+kh]^T + b1 ([rays][64]); the kernel
+ * does the per-sample part: a1 = relu(geo W0[:, kh:]^T + rb0), a2 = relu(a1 W1[:, :64]^T + geo W1[:, 64+kh:]^T
+ * + rb1), out = sigmoid(a2 W2^T + b2).  w0 [64][kh+64], w1 [64][64+kh+64], w2 [3][64] are the torch Linear
+ * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward. */
+int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t n_rays,
+                      int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
+                      const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);
+/* Data gradients: dpre2 [n][3] = dout * out * (1 - out), dpre1 / dpre0 [n][64] (pre-activation gradients of
+ * layers 1 / 0, the wgrad operands), dgeo [n][64], and s1 / s0 [rays][64] = sums of dpre1 / dpre0 over the
+ * samples of each ray (all that hray, W0[:, :kh], W1[:, 64:64+kh], b0 and b1 need). */
+int emer_rgb_head_bwd(const float *dout, const float *out, const float *a1, const float *a2, int64_t n_rays,
+                      int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
+                      const float *w2, float *dpre2, float *dpre1, float *dpre0, float *dgeo, float *s1,
+                      float *s0, void *stream);
+
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */
 int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, void *stream);

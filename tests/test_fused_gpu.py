@@ -1,4 +1,5 @@
-"""Fused MLP chains (emer_mlp_chain / emer_wgrad_segmented) vs fp64 torch references of the reference's heads."""
+"""Fused heads (register-resident emer_neck_* / emer_rgb_head_*, generic emer_mlp_chain, emer_wgrad_segmented) vs fp64
+torch references of the reference's heads."""
 import numpy as np
 import pytest
 import torch
@@ -39,6 +40,42 @@ def test_base_mlp(hip_lib, L, Fe, NG, N):
     _, dens2 = fused.base_mlp(*t2)
     dens2.sum().backward()
     assert t2[1].grad is not None and torch.isfinite(t2[0].grad).all()
+
+
+@pytest.mark.parametrize("L,Fe,NG,N,which", [(16, 2, 128, 1000, "all"), (16, 2, 128, 2048, "geo"), (10, 4, 128, 777, "all"),
+                                              (4, 2, 64, 16, "all"), (8, 1, 64, 33, "dens"), (3, 8, 64, 100, "all"),
+                                              (16, 4, 128, 50, "sem")])
+def test_neck_register_resident(hip_lib, L, Fe, NG, N, which):
+    """emer_neck_fwd / emer_neck_bwd: split outputs, ragged row counts, every combination of live output gradients."""
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    assert fused.neck_supported(L, Fe, 64, NG)
+    g = torch.Generator().manual_seed(L * 7 + NG + N)
+    K0, H = L * Fe, 64
+    enc = torch.randn(L, N, Fe, generator=g)
+    W0, b0 = torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g) * 0.1
+    W1, b1 = torch.randn(NG, H, generator=g) / H ** 0.5, torch.randn(NG, generator=g) * 0.1
+    t = [v.to(dev).requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    geo, sem, dens = fused.neck(*t)
+    r = [v.double().requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
+    x = r[0].permute(1, 0, 2).reshape(N, K0)
+    f_ref = F.linear(torch.relu(F.linear(x, r[1], r[2])), r[3], r[4])
+    d_ref = torch.exp(f_ref[:, 0] - 1)
+    _close("geo", geo, f_ref[:, :64]); _close("density", dens, d_ref)
+    assert (sem is None) == (NG == 64)
+    if sem is not None:
+        _close("sem", sem, f_ref[:, 64:])
+    gg, gs, gd = torch.randn(N, 64, generator=g), torch.randn(N, 64, generator=g), torch.randn(N, generator=g)
+    loss, loss_ref = 0.0, 0.0
+    if which in ("all", "geo"):
+        loss, loss_ref = loss + (geo * gg.to(dev)).sum(), loss_ref + (f_ref[:, :64] * gg.double()).sum()
+    if which in ("all", "sem") and sem is not None:
+        loss, loss_ref = loss + (sem * gs.to(dev)).sum(), loss_ref + (f_ref[:, 64:] * gs.double()).sum()
+    if which in ("all", "dens"):
+        loss, loss_ref = loss + (dens * gd.to(dev)).sum(), loss_ref + (d_ref * gd.double()).sum()
+    loss.backward(); loss_ref.backward()
+    for name, a, b in zip(("denc", "dW0", "db0", "dW1", "db1"), t, r):
+        _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
 @pytest.mark.parametrize("L,N", [(8, 1000), (8, 17), (4, 256)])
