@@ -273,6 +273,15 @@ static inline uint32_t dw_reduce_splits(int32_t n_blocks, int64_t stride) {
 }
 
 constexpr int32_t kDwRowsPerBlock = 1024;
+// rows per workgroup of the dW kernels: 1024 for the per-sample heads (1M rows -> 1024 workgroups), but never fewer
+// than ~512 workgroups' worth of parallelism for per-ray heads (8192 rows would otherwise occupy 8 CUs)
+static inline int32_t dw_rows_per_block(int64_t m) {
+    int64_t r = (m + 511) / 512;
+    r = (r + 31) / 32 * 32;  // 32-row LDS tiles
+    if (r < 64) r = 64;
+    if (r > kDwRowsPerBlock) r = kDwRowsPerBlock;
+    return (int32_t)r;
+}
 
 static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,
                          int64_t ldy, int64_t M, int32_t N, int32_t K, int act, float *aux, hipStream_t st,
@@ -306,7 +315,7 @@ extern "C" int emer_linear_fwd(const float *x, int64_t ldx, const float *w, cons
 // floats of workspace emer_linear_bwd needs for the dW / dbias partial sums (0 when dw is not requested)
 extern "C" int64_t emer_linear_bwd_workspace(int64_t m, int32_t n, int32_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    return ceil_div(m, kDwRowsPerBlock) * ((int64_t)n * k + n);
+    return ceil_div(m, dw_rows_per_block(m)) * ((int64_t)n * k + n);
 }
 
 extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x, int64_t ldx,
@@ -332,10 +341,11 @@ extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, in
         EMER_REQUIRE(x && ldx >= k && workspace, "linear_bwd: dw requested but x / workspace missing or ldx too small");
         const int32_t NG = n <= 32 ? 32 : 64;
         const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
-        const int32_t n_row_blocks = (int32_t)ceil_div(m, kDwRowsPerBlock);
+        const int32_t rpb = dw_rows_per_block(m);
+        const int32_t n_row_blocks = (int32_t)ceil_div(m, rpb);
         const dim3 grid((uint32_t)n_row_blocks, (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
 #define EMER_DW(A, B) hipLaunchKernelGGL((linear_dw_kernel<A, B>), grid, dim3(256), 0, st, dy, lddy, ya, ldy, act, d_aux_density, \
-                                         aux_density, x, ldx, workspace, m, n, k, kDwRowsPerBlock, dbias ? 1 : 0)
+                                         aux_density, x, ldx, workspace, m, n, k, rpb, dbias ? 1 : 0)
         if (NG == 32) { if (KG == 32) EMER_DW(1, 1); else if (KG == 64) EMER_DW(1, 2); else if (KG == 128) EMER_DW(1, 4); else EMER_DW(1, 8); }
         else          { if (KG == 32) EMER_DW(2, 1); else if (KG == 64) EMER_DW(2, 2); else if (KG == 128) EMER_DW(2, 4); else EMER_DW(2, 8); }
 #undef EMER_DW
@@ -660,6 +670,130 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
     if (want_bias && blockIdx.y == 0 && wave == 0 && lane < NG && n_base + lane < N) part[(int64_t)N * K + n_base + lane] = bsum;
 }
 
+// Streaming dW.  For v_mfma_f32_32x32x2 lane (j = lane & 31, ms = lane >> 5) supplies dPre[m + ms][n0 + j] (A) and
+// X[m + ms][k0 + j] (B): 32 lanes read 128 contiguous bytes of ONE row, i.e. row-major operands are already in the
+// matrix-core layout.  So the operands go from global memory straight into registers: no LDS staging, no transposes and
+// no barrier in the row loop.  Each wave owns a quarter of the workgroup's rows and the whole N x K tile (NT x KT
+// accumulators of 32x32); U row pairs of loads are in flight ahead of the matrix pipe.  The four waves are summed through
+// LDS once at the end.  Column k of the virtual concatenation maps to "base + m * stride" for row-major and level-major
+// segments alike, so the per-lane addressing is hoisted out of the loop.
+template <int NT, int KT>
+__global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
+                                                           float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
+                                                           int32_t rows_per_block, int want_bias) {
+    constexpr int U = 4, KP = KT * 32;
+    __shared__ float red[NT * 32 * KP + NT * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, ms = lane >> 5;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < M) ? r_begin + rows_per_block : M;
+    const int32_t rpw = rows_per_block >> 2;  // rows_per_block is a multiple of 32
+    const int64_t w_begin = r_begin + (int64_t)wave * rpw;
+    const int64_t w_end = (w_begin + rpw < r_end) ? w_begin + rpw : r_end;
+
+    const float *ap[NT];
+    bool aok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { aok[t] = t * 32 + j < N; ap[t] = dpre + (aok[t] ? t * 32 + j : 0); }
+    const float *bp[KT];
+    int64_t bst[KT];
+    bool bok[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int32_t kk = t * 32 + j;
+        bok[t] = false; bp[t] = sx.s[0].ptr; bst[t] = 0;
+#pragma unroll
+        for (int sg = 0; sg < EMER_CHAIN_MAX_SEGS; ++sg) {
+            if (sg < sx.n && kk < K && kk >= sx.s[sg].col && kk < sx.s[sg].col + sx.s[sg].width) {
+                const int32_t c = kk - sx.s[sg].col;
+                bok[t] = true;
+                if (sx.s[sg].mode == 1) {
+                    const int32_t f = sx.s[sg].f, lv = c / f;
+                    bp[t] = sx.s[sg].ptr + (int64_t)lv * sx.s[sg].n_total * f + (c - lv * f);
+                    bst[t] = f;
+                } else {
+                    bp[t] = sx.s[sg].ptr + c;
+                    bst[t] = sx.s[sg].ld;
+                }
+            }
+        }
+    }
+    const bool fix = sx.fix_a != nullptr && j == 0;  // trunc_exp side gradient joins column 0 of dPre
+
+    f32x16 acc[NT][KT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) acc[a][b] = f32x16{0};
+    float bsum[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) bsum[a] = 0.0f;
+
+    float ac[U][NT], bc[U][KT], an[U][NT], bn[U][KT];
+    auto load = [&](int64_t m0, float (&av)[U][NT], float (&bv)[U][KT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + 2 * u + ms;
+            const bool ok = m < w_end;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) av[u][t] = (ok && aok[t]) ? ap[t][m * ldd] : 0.0f;
+            if (fix && ok) av[u][0] += sx.fix_a[m] * fminf(sx.fix_b[m], 3269017.3724721107f);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bv[u][t] = (ok && bok[t]) ? bp[t][m * bst[t]] : 0.0f;
+        }
+    };
+    load(w_begin, ac, bc);
+    for (int64_t m0 = w_begin; m0 < w_end; m0 += 2 * U) {
+        load(m0 + 2 * U, an, bn);  // predicated off past the end
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+#pragma unroll
+                for (int b = 0; b < KT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][a], bc[u][b], acc[a][b], 0, 0, 0);
+                bsum[a] += ac[u][a];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ac[u][t] = an[u][t];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bc[u][t] = bn[u][t];
+        }
+    }
+    // ---- sum the four waves through LDS (wave 0 writes, 1..3 add in turn), then one coalesced store of the partial
+#pragma unroll
+    for (int a = 0; a < NT; ++a) bsum[a] += __shfl_down(bsum[a], 32, 64);
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+#pragma unroll
+                for (int b = 0; b < KT; ++b) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int i = (v & 3) + 8 * (v >> 2) + 4 * ms;
+                        float *q = red + (a * 32 + i) * KP + b * 32 + j;
+                        *q = (w == 0) ? acc[a][b][v] : *q + acc[a][b][v];
+                    }
+                }
+                if (ms == 0) {
+                    float *q = red + NT * 32 * KP + a * 32 + j;
+                    *q = (w == 0) ? bsum[a] : *q + bsum[a];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *__restrict__ part = partials + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+    for (int idx = tid; idx < N * K; idx += 256) {
+        const int n = idx / K, k = idx - n * K;
+        part[idx] = red[n * KP + k];
+    }
+    if (want_bias)
+        for (int n = tid; n < N; n += 256) part[(int64_t)N * K + n] = red[NT * 32 * KP + n];
+}
+
 }  // namespace emer
 
 extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *stream) {
@@ -722,9 +856,25 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
     hipStream_t st = as_stream(stream);
     const int32_t NG = n <= 32 ? 32 : 64;
     const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
-    const int32_t n_row_blocks = (int32_t)ceil_div(m, kDwRowsPerBlock);
+    const int32_t rpb = dw_rows_per_block(m);
+    const int32_t n_row_blocks = (int32_t)ceil_div(m, rpb);
+    bool stream_ok = n <= 64 && k <= 128;
+    for (int s = 0; s < n_segs; ++s) stream_ok = stream_ok && (segs[s].mode == 1 || segs[s].row_div == 1);
+    if (stream_ok) {  // no per-ray operand: operands stream straight into the MFMA layout
+        const int NT = n <= 32 ? 1 : 2, KT = (k + 31) / 32;
+        const dim3 sgrid((uint32_t)n_row_blocks);
+#define EMER_WS(A, B) hipLaunchKernelGGL((wgrad_stream_kernel<A, B>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+        if (NT == 1) { if (KT == 1) EMER_WS(1, 1); else if (KT == 2) EMER_WS(1, 2); else if (KT == 3) EMER_WS(1, 3); else EMER_WS(1, 4); }
+        else         { if (KT == 1) EMER_WS(2, 1); else if (KT == 2) EMER_WS(2, 2); else if (KT == 3) EMER_WS(2, 3); else EMER_WS(2, 4); }
+#undef EMER_WS
+        if (int rc = check_launch("wgrad_stream")) return rc;
+        const int64_t stride = (int64_t)n * k + n;
+        hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st,
+                           workspace, n_row_blocks, stride, (int64_t)n * k, dw, dbias);
+        return check_launch("wgrad_reduce");
+    }
     const dim3 grid((uint32_t)n_row_blocks, (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
-#define EMER_WG(A, B) hipLaunchKernelGGL((wgrad_seg_kernel<A, B>), grid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, kDwRowsPerBlock, dbias ? 1 : 0)
+#define EMER_WG(A, B) hipLaunchKernelGGL((wgrad_seg_kernel<A, B>), grid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
     if (NG == 32) { if (KG == 32) EMER_WG(1, 1); else if (KG == 64) EMER_WG(1, 2); else if (KG == 128) EMER_WG(1, 4); else EMER_WG(1, 8); }
     else          { if (KG == 32) EMER_WG(2, 1); else if (KG == 64) EMER_WG(2, 2); else if (KG == 128) EMER_WG(2, 4); else EMER_WG(2, 8); }
 #undef EMER_WG
