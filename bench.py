@@ -94,8 +94,8 @@ def pmc_traffic(dominant: str, D: int, F: int, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rays", type=int, default=8192)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--kind", default="static", choices=["static", "dynamic", "flow"])

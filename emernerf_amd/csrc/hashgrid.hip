@@ -152,7 +152,7 @@ struct SlicePlan {
     uint32_t max_local;                  // largest slice (entries)
     uint32_t ok;                         // 0 when some level would need more than 64 slices
     uint8_t xcd_of[EMER_MAX_LEVELS];     // backward: the XCD (0..7) that owns each level (cost-balanced)
-    uint32_t blocks_per_xcd;             // backward grid = 8 * blocks_per_xcd
+    uint32_t items_per_xcd[8];           // backward work items ((level, slice, range) triples) on each XCD's list
 };
 
 static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
@@ -207,8 +207,7 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
         placed[best] = true; p.xcd_of[best] = (uint8_t)x; load[x] += best_cost; nblk[x] += p.n_slices[best] * p.n_ranges[best];
     }
-    p.blocks_per_xcd = 0;
-    for (int i = 0; i < 8; ++i) p.blocks_per_xcd = nblk[i] > p.blocks_per_xcd ? nblk[i] : p.blocks_per_xcd;
+    for (int i = 0; i < 8; ++i) p.items_per_xcd[i] = nblk[i];
     return p;
 }
 
@@ -388,20 +387,39 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                                                                                    const float *__restrict__ x,
                                                                                    const float *__restrict__ dout, int64_t sn, int64_t sl,
                                                                                    const uint64_t *__restrict__ masks,
+                                                                                   uint32_t *__restrict__ work_ctr,
                                                                                    float *__restrict__ grad, int64_t N) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // XCD-aware work lookup: XCD xcd walks the levels assigned to it; j-th block of that XCD
-    const uint32_t xcd = blockIdx.x & 7u;
-    uint32_t j = blockIdx.x >> 3;
+    __shared__ uint32_t s_item;
+    // Persistent workgroups with XCD-affine work lists.  Each XCD has a list of (level, slice, range) items -- whole
+    // levels, so that a level's streamed inputs are fetched into ONE L2 -- consumed through an atomic cursor.  A
+    // workgroup whose own list is exhausted steals from the other XCDs' lists, which absorbs whatever the static cost
+    // model got wrong for the actual sample distribution.  Placement only affects speed, never results.
+    const uint32_t my_xcd = blockIdx.x & 7u;
+  for (;;) {
+    if (threadIdx.x == 0) {
+        uint32_t it = 0xFFFFFFFFu;
+        for (uint32_t t = 0; t < 8u; ++t) {
+            const uint32_t xx = (my_xcd + t) & 7u;
+            if (plan.items_per_xcd[xx] == 0u) continue;
+            const uint32_t jj = atomicAdd(work_ctr + xx, 1u);
+            if (jj < plan.items_per_xcd[xx]) { it = (xx << 24) | jj; break; }
+        }
+        s_item = it;
+    }
+    __syncthreads();
+    const uint32_t item = s_item;
+    __syncthreads();  // s_item may be rewritten by thread 0 right after the item is finished
+    if (item == 0xFFFFFFFFu) return;
+    const uint32_t xcd = item >> 24;
+    uint32_t j = item & 0xFFFFFFu;
     uint32_t level = 0, slice = 0, range = 0;
-    bool have = false;
     for (; level < g.n_levels; ++level) {
         if (plan.xcd_of[level] != xcd) continue;
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
-        if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; have = true; break; }
+        if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; break; }
         j -= nb;
     }
-    if (!have) return;
     const LevelInfo li = level_info(g, level);
     const bool dense = !li.hashed;
     const bool pairable = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
@@ -588,6 +606,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             if (v != 0.0f) __hip_atomic_fetch_add(out + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    __syncthreads();  // the accumulators are re-zeroed by the next item
+  }
 }
 
 // Slice bitmaps for callers that did not get them from the forward pass.
@@ -773,20 +793,30 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
 // once, so the caller does not zero the buffer.  The slice bitmaps come from emer_hashgrid_fwd (or
 // emer_hashgrid_slice_masks) for the SAME x.
 extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
-                                               int64_t sl, const uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
+                                               int64_t sl, uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
     EMER_REQUIRE(n >= 0 && n < (1ll << 31), "hashgrid_bwd_params_sliced: n out of range (sample ids are queued as 32-bit)");
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
     const SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 LDS slices; use emer_hashgrid_bwd_params");
-    const uint32_t max_blocks = plan.blocks_per_xcd;
+    uint32_t total_items = 0;
+    for (int i = 0; i < 8; ++i) total_items += plan.items_per_xcd[i];
     for (uint32_t l = 0; l < g->n_levels; ++l) {
         if (plan.n_ranges[l] > 1u) {  // levels merged with atomics start from zero (async memset node on the same stream)
             hipError_t e = hipMemsetAsync(grad + (size_t)g->offset[l] * F, 0, (size_t)g->size[l] * F * sizeof(float), as_stream(stream));
             if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
         }
     }
+    // work cursors: the 16 scratch words behind the bitmaps
+    uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * 64 * (size_t)ceil_div(n, 64));
+    {
+        hipError_t e = hipMemsetAsync(work_ctr, 0, 8 * sizeof(uint32_t), as_stream(stream));
+        if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
+    }
+    // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
+    uint32_t n_blocks = 256;
+    if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
     const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kWaveQueue * sizeof(uint32_t);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
@@ -795,8 +825,8 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
         }
-        hipLaunchKernelGGL(kern, dim3(max_blocks * 8u), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
-                           slice_masks, grad, n);
+        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
+                           slice_masks, work_ctr, grad, n);
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(1024) void mlp_chain_kernel(const emer_chain_desc d
 }
 
 // dW kernel with a segmented (virtual concat) X operand; dPre is given materialised.
-struct SegX { emer_chain_seg s[EMER_CHAIN_MAX_SEGS]; int32_t n; const float *fix_a; const float *fix_b; };
+struct SegX { emer_chain_seg s[EMER_CHAIN_MAX_SEGS]; int32_t n; const float *col0; };  // col0: replaces column 0 of dPre when non-null
 
 template <int NGT, int KGT>
 __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
@@ -596,9 +596,7 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
             const int r = idx / NG, c = idx % NG;
             const int64_t gr = r0 + r;
             const int32_t gn = n_base + c;
-            float dv = (gr < r_end && gn < N) ? dpre[gr * ldd + gn] : 0.0f;
-            if (sx.fix_a && gn == 0 && gr < r_end) dv += sx.fix_a[gr] * fminf(sx.fix_b[gr], 3269017.3724721107f);
-            dreg[i] = dv;
+            dreg[i] = (gr < r_end && gn < N) ? ((sx.col0 && gn == 0) ? sx.col0[gr] : dpre[gr * ldd + gn]) : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -681,7 +679,9 @@ template <int NT, int KT>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
                                                            float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
                                                            int32_t rows_per_block, int want_bias) {
-    constexpr int U = 4, KP = KT * 32;
+    // bytes in flight decide the speed (HBM needs ~60 KB per CU): 2 x U row pairs of (NT + KT) x 256 B per wave.  The widest
+    // tiles run one wave per SIMD, so they prefetch deepest.
+    constexpr int U = (NT * KT >= 6) ? 12 : (NT * KT >= 4 ? 8 : 4), KP = KT * 32;
     __shared__ float red[NT * 32 * KP + NT * 32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, ms = lane >> 5;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
@@ -691,9 +691,11 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
     const int64_t w_end = (w_begin + rpw < r_end) ? w_begin + rpw : r_end;
 
     const float *ap[NT];
+    int64_t ast[NT];
     bool aok[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { aok[t] = t * 32 + j < N; ap[t] = dpre + (aok[t] ? t * 32 + j : 0); }
+    for (int t = 0; t < NT; ++t) { aok[t] = t * 32 + j < N; ap[t] = dpre + (aok[t] ? t * 32 + j : 0); ast[t] = ldd; }
+    if (sx.col0 && j == 0) { ap[0] = sx.col0; ast[0] = 1; }  // column 0 of dPre comes from its own array (trunc_exp side gradient merged)
     const float *bp[KT];
     int64_t bst[KT];
     bool bok[KT];
@@ -717,7 +719,6 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
             }
         }
     }
-    const bool fix = sx.fix_a != nullptr && j == 0;  // trunc_exp side gradient joins column 0 of dPre
 
     f32x16 acc[NT][KT];
 #pragma unroll
@@ -735,8 +736,7 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
             const int64_t m = m0 + 2 * u + ms;
             const bool ok = m < w_end;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) av[u][t] = (ok && aok[t]) ? ap[t][m * ldd] : 0.0f;
-            if (fix && ok) av[u][0] += sx.fix_a[m] * fminf(sx.fix_b[m], 3269017.3724721107f);
+            for (int t = 0; t < NT; ++t) av[u][t] = (ok && aok[t]) ? ap[t][m * ast[t]] : 0.0f;
 #pragma unroll
             for (int t = 0; t < KT; ++t) bv[u][t] = (ok && bok[t]) ? bp[t][m * bst[t]] : 0.0f;
         }
@@ -835,15 +835,14 @@ extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *st
     return check_launch("mlp_chain");
 }
 
-extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float *fix_a, const float *fix_b, const emer_chain_seg *segs,
+extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float *col0, const emer_chain_seg *segs,
                                     int32_t n_segs, float *workspace, float *dw, float *dbias, int64_t m, int32_t n, int32_t k,
                                     void *stream) {
     EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "wgrad_segmented: bad sizes");
     if (m == 0) return EMER_OK;
     EMER_REQUIRE(dpre && segs && workspace && dw && n_segs >= 1 && n_segs <= EMER_CHAIN_MAX_SEGS, "wgrad_segmented: bad arguments");
     SegX sx;
-    sx.n = n_segs; sx.fix_a = fix_a; sx.fix_b = fix_b;
-    EMER_REQUIRE(!fix_a || fix_b, "wgrad_segmented: fix_a needs fix_b");
+    sx.n = n_segs; sx.col0 = col0;
     int32_t covered = 0;
     for (int s = 0; s < n_segs; ++s) {
         EMER_REQUIRE(segs[s].ptr && segs[s].col == covered && ((segs[s].mode == 0 && segs[s].row_div >= 1) || (segs[s].mode == 1 && segs[s].f >= 1)),

@@ -246,6 +246,7 @@ struct NeckBwdArgs {
     int64_t n; int32_t n_levels;
     WSrc w1t, w0t;       // W1^T (64 x K1), W0^T (K0 x 64)
     float *dpre1;        // density mode: [n] pre-activation gradient of the single output (for its wgrad)
+    float *dcol0;        // [n] d0[:, 0] + density fix (may be null)
     float *dpre0;        // [n][64]
     float *denc;         // level-major [L][n][F]
 };
@@ -285,7 +286,10 @@ __global__ __launch_bounds__(kFThreads, 3) void neck_bwd_kernel(const NeckBwdArg
                 {
                     f32x4 lo[4];
                     if (a.d0) ld_rm<4>(a.d0 + row * 64, ok, g, lo); else zero<4>(lo);
-                    if (g == 0) lo[0][0] += fix;
+                    if (g == 0) {
+                        lo[0][0] += fix;
+                        if (a.dcol0 && ok) a.dcol0[row] = lo[0][0];
+                    }
 #pragma unroll
                     for (int p = 0; p < 4; ++p) d[p] = lo[p];
                 }
@@ -520,10 +524,10 @@ extern "C" int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_fe
 
 // Data-gradient chain of emer_neck_fwd.  d0 / d1: gradients of output features 0..63 / 64..127 (either may be NULL
 // = zero; n_out == 1: both NULL).  ddens/dens: trunc_exp backward, joins feature 0.  Writes dpre0 [n][64] (gradient
-// at the hidden pre-activation), denc_lm [L][n][F], and for n_out == 1 dpre1 [n].
+// at the hidden pre-activation), denc_lm [L][n][F], for n_out == 1 dpre1 [n], and (optionally) dcol0 [n] = d0[:,0] + fix.
 extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const float *dens, const float *h1,
                              int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1, int32_t n_out,
-                             float *dpre1, float *dpre0, float *denc_lm, void *stream) {
+                             float *dpre1, float *dcol0, float *dpre0, float *denc_lm, void *stream) {
     EMER_REQUIRE(n >= 0, "neck_bwd: negative n");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(emer_neck_supported(n_levels, n_feat, 64, n_out), "neck_bwd: unsupported shape L=%d F=%d n_out=%d", n_levels, n_feat, n_out);
@@ -533,7 +537,7 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
     const int k0 = n_levels * n_feat;
     NeckBwdArgs a;
     a.d0 = d0; a.d1 = d1; a.ddens = ddens; a.dens = dens; a.h1 = h1; a.n = n; a.n_levels = n_levels;
-    a.dpre1 = dpre1; a.dpre0 = dpre0; a.denc = denc_lm;
+    a.dpre1 = dpre1; a.dcol0 = dcol0; a.dpre0 = dpre0; a.denc = denc_lm;
     a.w0t = WSrc{w0, 1, k0, k0, 64};     // (n = input feature, k = hidden) = w0[k][n]
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk);

@@ -111,8 +111,8 @@ def run_chain(segs, layers, buf_cols: int, n_rows: int, ref: Tensor) -> None:
         _lib.call("emer_mlp_chain", ctypes.byref(d), n_rows, _stream(ref))
 
 
-def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, fix_a: Optional[Tensor] = None, fix_b: Optional[Tensor] = None):
-    """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments."""
+def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Optional[Tensor] = None):
+    """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments.  col0 [M] replaces dpre[:, 0]."""
     M, N = dpre.shape
     dev = dpre.device
     with torch.cuda.device(dev):
@@ -123,7 +123,7 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, fix_a: Optio
         arr = (ChainSeg * MAX_SEGS)()
         for i, s in enumerate(segs):
             arr[i] = s
-        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(fix_a), _p(fix_b), arr, len(segs), _p(ws), _p(dw), _p(db),
+        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(col0), arr, len(segs), _p(ws), _p(dw), _p(db),
                   M, N, k_total, _stream(dpre))
     return dw, db
 
@@ -178,7 +178,8 @@ class _BaseMLPFn(torch.autograd.Function):
                   [layer(W1, None, 0, c_h, transposed=True, mask=h1, store=dpre0),
                    layer(W0, None, c_h, c_e, transposed=True, store=denc, store_lm=True)],
                   c_e + K0, N, enc)
-        dw1, db1 = wgrad(dgt, [seg(h1, 0, H)], H, fix_a=fa, fix_b=fb)
+        col0 = None if fa is None else dgt[:, 0] + fa * dens.clamp(max=E15)
+        dw1, db1 = wgrad(dgt, [seg(h1, 0, H)], H, col0=col0)
         dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
         return denc, dw0, db0, dw1, db1
 
@@ -236,13 +237,15 @@ class _NeckFn(torch.autograd.Function):
         fa = None if ddens is None else _c(ddens)
         dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
         denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+        # column 0 of the output-layer wgrad operand = d0[:, 0] + trunc_exp side gradient, written by the kernel
+        col0 = None if fa is None else torch.empty((N,), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
-            _lib.call("emer_neck_bwd", _p(d0c), _p(d1c), _p(fa), _p(dens), _p(h1), L, F, N, _p(W0), _p(W1), n_out, None, _p(dpre0),
-                      _p(denc), _stream(enc))
+            _lib.call("emer_neck_bwd", _p(d0c), _p(d1c), _p(fa), _p(dens), _p(h1), L, F, N, _p(W0), _p(W1), n_out, None, _p(col0),
+                      _p(dpre0), _p(denc), _stream(enc))
         # weight gradients.  Output rows whose gradient is structurally zero (an unused semantic half) cost nothing.
         if d0c is None:
             d0c = torch.zeros((N, 64), device=dev, dtype=torch.float32)
-        dw1, db1 = wgrad(d0c, [seg(h1, 0, 64)], 64, fix_a=fa, fix_b=None if fa is None else dens)
+        dw1, db1 = wgrad(d0c, [seg(h1, 0, 64)], 64, col0=col0)
         if n_out == 128:
             if d1c is not None:
                 dw1b, db1b = wgrad(d1c, [seg(h1, 0, 64)], 64)
@@ -298,7 +301,7 @@ class _DensityMLPFn(torch.autograd.Function):
             dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
             denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.call("emer_neck_bwd", None, None, _p(_c(ddens)), _p(dens), _p(h), L, F, N, _p(W0), _p(W1), 1, _p(dpre1),
+                _lib.call("emer_neck_bwd", None, None, _p(_c(ddens)), _p(dens), _p(h), L, F, N, _p(W0), _p(W1), 1, _p(dpre1), None,
                           _p(dpre0), _p(denc), _stream(enc))
             dw1, db1 = wgrad(dpre1, [seg(h, 0, H)], H)
             dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)

@@ -76,8 +76,10 @@ int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_l
  *   level-major [L][N][F] (coalesced, what the fused heads read): stride_n = F, stride_l = N*F.
  * slice_masks (may be NULL): [L][64][ceil(N/64)] u64 by-product consumed by emer_hashgrid_bwd_params_sliced:
  *   one bitmap per (level l, LDS slice s); bit (n % 64) of word n/64 is set iff a corner of sample n
- *   lives in slice s of level l.
+ *   lives in slice s of level l.  The buffer must hold EMER_SLICE_MASK_SCRATCH more words behind the bitmaps
+ *   (work cursors of the backward).
  * Replaces native.fwd (tcnn_modules.py:122). */
+#define EMER_SLICE_MASK_SCRATCH 16
 int emer_hashgrid_fwd(const emer_grid_desc *host_desc, const float *x, const void *params,
                       int param_dtype, float *out, int64_t out_stride_n, int64_t out_stride_l,
                       uint64_t *slice_masks, int64_t n, void *stream);
@@ -92,10 +94,10 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
 /* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
  * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice (accumulated in double) and
  * streams its 1-bit-per-sample slice bitmap ("owner computes"; see csrc/hashgrid.hip).  The training path.
- * slice_masks [L][64][ceil(N/64)]: from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
+ * slice_masks [L][64][ceil(N/64)] (+ EMER_SLICE_MASK_SCRATCH words the call overwrites): from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
 int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
                                     const float *dout, int64_t dout_stride_n,
-                                    int64_t dout_stride_l, const uint64_t *slice_masks,
+                                    int64_t dout_stride_l, uint64_t *slice_masks,
                                     float *grad, int64_t n, void *stream);
 int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
                               uint64_t *slice_masks, int64_t n, void *stream);
@@ -246,9 +248,10 @@ typedef struct emer_chain_desc {
 int emer_mlp_chain(const emer_chain_desc *host_desc, int64_t n_rows, void *stream);
 
 /* dW[N,K] += dpre[M,N]^T @ X[M,K], dbias[N] += colsum(dpre), with X given as up to EMER_CHAIN_MAX_SEGS
- * column segments (modes 0 and 1; a virtual concat).  fix_a/fix_b (may be NULL): dpre[row][0] += fix_a[row] *
- * min(fix_b[row], e^15) on the fly (density gradient merged into geometry feature 0).  workspace: emer_linear_bwd_workspace(m, n, k) floats. */
-int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const float *fix_a, const float *fix_b,
+ * column segments (modes 0 and 1; a virtual concat).  col0 (may be NULL): [m] values that REPLACE column 0 of dpre
+ * (the geometry-feature-0 gradient with the density gradient merged in, as emer_neck_bwd writes it).
+ * workspace: emer_linear_bwd_workspace(m, n, k) floats. */
+int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const float *col0,
                          const emer_chain_seg *host_segs, int32_t n_segs, float *workspace, float *dw,
                          float *dbias, int64_t m, int32_t n, int32_t k, void *stream);
 
@@ -270,10 +273,11 @@ int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t
 /* Data gradients of emer_neck_fwd.  d0 / d1 [n][64]: gradients of features 0..63 / 64..127 (NULL = zero);
  * ddens [n] (NULL = none) enters feature 0 as ddens * min(dens, e^15) (nerf_utils.py:69-72).
  * Writes dpre0 [n][64] (gradient at the hidden pre-activation, the wgrad operand), denc_lm [L][n][F] and,
- * for n_out == 1, dpre1 [n] (gradient at the single output's pre-activation). */
+ * for n_out == 1, dpre1 [n] (gradient at the single output's pre-activation).  dcol0 [n] (may be NULL) receives
+ * d0[:, 0] + ddens * min(dens, e^15): column 0 of the output-layer wgrad operand (emer_wgrad_segmented's col0). */
 int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const float *dens, const float *h1,
                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1,
-                  int32_t n_out, float *dpre1, float *dpre0, float *denc_lm, void *stream);
+                  int32_t n_out, float *dpre1, float *dcol0, float *dpre0, float *denc_lm, void *stream);
 
 /* rgb head: mlp.MLP(in = kh + 64, hidden 64, 3 layers, skip connection at layer 1) + sigmoid
  * (radiance_field.py:130-143,622-658, mlp.py:20-46) on input [hray[ray] | geo[sample]], where hray
