@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kFThreads, 3) void neck_bwd_kernel(const NeckBwdArg
 // ------------------------------------------------------------------------------------------------- rgb forward
 struct RgbFwdArgs {
     const float *geo; int64_t ld_geo;  // [n][>= 64]
-    const float *rb0, *rb1;            // [rays][64] per-ray pre-activations (bias included)
+    const float *rb0, *rb1; int64_t ld_rb;  // [rays][64] (row stride ld_rb) per-ray pre-activations, bias included
     int32_t tiles_per_ray; int64_t n_rays;
     WSrc w0g, w1a, w1g, w2; const float *b2;
     float *a1, *a2;                    // [n][64]
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_fwd_kernel(const RgbFwdArgs 
     const int tpr = a.tiles_per_ray;
     for (int64_t ray = (int64_t)blockIdx.x * kFWaves + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * kFWaves) {
         f32x4 r0[4], r1[4];
-        ld_rm<4>(a.rb0 + ray * 64, true, g, r0);
-        ld_rm<4>(a.rb1 + ray * 64, true, g, r1);
+        ld_rm<4>(a.rb0 + ray * a.ld_rb, true, g, r0);
+        ld_rm<4>(a.rb1 + ray * a.ld_rb, true, g, r1);
         const int64_t row_base = ray * tpr * 16 + m;
         f32x4 xn[4];
         ld_rm<4>(a.geo + row_base * a.ld_geo, true, g, xn);
@@ -560,14 +560,15 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
 // w0 [64][kh + 64] = [W0h | W0g], w1 [64][64 + kh + 64] = [W1a | W1h | W1g], w2 [3][64] (torch Linear layouts of
 // mlp.py:20-36 with the skip connection at layer 1).  rb0 = hray W0h^T + b0, rb1 = hray W1h^T + b1: [rays][64].
 // Rows of ray r are r*S .. r*S + S - 1; S must be a multiple of 16.
-extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t n_rays,
+extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                                  int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1, const float *w2,
                                  const float *b2, float *a1, float *a2, float *out, void *stream) {
     EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "rgb_head_fwd: bad sizes (S must be a multiple of 16)");
     if (n_rays == 0) return EMER_OK;
-    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && a1 && a2 && out && ld_geo >= 64 && ld_geo % 4 == 0, "rgb_head_fwd: bad arguments");
+    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && a1 && a2 && out && ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_rb % 4 == 0,
+                 "rgb_head_fwd: bad arguments");
     RgbFwdArgs a;
-    a.geo = geo; a.ld_geo = ld_geo; a.rb0 = rb0; a.rb1 = rb1; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
+    a.geo = geo; a.ld_geo = ld_geo; a.rb0 = rb0; a.rb1 = rb1; a.ld_rb = ld_rb; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
     const int64_t k0 = kh + 64, k1 = 64 + k0;
     a.w0g = WSrc{w0 + kh, k0, 1, 64, 64};
     a.w1a = WSrc{w1, k1, 1, 64, 64};

@@ -118,8 +118,9 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
     with torch.cuda.device(dev):
         n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, k_total))
         ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
-        dw = torch.zeros((N, k_total), device=dev, dtype=torch.float32)
-        db = torch.zeros((N,), device=dev, dtype=torch.float32) if want_bias else None
+        buf = torch.zeros((N * k_total + (N if want_bias else 0),), device=dev, dtype=torch.float32)  # one fill for both
+        dw = buf[:N * k_total].view(N, k_total)
+        db = buf[N * k_total:] if want_bias else None
         arr = (ChainSeg * MAX_SEGS)()
         for i, s in enumerate(segs):
             arr[i] = s
@@ -344,11 +345,15 @@ class _RgbHeadFn(torch.autograd.Function):
         ctx.S = S
         ctx.fast = (H == 64 and NG == 64 and C == 3 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
         if ctx.fast:
-            # per-ray part of layers 0 and 1 as per-ray pre-activations (8192-row GEMMs instead of 1M-row ones)
-            rb0 = torch.addmm(B0, hr, W0[:, :Kh].t())
-            rb1 = torch.addmm(B1, hr, W1[:, H:H + Kh].t())
+            # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row GEMM instead of two 1M-row ones)
+            wcat = torch.cat([W0[:, :Kh], W1[:, H:H + Kh]], 0)
+            rb = torch.empty((R, 2 * H), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.call("emer_rgb_head_fwd", _p(g), g.stride(0), _p(rb0), _p(rb1), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(B2),
+                _lib.call("emer_linear_fwd", _p(hr), hr.stride(0), _p(wcat), _p(torch.cat([B0, B1])), _p(rb), 2 * H, R, 2 * H, Kh,
+                          ACT_NONE, None, _stream(g))
+            rb0, rb1 = rb[:, :H], rb[:, H:]
+            with torch.cuda.device(dev):
+                _lib.call("emer_rgb_head_fwd", _p(g), g.stride(0), _p(rb0), _p(rb1), rb.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(B2),
                           _p(a1), _p(a2), _p(out), _stream(g))
             ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
             return out

@@ -282,11 +282,11 @@ int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const fl
 /* rgb head: mlp.MLP(in = kh + 64, hidden 64, 3 layers, skip connection at layer 1) + sigmoid
  * (radiance_field.py:130-143,622-658, mlp.py:20-46) on input [hray[ray] | geo[sample]], where hray
  * (dir-PE | appearance embedding, kh columns) is constant along a ray.  The per-ray part arrives as
- * pre-activations rb0 = hray W0[:, :kh]^T + b0 and rb1 = hray W1[:, 64:64+kh]^T + b1 ([rays][64]); the kernel
+ * pre-activations rb0 = hray W0[:, :kh]^T + b0 and rb1 = hray W1[:, 64:64+kh]^T + b1 ([rays][64], row stride ld_rb); the kernel
  * does the per-sample part: a1 = relu(geo W0[:, kh:]^T + rb0), a2 = relu(a1 W1[:, :64]^T + geo W1[:, 64+kh:]^T
  * + rb1), out = sigmoid(a2 W2^T + b2).  w0 [64][kh+64], w1 [64][64+kh+64], w2 [3][64] are the torch Linear
  * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward. */
-int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t n_rays,
+int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
                       const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);
 /* Data gradients: dpre2 [n][3] = dout * out * (1 - out), dpre1 / dpre0 [n][64] (pre-activation gradients of
