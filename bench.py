@@ -35,7 +35,7 @@ def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
     return fwd, bwd
 
 
-def cpu_baseline(trainer, rays: int, samples: int, steps: int = 6):
+def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
     """Oracle port (oracle/ref_path.py on the C oracle) timed on this box's host cores, bounded sample."""
     from oracle import oracle as O
     from oracle.ref_path import RefPath
@@ -63,7 +63,8 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 6):
         jit = [torch.rand(rays, generator=g) for _ in range(len(prop_samples) + 1)]
         ref.train_step(data, opt_main, opt_prop, samples, prop_samples, jitters=jit, prop_grad=prop_grad)
 
-    one(False)  # warm-up (allocations, OpenMP pool)
+    one(True)   # warm-up both step types (allocations, OpenMP pool)
+    one(False)
     t0 = time.perf_counter()
     for i in range(steps):
         one(i % 6 == 0)
@@ -102,7 +103,7 @@ def main():
     ap.add_argument("--table-init", type=float, default=None, help="U(-a,a) tables instead of tcnn's +-1e-4 init")
     ap.add_argument("--start-step", type=int, default=1000, help="training step the run starts at (1000 = steady-state "
                     "proposal schedule: 1 step in 6 trains the proposal nets, nerfacc_prop_net.py:280-296)")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
