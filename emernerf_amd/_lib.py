@@ -59,7 +59,7 @@ SIGNATURES = {
     "emer_linear_bwd": [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32,
                         c_int32, c_int, _P, _P, _P],
     "emer_mlp_chain": [_P, c_int64, _P],
-    "emer_wgrad_segmented": [_P, c_int64, _P, _P, c_int32, _P, _P, _P, c_int64, c_int32, c_int32, _P],
+    "emer_wgrad_segmented": [_P, c_int64, _P, _P, c_int32, _P, _P, c_int64, _P, c_int64, c_int32, c_int32, _P],
     "emer_neck_supported": [c_int32, c_int32, c_int32, c_int32],
     "emer_neck_fwd": [_P, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P],
     "emer_neck_bwd": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P],

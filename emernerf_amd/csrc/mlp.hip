@@ -242,8 +242,20 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float *__restrict_
 // dw[i] += sum_b partials[b][i]  (i < N*K),  dbias[i - N*K] += ...  (i >= N*K).
 // The partial blocks are cut into gridDim.y ranges so that the (small) N*K + N extent still fills the chip; each
 // thread sums its range with four independent accumulators (loads in flight) and merges with one f32 atomic.
+struct DwDst {  // where column k of the (virtually concatenated) operand lands in dw: dw[n * ld + dst + (k - col)]
+    int32_t col[EMER_CHAIN_MAX_SEGS], width[EMER_CHAIN_MAX_SEGS], dst[EMER_CHAIN_MAX_SEGS];
+    int32_t n, K;
+    int64_t ld;
+};
+static inline DwDst dw_dst_identity(int32_t k) {
+    DwDst d;
+    for (int i = 0; i < EMER_CHAIN_MAX_SEGS; ++i) { d.col[i] = 0; d.width[i] = 0; d.dst[i] = 0; }
+    d.col[0] = 0; d.width[0] = k; d.dst[0] = 0; d.n = 1; d.K = k; d.ld = k;
+    return d;
+}
+
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float *__restrict__ partials, int32_t n_blocks, int64_t stride,
-                                                               int64_t nk, float *__restrict__ dw, float *__restrict__ dbias) {
+                                                               int64_t nk, float *__restrict__ dw, float *__restrict__ dbias, const DwDst dst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= stride) return;
     const int32_t per = (n_blocks + (int32_t)gridDim.y - 1) / (int32_t)gridDim.y;
@@ -261,8 +273,14 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float *__re
     for (; b < b1; ++b) a0 += p[(int64_t)b * stride];
     const float a = (a0 + a1) + (a2 + a3);
     if (b0 >= b1) return;
-    if (i < nk) __hip_atomic_fetch_add(dw + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (dbias) __hip_atomic_fetch_add(dbias + (i - nk), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < nk) {
+        const int32_t n = (int32_t)(i / dst.K), k = (int32_t)(i - (int64_t)n * dst.K);
+        int64_t o = -1;
+#pragma unroll
+        for (int sg = 0; sg < EMER_CHAIN_MAX_SEGS; ++sg)
+            if (sg < dst.n && k >= dst.col[sg] && k < dst.col[sg] + dst.width[sg]) o = (int64_t)n * dst.ld + dst.dst[sg] + (k - dst.col[sg]);
+        if (o >= 0) __hip_atomic_fetch_add(dw + o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (dbias) __hip_atomic_fetch_add(dbias + (i - nk), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static inline uint32_t dw_reduce_splits(int32_t n_blocks, int64_t stride) {
@@ -351,8 +369,9 @@ extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, in
 #undef EMER_DW
         if (int rc = check_launch("linear_dw")) return rc;
         const int64_t stride = (int64_t)n * k + n;
+        const DwDst ddst = dw_dst_identity(k);
         hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st, workspace, n_row_blocks,
-                           stride, (int64_t)n * k, dw, dbias);
+                           stride, (int64_t)n * k, dw, dbias, ddst);
         if (int rc = check_launch("linear_dw_reduce")) return rc;
     }
     return EMER_OK;
@@ -836,15 +855,19 @@ extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *st
 }
 
 extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float *col0, const emer_chain_seg *segs,
-                                    int32_t n_segs, float *workspace, float *dw, float *dbias, int64_t m, int32_t n, int32_t k,
-                                    void *stream) {
+                                    int32_t n_segs, float *workspace, float *dw, int64_t ld_dw, float *dbias, int64_t m, int32_t n,
+                                    int32_t k, void *stream) {
     EMER_REQUIRE(m >= 0 && n >= 1 && k >= 1, "wgrad_segmented: bad sizes");
     if (m == 0) return EMER_OK;
     EMER_REQUIRE(dpre && segs && workspace && dw && n_segs >= 1 && n_segs <= EMER_CHAIN_MAX_SEGS, "wgrad_segmented: bad arguments");
     SegX sx;
     sx.n = n_segs; sx.col0 = col0;
+    DwDst ddst = dw_dst_identity(k);
+    ddst.n = n_segs; ddst.ld = ld_dw;
     int32_t covered = 0;
     for (int s = 0; s < n_segs; ++s) {
+        EMER_REQUIRE(segs[s].dst_col >= 0 && segs[s].dst_col + segs[s].width <= ld_dw, "wgrad_segmented: segment %d lands outside dw (ld_dw=%lld)", s, (long long)ld_dw);
+        ddst.col[s] = segs[s].col; ddst.width[s] = segs[s].width; ddst.dst[s] = segs[s].dst_col;
         EMER_REQUIRE(segs[s].ptr && segs[s].col == covered && ((segs[s].mode == 0 && segs[s].row_div >= 1) || (segs[s].mode == 1 && segs[s].f >= 1)),
                      "wgrad_segmented: segments must be contiguous, mode 0 or 1");
         sx.s[s] = segs[s];
@@ -869,7 +892,7 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
         if (int rc = check_launch("wgrad_stream")) return rc;
         const int64_t stride = (int64_t)n * k + n;
         hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st,
-                           workspace, n_row_blocks, stride, (int64_t)n * k, dw, dbias);
+                           workspace, n_row_blocks, stride, (int64_t)n * k, dw, dbias, ddst);
         return check_launch("wgrad_reduce");
     }
     const dim3 grid((uint32_t)n_row_blocks, (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
@@ -880,6 +903,6 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
     if (int rc = check_launch("wgrad_segmented")) return rc;
     const int64_t stride = (int64_t)n * k + n;
     hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st, workspace, n_row_blocks, stride,
-                       (int64_t)n * k, dw, dbias);
+                       (int64_t)n * k, dw, dbias, ddst);
     return check_launch("wgrad_reduce");
 }

@@ -32,7 +32,7 @@ E15 = 3269017.3724721107
 
 class ChainSeg(ctypes.Structure):
     _fields_ = [("ptr", c_void_p), ("ld", c_int64), ("n_total", c_int64), ("fix_a", c_void_p), ("fix_b", c_void_p),
-                ("col", c_int32), ("width", c_int32), ("row_div", c_int32), ("mode", c_int32), ("f", c_int32), ("_pad", c_int32)]
+                ("col", c_int32), ("width", c_int32), ("row_div", c_int32), ("mode", c_int32), ("f", c_int32), ("dst_col", c_int32)]
 
 
 class ChainLayer(ctypes.Structure):
@@ -56,16 +56,17 @@ def _stream(t: Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def seg(t: Tensor, col: int, width: int, ld: Optional[int] = None, row_div: int = 1) -> ChainSeg:
-    """Row-major segment: value(row, c) = t[(row // row_div), c]."""
+def seg(t: Tensor, col: int, width: int, ld: Optional[int] = None, row_div: int = 1, dst_col: Optional[int] = None) -> ChainSeg:
+    """Row-major segment: value(row, c) = t[(row // row_div), c].  dst_col (wgrad only): where the segment's gradient
+    columns land in the output matrix (default: its own position in the virtual concatenation)."""
     return ChainSeg(ptr=_p(t), ld=ld if ld is not None else t.stride(-2), n_total=0, fix_a=None, fix_b=None, col=col,
-                    width=width, row_div=row_div, mode=0, f=1)
+                    width=width, row_div=row_div, mode=0, f=1, dst_col=col if dst_col is None else dst_col)
 
 
 def seg_lm(t: Tensor, col: int) -> ChainSeg:
     """Level-major grid encoding [L, N, F] as L*F columns."""
     L, N, F = t.shape
-    return ChainSeg(ptr=_p(t), ld=0, n_total=N, fix_a=None, fix_b=None, col=col, width=L * F, row_div=1, mode=1, f=F)
+    return ChainSeg(ptr=_p(t), ld=0, n_total=N, fix_a=None, fix_b=None, col=col, width=L * F, row_div=1, mode=1, f=F, dst_col=col)
 
 
 def layer(w: Tensor, bias: Optional[Tensor], in_col: int, out_col: int, act: int = ACT_NONE, transposed: bool = False,
@@ -111,22 +112,54 @@ def run_chain(segs, layers, buf_cols: int, n_rows: int, ref: Tensor) -> None:
         _lib.call("emer_mlp_chain", ctypes.byref(d), n_rows, _stream(ref))
 
 
-def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Optional[Tensor] = None):
-    """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments.  col0 [M] replaces dpre[:, 0]."""
+def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Optional[Tensor] = None,
+          out_w: Optional[Tensor] = None, out_b: Optional[Tensor] = None):
+    """dW [N,K], db [N] for dpre [M,N] against the (virtually concatenated) segments.  col0 [M] replaces dpre[:, 0].
+    out_w / out_b: ACCUMULATE into these instead of returning fresh tensors (out_w [N, >= K] with unit column stride;
+    segment s lands at columns dst_col_s..).  Returns (dW or None, db or None)."""
     M, N = dpre.shape
     dev = dpre.device
     with torch.cuda.device(dev):
         n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, k_total))
         ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
-        buf = torch.zeros((N * k_total + (N if want_bias else 0),), device=dev, dtype=torch.float32)  # one fill for both
-        dw = buf[:N * k_total].view(N, k_total)
-        db = buf[N * k_total:] if want_bias else None
+        need_b = want_bias and out_b is None
+        if out_w is None or need_b:
+            buf = torch.zeros((N * (k_total if out_w is None else 0) + (N if need_b else 0),), device=dev, dtype=torch.float32)  # one fill
+        dw = buf[:N * k_total].view(N, k_total) if out_w is None else None
+        db = (buf[-N:] if need_b else None)
+        tw = dw if out_w is None else out_w
+        tb = out_b if out_b is not None else db
+        assert tw.stride(1) == 1 and tw.dtype == torch.float32 and (tb is None or tb.is_contiguous())
         arr = (ChainSeg * MAX_SEGS)()
         for i, s in enumerate(segs):
             arr[i] = s
-        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(col0), arr, len(segs), _p(ws), _p(dw), _p(db),
-                  M, N, k_total, _stream(dpre))
+        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(col0), arr, len(segs), _p(ws), _p(tw), tw.stride(0),
+                  _p(tb) if want_bias else None, M, N, k_total, _stream(dpre))
     return dw, db
+
+
+def _sink(p) -> Optional[Tensor]:
+    """The tensor a parameter's gradient may be accumulated into directly: its existing fp32 ``.grad`` with unit
+    column stride.  This is what autograd's AccumulateGrad would do after the backward (``grad += dW``), fused into
+    the weight-gradient reduction -- it saves a zero-fill and an add launch per parameter.  Opt-in (``USE_GRAD_SINKS``):
+    parameter hooks are bypassed, so only a trainer that owns its gradient buffers should enable it."""
+    if not USE_GRAD_SINKS:
+        return None
+    g = getattr(p, "grad", None)
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or g.stride(-1) != 1:
+        return None
+    return g
+
+
+USE_GRAD_SINKS = False
+
+
+def _target(sink: Optional[Tensor], shape, dev):
+    """(tensor to accumulate into, value to hand back to autograd): the parameter's .grad (-> None) or fresh zeros."""
+    if sink is not None:
+        return sink, None
+    t = torch.zeros(shape, device=dev, dtype=torch.float32)
+    return t, t
 
 
 def _r4(x: int) -> int:
@@ -220,6 +253,7 @@ class _NeckFn(torch.autograd.Function):
         h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, any(ctx.needs_input_grad))
         ctx.save_for_backward(enc, W0, W1, h1, dens)
         ctx.n_out = n_out
+        ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1))
         if out1 is None:
             return out0, dens
         return out0, out1, dens
@@ -243,18 +277,20 @@ class _NeckFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call("emer_neck_bwd", _p(d0c), _p(d1c), _p(fa), _p(dens), _p(h1), L, F, N, _p(W0), _p(W1), n_out, None, _p(col0),
                       _p(dpre0), _p(denc), _stream(enc))
-        # weight gradients.  Output rows whose gradient is structurally zero (an unused semantic half) cost nothing.
+        # weight gradients, accumulated straight into the parameters' .grad when the trainer allows it (_sink).
+        # Output rows whose gradient is structurally zero (an unused semantic half) cost nothing.
+        sw0, sb0, sw1, sb1 = ctx.sinks
+        tw1, rw1 = _target(sw1, (n_out, 64), dev)
+        tb1, rb1 = _target(sb1, (n_out,), dev)
+        tw0, rw0 = _target(sw0, (64, L * F), dev)
+        tb0, rb0 = _target(sb0, (64,), dev)
         if d0c is None:
             d0c = torch.zeros((N, 64), device=dev, dtype=torch.float32)
-        dw1, db1 = wgrad(d0c, [seg(h1, 0, 64)], 64, col0=col0)
-        if n_out == 128:
-            if d1c is not None:
-                dw1b, db1b = wgrad(d1c, [seg(h1, 0, 64)], 64)
-            else:
-                dw1b, db1b = torch.zeros_like(dw1), torch.zeros_like(db1)
-            dw1, db1 = torch.cat([dw1, dw1b], 0), torch.cat([db1, db1b], 0)
-        dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], L * F)
-        return denc, dw0, db0, dw1, db1
+        wgrad(d0c, [seg(h1, 0, 64)], 64, col0=col0, out_w=tw1[:64], out_b=tb1[:64])
+        if n_out == 128 and d1c is not None:
+            wgrad(d1c, [seg(h1, 0, 64)], 64, out_w=tw1[64:], out_b=tb1[64:])
+        wgrad(dpre0, [seg_lm(enc, 0)], L * F, out_w=tw0, out_b=tb0)
+        return denc, rw0, rb0, rw1, rb1
 
 
 def neck(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
@@ -275,6 +311,7 @@ class _DensityMLPFn(torch.autograd.Function):
         dev = enc.device
         need_grad = any(ctx.needs_input_grad)
         ctx.fast = neck_supported(L, F, H, 1)
+        ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1))
         if ctx.fast:
             h, _, _, dens = _neck_fwd(enc, W0, B0, W1, B1, 1, need_grad)
             ctx.save_for_backward(enc, W0, W1, h, dens)
@@ -304,9 +341,14 @@ class _DensityMLPFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.call("emer_neck_bwd", None, None, _p(_c(ddens)), _p(dens), _p(h), L, F, N, _p(W0), _p(W1), 1, _p(dpre1), None,
                           _p(dpre0), _p(denc), _stream(enc))
-            dw1, db1 = wgrad(dpre1, [seg(h, 0, H)], H)
-            dw0, db0 = wgrad(dpre0, [seg_lm(enc, 0)], K0)
-            return denc, dw0, db0, dw1, db1
+            sw0, sb0, sw1, sb1 = ctx.sinks
+            tw1, rw1 = _target(sw1, (1, H), dev)
+            tb1, rb1 = _target(sb1, (1,), dev)
+            tw0, rw0 = _target(sw0, (H, K0), dev)
+            tb0, rb0 = _target(sb0, (H,), dev)
+            wgrad(dpre1, [seg(h, 0, H)], H, out_w=tw1, out_b=tb1)
+            wgrad(dpre0, [seg_lm(enc, 0)], K0, out_w=tw0, out_b=tb0)
+            return denc, rw0, rb0, rw1, rb1
         dpre1 = (_c(ddens).view(N, 1) * dens.view(N, 1).clamp(max=E15)).contiguous()
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
         denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
@@ -343,6 +385,7 @@ class _RgbHeadFn(torch.autograd.Function):
         a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
         ctx.S = S
+        ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
         ctx.fast = (H == 64 and NG == 64 and C == 3 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
         if ctx.fast:
             # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row GEMM instead of two 1M-row ones)
@@ -390,14 +433,23 @@ class _RgbHeadFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.call("emer_rgb_head_bwd", _p(_c(dout)), _p(out), _p(a1), _p(a2), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(dpre2),
                           _p(dpre1), _p(dpre0), _p(dgeo), _p(s1), _p(s0), _stream(g))
-            dw2, db2 = wgrad(dpre2, [seg(a2, 0, H)], H)
-            dw1ag, _ = wgrad(dpre1, [seg(a1, 0, H), seg(g, H, NG, ld=g.stride(0))], H + NG, want_bias=False)
-            dw0g, _ = wgrad(dpre0, [seg(g, 0, NG, ld=g.stride(0))], NG, want_bias=False)
-            # everything that multiplies the per-ray operand comes from the per-ray sums of dpre1 / dpre0
-            dw1 = torch.cat([dw1ag[:, :H], s1.t() @ hr, dw1ag[:, H:]], 1)
-            dw0 = torch.cat([s0.t() @ hr, dw0g], 1)
+            sw0, sb0, sw1, sb1, sw2, sb2 = ctx.sinks
+            tw2, rw2 = _target(sw2, (C, H), dev)
+            tb2, rb2 = _target(sb2, (C,), dev)
+            tw1, rw1 = _target(sw1, (H, H + K0), dev)
+            tb1, rb1 = _target(sb1, (H,), dev)
+            tw0, rw0 = _target(sw0, (H, K0), dev)
+            tb0, rb0 = _target(sb0, (H,), dev)
+            wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
+            # per-sample column blocks [A1 | . | geo] of dW1 and [. | geo] of dW0 ...
+            wgrad(dpre1, [seg(a1, 0, H, dst_col=0), seg(g, H, NG, ld=g.stride(0), dst_col=H + Kh)], H + NG, want_bias=False, out_w=tw1)
+            wgrad(dpre0, [seg(g, 0, NG, ld=g.stride(0), dst_col=Kh)], NG, want_bias=False, out_w=tw0)
+            # ... and everything that multiplies the per-ray operand from the per-ray sums of dpre1 / dpre0
+            # (8192-row GEMMs; colsum(s) is the bias gradient)
+            wgrad(s1, [seg(hr, 0, Kh, dst_col=H)], Kh, out_w=tw1, out_b=tb1)
+            wgrad(s0, [seg(hr, 0, Kh, dst_col=0)], Kh, out_w=tw0, out_b=tb0)
             dhray = torch.addmm(s1 @ W1[:, H:H + Kh], s0, W0[:, :Kh])
-            return dhray, dgeo, None, dw0, s0.sum(0), dw1, s1.sum(0), dw2, db2
+            return dhray, dgeo, None, rw0, rb0, rw1, rb1, rw2, rb2
         dpre2 = (_c(dout) * out * (1.0 - out)).contiguous()            # sigmoid'
         dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)

@@ -24,7 +24,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import ops
+from . import fused, ops
 from .prop_net import PropNetEstimator, get_proposal_requires_grad_fn
 from .radiance_field import DensityField, RadianceField, build_density_field, build_radiance_field_from_cfg
 from .render_utils import render_rays
@@ -160,6 +160,9 @@ class Trainer:
             p.to(self.device)
         self.estimator = PropNetEstimator(None, None).to(self.device)
         self.flat = FlatParams({"main": [self.model], "prop": self.props}, self.device)
+        # this trainer owns every gradient buffer (views of flat.grads, zeroed each step, no parameter hooks), so the
+        # fused heads may accumulate weight gradients straight into .grad (fused._sink)
+        fused.USE_GRAD_SINKS = True
         self.m = torch.zeros_like(self.flat.params)
         self.v = torch.zeros_like(self.flat.params)
         self.opt_steps = {"main": 0, "prop": 0}

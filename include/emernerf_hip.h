@@ -217,7 +217,8 @@ typedef struct emer_chain_seg {
     int64_t n_total;
     const float *fix_a;
     const float *fix_b;
-    int32_t col, width, row_div, mode, f, _pad;
+    int32_t col, width, row_div, mode, f;
+    int32_t dst_col; /* emer_wgrad_segmented only: column of dw where this segment's first column lands */
 } emer_chain_seg;
 
 /* out[:, out_col:out_col+N] (op)= act(in[:, in_col:in_col+K] @ W^T + bias), W element (n,k) = w[n*w_sn + k*w_sk].
@@ -250,10 +251,12 @@ int emer_mlp_chain(const emer_chain_desc *host_desc, int64_t n_rows, void *strea
 /* dW[N,K] += dpre[M,N]^T @ X[M,K], dbias[N] += colsum(dpre), with X given as up to EMER_CHAIN_MAX_SEGS
  * column segments (modes 0 and 1; a virtual concat).  col0 (may be NULL): [m] values that REPLACE column 0 of dpre
  * (the geometry-feature-0 gradient with the density gradient merged in, as emer_neck_bwd writes it).
- * workspace: emer_linear_bwd_workspace(m, n, k) floats. */
+ * dw has row stride ld_dw and segment s lands at columns [dst_col_s, dst_col_s + width_s) -- so the gradient of a
+ * virtually concatenated operand can be ACCUMULATED straight into column blocks of a wider weight-gradient matrix
+ * (e.g. a parameter's .grad).  workspace: emer_linear_bwd_workspace(m, n, k) floats. */
 int emer_wgrad_segmented(const float *dpre, int64_t ld_dpre, const float *col0,
                          const emer_chain_seg *host_segs, int32_t n_segs, float *workspace, float *dw,
-                         float *dbias, int64_t m, int32_t n, int32_t k, void *stream);
+                         int64_t ld_dw, float *dbias, int64_t m, int32_t n, int32_t k, void *stream);
 
 /* ---- register-resident fused heads (hidden width 64; csrc/mlp_fused.hip) ------------------------------
  * The per-sample hot heads of RadianceField / DensityField as single kernels in which a wave keeps its 16 rows

@@ -129,3 +129,48 @@ def test_rgb_head(hip_lib, R, S, Kh, NG, ld):
     _close("dfeats", fd.grad, f64.grad, rtol=2e-4, scale_atol=5e-5)
     for i, (a, b) in enumerate(zip(wd, w64)):
         _close(f"dW{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+
+
+def test_grad_sinks_equal_autograd_accumulation(hip_lib):
+    """fused.USE_GRAD_SINKS: weight gradients accumulated straight into an existing .grad == what autograd's
+    AccumulateGrad produces (old .grad + dW), for the neck, the proposal density MLP and the rgb head."""
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    R, S, Kh, L, Fe = 6, 32, 43, 16, 2
+    N = R * S
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(dev)
+
+    def params():
+        gg = torch.Generator().manual_seed(11)
+        r = lambda *shape, s=1.0: torch.nn.Parameter((torch.randn(*shape, generator=gg) * s).to(dev))
+        return {"n": [r(64, L * Fe, s=0.2), r(64, s=0.1), r(128, 64, s=0.1), r(128, s=0.1)],
+                "d": [r(64, 8, s=0.3), r(64, s=0.1), r(1, 64, s=0.1), r(1, s=0.1)],
+                "c": [r(64, Kh + 64, s=0.1), r(64, s=0.1), r(64, 64 + Kh + 64, s=0.1), r(64, s=0.1), r(3, 64, s=0.1), r(3, s=0.1)]}
+
+    enc, enc1, hray, geo = mk(L, N, Fe), mk(8, N, 1), mk(R, Kh), mk(N, 64)
+    w = [mk(N, 64), mk(N), mk(N), mk(N, 3)]
+
+    def run(P):
+        geo_o, sem_o, dens = fused.neck(enc, *P["n"])
+        d2 = fused.density_mlp(enc1, *P["d"])
+        rgb = fused.rgb_head(hray, geo, S, *P["c"])
+        ((geo_o * w[0]).sum() + (dens * w[1]).sum() + (d2 * w[2]).sum() + (rgb * w[3]).sum()).backward()
+
+    ref = params()
+    run(ref)  # plain autograd: .grad created by AccumulateGrad
+    got = params()
+    pre = {}
+    for k, ps in got.items():
+        for i, p in enumerate(ps):
+            p.grad = torch.full_like(p, 0.25)  # a pre-existing gradient the sinks must ADD to
+            pre[(k, i)] = p.grad.data_ptr()
+    fused.USE_GRAD_SINKS = True
+    try:
+        run(got)
+    finally:
+        fused.USE_GRAD_SINKS = False
+    for k in ref:
+        for i, (a, b) in enumerate(zip(got[k], ref[k])):
+            assert a.grad.data_ptr() == pre[(k, i)], "gradient was not accumulated in place"
+            _close(f"{k}{i}", a.grad - 0.25, b.grad, rtol=2e-4, scale_atol=5e-5)
