@@ -146,11 +146,12 @@ __device__ __forceinline__ void cell_of(const LevelInfo &li, const float (&xv)[D
 
 // slice plan of the owner-computes backward (described further down); the forward kernel emits the masks
 struct SlicePlan {
-    uint32_t shift[EMER_MAX_LEVELS];     // slice = idx >> shift (contiguous index ranges)
-    uint32_t n_slices[EMER_MAX_LEVELS];  // <= 64
+    uint32_t shift[EMER_MAX_LEVELS];     // slice = idx >> shift (contiguous index ranges that fit the LDS)
+    uint32_t n_slices[EMER_MAX_LEVELS];
+    uint32_t gsub[EMER_MAX_LEVELS];      // log2(slices per bitmap group): bitmap row = slice >> gsub (<= 64 rows per level)
     uint32_t n_ranges[EMER_MAX_LEVELS];  // dense levels: the sample stream is also cut in ranges (2-D decomposition)
     uint32_t max_local;                  // largest slice (entries)
-    uint32_t ok;                         // 0 when some level would need more than 64 slices
+    uint32_t ok;                         // 0 when some level would need more than 64 bitmap groups of 64 slices
     uint8_t xcd_of[EMER_MAX_LEVELS];     // backward: the XCD (0..7) that owns each level (cost-balanced)
     uint32_t items_per_xcd[8];           // backward work items ((level, slice, range) triples) on each XCD's list
 };
@@ -158,8 +159,9 @@ struct SlicePlan {
 static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
     // fitted to tools/kbench.py --per-level on MI355X (1M samples, ms on one XCD): coarse levels pay for
     // same-address LDS adds (many samples per cell), dense levels for the ordered scan + run reduction
-    if (g->hashed[l]) return 0.28f + 36.0f / (float)g->res[l];
-    return 0.22f + 0.13f * log2f(1.0f + (float)p.n_slices[l]);
+    const float rescans = (float)(1u << p.gsub[l]);
+    if (g->hashed[l]) return (0.28f + 36.0f / (float)g->res[l]) * rescans;
+    return (0.22f + 0.13f * log2f(1.0f + (float)p.n_slices[l])) * rescans;
 }
 
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
@@ -167,13 +169,15 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     const uint32_t F = g->n_features;
     const uint32_t max_entries = (128u * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
     p.max_local = 0; p.ok = 1;
-    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) { p.shift[l] = 0; p.n_slices[l] = 0; p.n_ranges[l] = 1; }
+    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) { p.shift[l] = 0; p.n_slices[l] = 0; p.n_ranges[l] = 1; p.gsub[l] = 0; }
     for (uint32_t l = 0; l < g->n_levels; ++l) {
         const uint32_t size = g->size[l];
         uint32_t k = 6;
         if (g->hashed[l]) {
-            // the hash spreads samples evenly: 64 slices, one pass over all samples each
+            // the hash spreads samples evenly: 64 slices (more when 1/64 of the table does not fit the LDS), one pass
+            // over all samples each
             while ((1ull << k) * 64ull < size) ++k;
+            while ((1u << k) > max_entries) --k;
             p.n_ranges[l] = 1;
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
@@ -185,13 +189,17 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         }
         p.shift[l] = k;
         p.n_slices[l] = (uint32_t)ceil_div(size, 1ll << k);
+        // The forward emits at most 64 bitmaps per level.  A table with more slices shares one bitmap among 2^gsub
+        // neighbouring slices; their owners scan the same bitmap and keep only the hits of their own slice.
+        while (((p.n_slices[l] + (1u << p.gsub[l]) - 1u) >> p.gsub[l]) > 64u) ++p.gsub[l];
         const uint32_t local = 1u << k;
-        if (local > max_entries || p.n_slices[l] > 64) p.ok = 0;
+        if (local > max_entries || p.gsub[l] > 6u) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
     }
     // Levels -> XCDs, longest-processing-time first.  A level stays on ONE XCD so that its streamed inputs
     // (x, dout, bitmaps) are fetched into a single L2.  Relative costs measured on MI355X at 1M samples
-    // (tools/probe_bwd.py): hashed level ~1, dense levels between 0.4 and 1.9 growing with the slab count.
+    // (tools/probe_bwd.py): hashed level ~1, dense levels between 0.4 and 1.9 growing with the slab count; a level
+    // whose slices share bitmaps re-examines every candidate 2^gsub times.
     float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool placed[EMER_MAX_LEVELS] = {};
@@ -211,8 +219,12 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     return p;
 }
 
+// bitmap row (group of 2^gsub slices) an entry belongs to
 __device__ __forceinline__ uint32_t slice_of(const SlicePlan &p, uint32_t level, uint32_t idx) {
-    return idx >> p.shift[level];
+    return idx >> (p.shift[level] + p.gsub[level]);
+}
+__device__ __forceinline__ uint32_t bitmap_rows(const SlicePlan &p, uint32_t level) {
+    return (p.n_slices[level] + (1u << p.gsub[level]) - 1u) >> p.gsub[level];
 }
 
 
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
     }
     if (masks) {  // the whole wave takes part in the transpose (tail lanes carry an empty mask)
         const int lane = threadIdx.x & 63;
-        store_slice_bitmaps(masks, mask, level, plan.n_slices[level], n - lane, (N + 63) >> 6, lane);
+        store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), n - lane, (N + 63) >> 6, lane);
     }
 }
 
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     __syncthreads();
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
-    const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + slice) * n_words;  // this slice: 1 bit per sample
+    const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + (slice >> plan.gsub[level])) * n_words;  // 1 bit per sample
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     // Every lane holds one 64-sample word of the bitmap; a trip of the workgroup covers 1024 words.  The next
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_gr
         }
     }
     const int lane = threadIdx.x & 63;
-    store_slice_bitmaps(masks, mask, level, plan.n_slices[level], n - lane, (N + 63) >> 6, lane);
+    store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), n - lane, (N + 63) >> 6, lane);
 }
 
 // ------------------------------------------------------------------------- backward (input)
