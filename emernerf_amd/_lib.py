@@ -79,6 +79,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime (libamdhip64) and the process must end up with exactly one -- if this
+    # library were loaded before torch, it would bind the system copy and see no device once torch initialises its own
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EmerError(
             f"{LIB_PATH} not found. Build it with `python -m emernerf_amd._build` (hipcc, gfx950). "

@@ -206,7 +206,11 @@ class Trainer:
         loss = self.losses(results, data)
         (loss * self.loss_scale).backward()
         if self.world_size > 1:
-            dist.all_reduce(self.flat.grads)  # the single RCCL collective of the step (sum; 1/W folded into Adam)
+            # the single RCCL collective of the step (sum; 1/W folded into Adam).  Proposal-net gradients exist only on
+            # the steps that train them (same schedule on every rank), so the other steps exchange the main range only
+            # (50 MB instead of 90 MB at the metric configuration)
+            a, b = self.flat.ranges["main"]
+            dist.all_reduce(self.flat.grads if prop_grad else self.flat.grads[a:b])
         lr = self.lr * lr_factor(step, self.num_iters)
         if prop_grad:
             self._adam("prop", lr)
