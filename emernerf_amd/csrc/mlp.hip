@@ -694,13 +694,31 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
 // accumulators of 32x32); U row pairs of loads are in flight ahead of the matrix pipe.  The four waves are summed through
 // LDS once at the end.  Column k of the virtual concatenation maps to "base + m * stride" for row-major and level-major
 // segments alike, so the per-lane addressing is hoisted out of the loop.
-template <int NT, int KT>
+template <int W> struct VecF;
+template <> struct VecF<1> { using T = float; };
+template <> struct VecF<2> { using T = float2; };
+template <> struct VecF<4> { using T = float4; };
+template <int W> __device__ __forceinline__ void vec_load(const float *p, float (&v)[W]) {
+    typename VecF<W>::T t = *reinterpret_cast<const typename VecF<W>::T *>(p);
+    const float *f = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = f[i];
+}
+
+// VEC = false: tile t of an operand holds columns 32 t + j (one dword per tile per row).
+// VEC = true : tile t holds columns T j + t (T = tiles of that operand) -- the assignment of columns to MFMA tiles is
+//              free, and with this one a lane's T columns of a row are CONTIGUOUS: one 4*T-byte load per operand per row
+//              (a wave instruction covers two full 128*T-byte row pieces) instead of T dword loads.  Needs every
+//              segment boundary and leading dimension to be a multiple of T.
+template <int NT, int KT, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
                                                            float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
                                                            int32_t rows_per_block, int want_bias) {
     // bytes in flight decide the speed (HBM needs ~60 KB per CU): 2 x U row pairs of (NT + KT) x 256 B per wave.  The widest
     // tiles run one wave per SIMD, so they prefetch deepest.
     constexpr int U = (NT * KT >= 6) ? 12 : (NT * KT >= 4 ? 8 : 4), KP = KT * 32;
+    constexpr int AG = VEC ? 1 : NT, AW = VEC ? NT : 1;  // A operand: AG loads of AW floats per row
+    constexpr int BG = VEC ? 1 : KT, BW = VEC ? KT : 1;
     __shared__ float red[NT * 32 * KP + NT * 32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, ms = lane >> 5;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
@@ -709,31 +727,38 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
     const int64_t w_begin = r_begin + (int64_t)wave * rpw;
     const int64_t w_end = (w_begin + rpw < r_end) ? w_begin + rpw : r_end;
 
-    const float *ap[NT];
-    int64_t ast[NT];
-    bool aok[NT];
+    // first column of load group q: VEC: q = 0, columns T j .. T j + T - 1;  scalar: column 32 q + j
+    const float *ap[AG];
+    int64_t ast[AG];
+    bool aok[AG];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { aok[t] = t * 32 + j < N; ap[t] = dpre + (aok[t] ? t * 32 + j : 0); ast[t] = ldd; }
-    if (sx.col0 && j == 0) { ap[0] = sx.col0; ast[0] = 1; }  // column 0 of dPre comes from its own array (trunc_exp side gradient merged)
-    const float *bp[KT];
-    int64_t bst[KT];
-    bool bok[KT];
+    for (int q = 0; q < AG; ++q) {
+        const int32_t n0 = VEC ? NT * j : q * 32 + j;
+        aok[q] = n0 < N;  // VEC: N is a multiple of NT (host check)
+        ap[q] = dpre + (aok[q] ? n0 : 0);
+        ast[q] = ldd;
+    }
+    const bool c0 = sx.col0 != nullptr && j == 0;  // column 0 of dPre comes from its own array (trunc_exp side gradient merged)
+    if (!VEC && c0) { ap[0] = sx.col0; ast[0] = 1; }
+    const float *bp[BG];
+    int64_t bst[BG];
+    bool bok[BG];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        const int32_t kk = t * 32 + j;
-        bok[t] = false; bp[t] = sx.s[0].ptr; bst[t] = 0;
+    for (int q = 0; q < BG; ++q) {
+        const int32_t kk = VEC ? KT * j : q * 32 + j;
+        bok[q] = false; bp[q] = sx.s[0].ptr; bst[q] = 0;
 #pragma unroll
         for (int sg = 0; sg < EMER_CHAIN_MAX_SEGS; ++sg) {
             if (sg < sx.n && kk < K && kk >= sx.s[sg].col && kk < sx.s[sg].col + sx.s[sg].width) {
                 const int32_t c = kk - sx.s[sg].col;
-                bok[t] = true;
+                bok[q] = true;
                 if (sx.s[sg].mode == 1) {
                     const int32_t f = sx.s[sg].f, lv = c / f;
-                    bp[t] = sx.s[sg].ptr + (int64_t)lv * sx.s[sg].n_total * f + (c - lv * f);
-                    bst[t] = f;
+                    bp[q] = sx.s[sg].ptr + (int64_t)lv * sx.s[sg].n_total * f + (c - lv * f);
+                    bst[q] = f;
                 } else {
-                    bp[t] = sx.s[sg].ptr + c;
-                    bst[t] = sx.s[sg].ld;
+                    bp[q] = sx.s[sg].ptr + c;
+                    bst[q] = sx.s[sg].ld;
                 }
             }
         }
@@ -755,9 +780,24 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
             const int64_t m = m0 + 2 * u + ms;
             const bool ok = m < w_end;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) av[u][t] = (ok && aok[t]) ? ap[t][m * ast[t]] : 0.0f;
+            for (int q = 0; q < AG; ++q) {
+                float v[AW];
 #pragma unroll
-            for (int t = 0; t < KT; ++t) bv[u][t] = (ok && bok[t]) ? bp[t][m * bst[t]] : 0.0f;
+                for (int i = 0; i < AW; ++i) v[i] = 0.0f;
+                if (ok && aok[q]) vec_load<AW>(ap[q] + m * ast[q], v);
+#pragma unroll
+                for (int i = 0; i < AW; ++i) av[u][q * AW + i] = v[i];
+            }
+            if (VEC && c0 && ok) av[u][0] = sx.col0[m];
+#pragma unroll
+            for (int q = 0; q < BG; ++q) {
+                float v[BW];
+#pragma unroll
+                for (int i = 0; i < BW; ++i) v[i] = 0.0f;
+                if (ok && bok[q]) vec_load<BW>(bp[q] + m * bst[q], v);
+#pragma unroll
+                for (int i = 0; i < BW; ++i) bv[u][q * BW + i] = v[i];
+            }
         }
     };
     load(w_begin, ac, bc);
@@ -780,7 +820,8 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
             for (int t = 0; t < KT; ++t) bc[u][t] = bn[u][t];
         }
     }
-    // ---- sum the four waves through LDS (wave 0 writes, 1..3 add in turn), then one coalesced store of the partial
+    // ---- sum the four waves through LDS (wave 0 writes, 1..3 add in turn), then one coalesced store of the partial.
+    // red is indexed by ACTUAL (n, k): tile (a, b), element (i, j)  ->  VEC: n = NT i + a, k = KT j + b;  else n = 32 a + i, k = 32 b + j
 #pragma unroll
     for (int a = 0; a < NT; ++a) bsum[a] += __shfl_down(bsum[a], 32, 64);
     for (int w = 0; w < 4; ++w) {
@@ -792,12 +833,13 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const int i = (v & 3) + 8 * (v >> 2) + 4 * ms;
-                        float *q = red + (a * 32 + i) * KP + b * 32 + j;
+                        const int n = VEC ? NT * i + a : a * 32 + i, k = VEC ? KT * j + b : b * 32 + j;
+                        float *q = red + n * KP + k;
                         *q = (w == 0) ? acc[a][b][v] : *q + acc[a][b][v];
                     }
                 }
                 if (ms == 0) {
-                    float *q = red + NT * 32 * KP + a * 32 + j;
+                    float *q = red + NT * 32 * KP + (VEC ? NT * j + a : a * 32 + j);
                     *q = (w == 0) ? bsum[a] : *q + bsum[a];
                 }
             }
@@ -883,12 +925,25 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
     bool stream_ok = n <= 64 && k <= 128;
     for (int s = 0; s < n_segs; ++s) stream_ok = stream_ok && (segs[s].mode == 1 || segs[s].row_div == 1);
     if (stream_ok) {  // no per-ray operand: operands stream straight into the MFMA layout
-        const int NT = n <= 32 ? 1 : 2, KT = (k + 31) / 32;
+        const int NT = n <= 32 ? 1 : 2;
+        int KT = (k + 31) / 32;
         const dim3 sgrid((uint32_t)n_row_blocks);
-#define EMER_WS(A, B) hipLaunchKernelGGL((wgrad_stream_kernel<A, B>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
-        if (NT == 1) { if (KT == 1) EMER_WS(1, 1); else if (KT == 2) EMER_WS(1, 2); else if (KT == 3) EMER_WS(1, 3); else EMER_WS(1, 4); }
-        else         { if (KT == 1) EMER_WS(2, 1); else if (KT == 2) EMER_WS(2, 2); else if (KT == 3) EMER_WS(2, 3); else EMER_WS(2, 4); }
+        // vector loads (one per operand per row) when every boundary is a multiple of the vector width
+        const int KTv = KT == 3 ? 4 : KT;
+        bool vec = (n % NT == 0) && (ldd % NT == 0) && ((uintptr_t)dpre % (4 * NT) == 0) && (k % KTv == 0) && (NT * KTv > 1);
+        for (int s = 0; s < n_segs && vec; ++s) {
+            const emer_chain_seg &S = segs[s];
+            vec = (S.col % KTv == 0) && (S.width % KTv == 0) && ((uintptr_t)S.ptr % (4 * KTv) == 0) &&
+                  (S.mode == 1 ? (S.f % KTv == 0) : (S.ld % KTv == 0));
+        }
+        if (vec) KT = KTv;
+#define EMER_WS(A, B) do { if (vec) hipLaunchKernelGGL((wgrad_stream_kernel<A, B, true>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0); \
+                           else hipLaunchKernelGGL((wgrad_stream_kernel<A, B, false>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0); } while (0)
+#define EMER_WS3(A) hipLaunchKernelGGL((wgrad_stream_kernel<A, 3, false>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+        if (NT == 1) { if (KT == 1) EMER_WS(1, 1); else if (KT == 2) EMER_WS(1, 2); else if (KT == 3) EMER_WS3(1); else EMER_WS(1, 4); }
+        else         { if (KT == 1) EMER_WS(2, 1); else if (KT == 2) EMER_WS(2, 2); else if (KT == 3) EMER_WS3(2); else EMER_WS(2, 4); }
 #undef EMER_WS
+#undef EMER_WS3
         if (int rc = check_launch("wgrad_stream")) return rc;
         const int64_t stride = (int64_t)n * k + n;
         hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st,
