@@ -290,14 +290,17 @@ static inline uint32_t dw_reduce_splits(int32_t n_blocks, int64_t stride) {
     return (uint32_t)(s < 1 ? 1 : s);
 }
 
-constexpr int32_t kDwRowsPerBlock = 1024;
-// rows per workgroup of the dW kernels: 1024 for the per-sample heads (1M rows -> 1024 workgroups), but never fewer
-// than ~512 workgroups' worth of parallelism for per-ray heads (8192 rows would otherwise occupy 8 CUs)
-static inline int32_t dw_rows_per_block(int64_t m) {
+// Rows per workgroup of the dW kernels.  Big tiles hold few waves per SIMD (their accumulators fill the register
+// file), so they want long row ranges (fewer partials, longer streams): 64x128 -> 4096 rows, 64 x (<=64) -> 2048, n <= 32 ->
+// 1024.  Never fewer than ~512 workgroups' worth of parallelism for per-ray heads (8192 rows would otherwise occupy 8
+// CUs).  emer_linear_bwd_workspace uses the same rule.
+static inline int32_t dw_rows_per_block(int64_t m, int32_t n, int32_t k) {
+    const int tiles = ((n + 31) / 32) * ((k + 31) / 32);
+    const int64_t cap = tiles >= 6 ? 4096 : (n > 32 ? 2048 : 1024);
     int64_t r = (m + 511) / 512;
     r = (r + 31) / 32 * 32;  // 32-row LDS tiles
     if (r < 64) r = 64;
-    if (r > kDwRowsPerBlock) r = kDwRowsPerBlock;
+    if (r > cap) r = cap;
     return (int32_t)r;
 }
 
@@ -333,7 +336,7 @@ extern "C" int emer_linear_fwd(const float *x, int64_t ldx, const float *w, cons
 // floats of workspace emer_linear_bwd needs for the dW / dbias partial sums (0 when dw is not requested)
 extern "C" int64_t emer_linear_bwd_workspace(int64_t m, int32_t n, int32_t k) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    return ceil_div(m, dw_rows_per_block(m)) * ((int64_t)n * k + n);
+    return ceil_div(m, dw_rows_per_block(m, n, k)) * ((int64_t)n * k + n);
 }
 
 extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, int64_t ldy, const float *x, int64_t ldx,
@@ -359,7 +362,7 @@ extern "C" int emer_linear_bwd(const float *dy, int64_t lddy, const float *y, in
         EMER_REQUIRE(x && ldx >= k && workspace, "linear_bwd: dw requested but x / workspace missing or ldx too small");
         const int32_t NG = n <= 32 ? 32 : 64;
         const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
-        const int32_t rpb = dw_rows_per_block(m);
+        const int32_t rpb = dw_rows_per_block(m, n, k);
         const int32_t n_row_blocks = (int32_t)ceil_div(m, rpb);
         const dim3 grid((uint32_t)n_row_blocks, (uint32_t)ceil_div(k, KG), (uint32_t)ceil_div(n, NG));
 #define EMER_DW(A, B) hipLaunchKernelGGL((linear_dw_kernel<A, B>), grid, dim3(256), 0, st, dy, lddy, ya, ldy, act, d_aux_density, \
@@ -920,7 +923,7 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
     hipStream_t st = as_stream(stream);
     const int32_t NG = n <= 32 ? 32 : 64;
     const int32_t KG = k <= 32 ? 32 : (k <= 64 ? 64 : (k <= 128 ? 128 : 256));
-    const int32_t rpb = dw_rows_per_block(m);
+    const int32_t rpb = dw_rows_per_block(m, n, k);
     const int32_t n_row_blocks = (int32_t)ceil_div(m, rpb);
     bool stream_ok = n <= 64 && k <= 128;
     for (int s = 0; s < n_segs; ++s) stream_ok = stream_ok && (segs[s].mode == 1 || segs[s].row_div == 1);
