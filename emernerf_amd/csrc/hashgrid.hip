@@ -75,26 +75,55 @@ __device__ __forceinline__ LevelInfo level_info(const emer_grid_desc &g, uint32_
     return LevelInfo{g.scale[l], g.res[l], g.size[l], g.offset[l], g.hashed[l]};
 }
 
-// XCD-aware block -> (level, chunk) map (see file header).  Returns false for padding blocks.
-__device__ __forceinline__ bool map_block(uint32_t bid, uint32_t L, uint32_t n_chunks, uint32_t &level, uint32_t &chunk) {
-    const uint32_t full_groups = L >> 3, rem = L & 7u;
+// XCD-aware block -> (level, chunk) map (see file header).  The (level, chunk) space is walked level-major and cut into
+// eight CONTIGUOUS, equal-COST segments, one per XCD (block b runs on XCD b % 8): an XCD touches two or three levels at
+// most, so a level's table stays in one or two L2s, and the finer levels -- whose gathers miss L1 more often -- get
+// proportionally fewer samples per XCD.  Returns false for padding blocks.
+struct LevelMap {
+    uint32_t start[8], count[8];
+};
+__device__ __forceinline__ bool map_block(uint32_t bid, const LevelMap &lm, uint32_t n_chunks, uint32_t &level, uint32_t &chunk) {
     const uint32_t x = bid & 7u, j = bid >> 3;
-    const uint32_t blocks_full = full_groups * n_chunks;  // per XCD
-    if (j < blocks_full) {
-        const uint32_t k = j / n_chunks;
-        chunk = j - k * n_chunks;
-        level = k * 8u + x;
-        return true;
-    }
-    const uint32_t id2 = (j - blocks_full) * 8u + x;  // leftover levels: spread over all XCDs
-    if (id2 >= rem * n_chunks) return false;
-    chunk = id2 / rem;
-    level = full_groups * 8u + (id2 - chunk * rem);
+    if (j >= lm.count[x]) return false;
+    const uint32_t idx = lm.start[x] + j;
+    level = idx / n_chunks;
+    chunk = idx - level * n_chunks;
     return true;
 }
-static inline uint32_t grid_blocks(uint32_t L, uint32_t n_chunks) {
-    const uint32_t full_groups = L >> 3, rem = L & 7u;
-    return 8u * full_groups * n_chunks + (uint32_t)ceil_div((int64_t)rem * n_chunks, 8) * 8u;
+// relative gather cost of a level per sample, fitted to tools/kbench.py --per-level on MI355X: flat up to res ~150,
+// then ~+35 % per doubling of the resolution (adjacent ray samples stop sharing cache lines)
+static inline float fwd_level_cost(const emer_grid_desc *g, uint32_t l) {
+    const float r = (float)g->res[l];
+    float c = 1.0f + 0.35f * log2f(r / 150.0f);
+    return c < 1.0f ? 1.0f : (c > 2.1f ? 2.1f : c);
+}
+static LevelMap make_level_map(const emer_grid_desc *g, uint32_t n_chunks, uint32_t *blocks_out) {
+    LevelMap lm;
+    const uint32_t L = g->n_levels;
+    double total = 0.0;
+    for (uint32_t l = 0; l < L; ++l) total += fwd_level_cost(g, l);
+    // boundary of segment x: smallest position whose cumulative cost reaches x/8 of the total
+    uint64_t bound[9];
+    bound[0] = 0; bound[8] = (uint64_t)L * n_chunks;
+    for (int x = 1; x < 8; ++x) {
+        const double target = total * x / 8.0;
+        double cum = 0.0;
+        uint64_t pos = bound[8];
+        for (uint32_t l = 0; l < L; ++l) {
+            const double c = fwd_level_cost(g, l);
+            if (cum + c >= target) { pos = (uint64_t)l * n_chunks + (uint64_t)((target - cum) / c * n_chunks); break; }
+            cum += c;
+        }
+        bound[x] = pos < bound[x - 1] ? bound[x - 1] : pos;
+    }
+    uint32_t mx = 0;
+    for (int x = 0; x < 8; ++x) {
+        lm.start[x] = (uint32_t)bound[x];
+        lm.count[x] = (uint32_t)(bound[x + 1] - bound[x]);
+        if (lm.count[x] > mx) mx = lm.count[x];
+    }
+    *blocks_out = mx * 8u;
+    return lm;
 }
 
 template <int D>
@@ -256,10 +285,10 @@ __device__ __forceinline__ void store_slice_bitmaps(uint64_t *__restrict__ bitma
 template <int D, int F, typename PT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc g, const float *__restrict__ x,
                                                            const PT *__restrict__ params, float *__restrict__ out,
-                                                           int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks,
+                                                           int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks, const LevelMap lmap,
                                                            const SlicePlan plan, uint64_t *__restrict__ masks) {
     uint32_t level, chunk;
-    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    if (!map_block(blockIdx.x, lmap, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
     const bool valid = n < N;
     if (!valid && !masks) return;
@@ -356,9 +385,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
 template <int D, int F, typename GT>
 __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_grid_desc g, const float *__restrict__ x,
                                                                   const float *__restrict__ dout, int64_t sn, int64_t sl,
-                                                                  GT *__restrict__ grad, int64_t N, uint32_t n_chunks) {
+                                                                  GT *__restrict__ grad, int64_t N, uint32_t n_chunks, const LevelMap lmap) {
     uint32_t level, chunk;
-    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    if (!map_block(blockIdx.x, lmap, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
     if (n >= N) return;
     const LevelInfo li = level_info(g, level);
@@ -687,9 +716,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 template <int D>
 __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_grid_desc g, const SlicePlan plan,
                                                                    const float *__restrict__ x, uint64_t *__restrict__ masks,
-                                                                   int64_t N, uint32_t n_chunks) {
+                                                                   int64_t N, uint32_t n_chunks, const LevelMap lmap) {
     uint32_t level, chunk;
-    if (!map_block(blockIdx.x, g.n_levels, n_chunks, level, chunk)) return;
+    if (!map_block(blockIdx.x, lmap, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
     const LevelInfo li = level_info(g, level);
     uint64_t mask = 0;
@@ -798,17 +827,18 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     EMER_REQUIRE(x && params && out, "hashgrid_fwd: null pointer");
     EMER_REQUIRE(param_dtype == EMER_F32 || param_dtype == EMER_F16, "hashgrid_fwd: bad param_dtype %d", param_dtype);
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
-    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    uint32_t blocks = 0;
+    const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     const SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice masks requested but a level needs more than 64 LDS slices");
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
         if (param_dtype == EMER_F32)
             hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const float *)params, out, sn, sl, n, n_chunks, plan, slice_masks);
+                               (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
         else
             hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const __half *)params, out, sn, sl, n, n_chunks, plan, slice_masks);
+                               (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
         return check_launch("hashgrid_fwd");
     });
 }
@@ -822,16 +852,17 @@ extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x,
     EMER_REQUIRE(grad_dtype == EMER_F32 || grad_dtype == EMER_F16, "hashgrid_bwd_params: bad grad_dtype %d", grad_dtype);
     EMER_REQUIRE(!(grad_dtype == EMER_F16 && (g->n_features & 1u)), "hashgrid_bwd_params: fp16 gradients need an even n_features");
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
-    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    uint32_t blocks = 0;
+    const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
         if (grad_dtype == EMER_F32) {
             hipLaunchKernelGGL((hashgrid_bwd_params_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g,
-                               x, dout, sn, sl, (float *)grad, n, n_chunks);
+                               x, dout, sn, sl, (float *)grad, n, n_chunks, lmap);
         } else {
             if constexpr (F % 2 == 0)
                 hipLaunchKernelGGL((hashgrid_bwd_params_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream),
-                                   *g, x, dout, sn, sl, (__half *)grad, n, n_chunks);
+                                   *g, x, dout, sn, sl, (__half *)grad, n, n_chunks, lmap);
         }
         return check_launch("hashgrid_bwd_params");
     });
@@ -853,11 +884,12 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
     const SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 64 LDS slices");
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
-    const uint32_t blocks = grid_blocks(g->n_levels, n_chunks);
+    uint32_t blocks = 0;
+    const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto) {
         constexpr int D = decltype(d)::value;
         hipLaunchKernelGGL((hashgrid_slice_masks_kernel<D>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, plan, x, slice_masks, n,
-                           n_chunks);
+                           n_chunks, lmap);
         return check_launch("hashgrid_slice_masks");
     });
 }
