@@ -28,8 +28,8 @@ namespace emer {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kFThreads = 384;  // 6 waves; two workgroups per CU = 3 waves per SIMD = 170 VGPRs each
-constexpr int kFWaves = kFThreads / 64;
+constexpr int kFThreads = 384;  // rgb head: 6 waves; two workgroups per CU = 3 waves per SIMD = 170 VGPRs each
+constexpr int kNThreads = 512;  // neck: 8 waves; two workgroups per CU = 4 waves per SIMD = 128 VGPRs each
 constexpr int kNeckChunk = 8;  // consecutive 16-row tiles a wave processes per work item
 
 struct WSrc {
@@ -186,7 +186,7 @@ struct NeckFwdArgs {
 
 // NT1 = output tiles of the second layer: 4 (64 features), 8 (128 features), 1 (density only: 1 feature -> trunc_exp)
 template <int KT0, int F, int NT1>
-__global__ __launch_bounds__(kFThreads, 3) void neck_fwd_kernel(const NeckFwdArgs a) {
+__global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int P0 = KT0 * 16 + 4, P1 = 64 + 4;
     float *w0l = smem, *w1l = w0l + 64 * P0, *b0l = w1l + NT1 * 16 * P1, *b1l = b0l + 64;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kFThreads, 3) void neck_fwd_kernel(const NeckFwdArg
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const float *w0p = w0l + m * P0 + 4 * g, *w1p = w1l + m * P1 + 4 * g;
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
-    for (int64_t c = (int64_t)blockIdx.x * kFWaves + wave; c < n_chunks; c += (int64_t)gridDim.x * kFWaves) {
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int64_t t0 = c * kNeckChunk;
         f32x4 xn[KT0];
         ld_lm<KT0, F>(a.enc, a.n, a.n_levels, t0 * 16 + m, t0 * 16 + m < a.n, g, xn);
@@ -253,7 +253,7 @@ struct NeckBwdArgs {
 
 // KT1 = input tiles of the transposed second layer: 4 / 8 (neck), 0 (density mode: rank-1, no MFMA)
 template <int KT0, int F, int KT1>
-__global__ __launch_bounds__(kFThreads, 3) void neck_bwd_kernel(const NeckBwdArgs a) {
+__global__ __launch_bounds__(kNThreads, 4) void neck_bwd_kernel(const NeckBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K1 = (KT1 == 0 ? 1 : KT1) * 16;
     constexpr int P1 = K1 + 4, P0 = 64 + 4;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kFThreads, 3) void neck_bwd_kernel(const NeckBwdArg
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const float *w1p = w1l + m * P1 + 4 * g, *w0p = w0l + m * P0 + 4 * g;
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
-    for (int64_t c = (int64_t)blockIdx.x * kFWaves + wave; c < n_chunks; c += (int64_t)gridDim.x * kFWaves) {
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int64_t t0 = c * kNeckChunk;
         for (int j = 0; j < kNeckChunk && t0 + j < n_tiles; ++j) {
             const int64_t row = (t0 + j) * 16 + m;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_fwd_kernel(const RgbFwdArgs 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const int off = m * P + 4 * g;
     const int tpr = a.tiles_per_ray;
-    for (int64_t ray = (int64_t)blockIdx.x * kFWaves + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * kFWaves) {
+    for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         f32x4 r0[4], r1[4];
         ld_rm<4>(a.rb0 + ray * a.ld_rb, true, g, r0);
         ld_rm<4>(a.rb1 + ray * a.ld_rb, true, g, r1);
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_bwd_kernel(const RgbBwdArgs 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const int off = m * P + 4 * g;
     const int tpr = a.tiles_per_ray;
-    for (int64_t ray = (int64_t)blockIdx.x * kFWaves + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * kFWaves) {
+    for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         f32x4 s1[4], s0[4];
         zero<4>(s1); zero<4>(s0);
         const int64_t row_base = ray * tpr * 16 + m;
@@ -449,8 +449,9 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_bwd_kernel(const RgbBwdArgs 
     }
 }
 
-static inline uint32_t fused_grid(int64_t work_items) {
-    int64_t blocks = (work_items + kFWaves - 1) / kFWaves;
+static inline uint32_t fused_grid(int64_t work_items, int threads = kFThreads) {
+    const int waves = threads / 64;
+    int64_t blocks = (work_items + waves - 1) / waves;
     if (blocks > 512) blocks = 512;  // persistent: 2 workgroups per CU
     return (uint32_t)(blocks < 1 ? 1 : blocks);
 }
@@ -481,7 +482,7 @@ extern "C" int emer_neck_supported(int32_t n_levels, int32_t n_feat, int32_t hid
         int rc_ = EMER_E_INVALID;                                                                                  \
         auto go = [&](auto kern) {                                                                             \
             if (int r = set_lds(kern, LDS(kt0), WHAT)) return r;                                               \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), LDS(kt0), st, ARGS);                         \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kNThreads), LDS(kt0), st, ARGS);                         \
             return check_launch(WHAT);                                                                         \
         };                                                                                                     \
         if (n_feat == 1) { if (kt0 == 1) rc_ = go(KERNEL<1, 1, NTX>); else if (kt0 == 2) rc_ = go(KERNEL<2, 1, NTX>); else if (kt0 == 3) rc_ = go(KERNEL<3, 1, NTX>); else rc_ = go(KERNEL<4, 1, NTX>); } \
@@ -509,7 +510,7 @@ extern "C" int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_fe
     a.w1 = WSrc{w1, 64, 1, n_out, 64};
     a.b0 = b0; a.b1 = b1; a.h1 = h1; a.out0 = out0; a.out1 = out1; a.dens = dens;
     hipStream_t st = as_stream(stream);
-    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk);
+    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     if (n_out == 1) {
         auto lds = [](int kt0) { return (size_t)(64 * (kt0 * 16 + 4) + 16 * 68 + 64 + 16) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 1, a, lds, "neck_fwd");
@@ -540,7 +541,7 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
     a.dpre1 = dpre1; a.dcol0 = dcol0; a.dpre0 = dpre0; a.denc = denc_lm;
     a.w0t = WSrc{w0, 1, k0, k0, 64};     // (n = input feature, k = hidden) = w0[k][n]
     hipStream_t st = as_stream(stream);
-    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk);
+    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     if (n_out == 1) {
         a.w1t = WSrc{w1, 1, 64, 64, 1};  // (n = hidden, k = 0) = w1[0][n]
         auto lds = [](int kt0) { return (size_t)(64 * 20 + kt0 * 16 * 68) * sizeof(float); };
