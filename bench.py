@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (fields per the driver contract + "roofline" + "c
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -63,6 +64,22 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
         jit = [torch.rand(rays, generator=g) for _ in range(len(prop_samples) + 1)]
         ref.train_step(data, opt_main, opt_prop, samples, prop_samples, jitters=jit, prop_grad=prop_grad)
 
+    # PSNR of the HIP path vs the oracle on identical rays / parameters (the second half of BASELINE.json's metric):
+    # eval-mode render (no stratified jitter), composited rgb, -10 log10(mse); depth as relative error
+    from emernerf_amd.render_utils import render_rays as hip_render_rays
+    mods = [trainer.model, trainer.estimator] + list(trainer.props)
+    for m in mods:
+        m.eval()
+    with torch.no_grad():
+        dev_data = {k: v.to(trainer.device) for k, v in data.items()}
+        hip = hip_render_rays(radiance_field=trainer.model, proposal_estimator=trainer.estimator, proposal_networks=trainer.props,
+                              data_dict=dev_data, cfg=trainer.rcfg, proposal_requires_grad=False)
+        orc = ref.render_rays(data, samples, prop_samples, jitters=None, training=False)
+    for m in mods:
+        m.train()
+    mse = float(((hip["rgb"].cpu().double() - orc["rgb"].double()) ** 2).mean())
+    psnr = float("inf") if mse == 0.0 else -10.0 * math.log10(mse)
+    depth_rel = float(((hip["depth"].cpu().double() - orc["depth"].double()).abs() / orc["depth"].double().abs().clamp_min(1e-6)).max())
     one(True)   # warm-up both step types (allocations, OpenMP pool)
     one(False)
     t0 = time.perf_counter()
@@ -70,6 +87,7 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
         one(i % 6 == 0)
     dt = time.perf_counter() - t0
     return {"value": rays * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "psnr_vs_oracle_db": min(psnr, 999.0), "depth_max_rel_err_vs_oracle": depth_rel,
             "sample": f"{steps} full optimizer steps of {rays} rays x {samples} samples (same model/config, 1 in 6 steps "
                       f"trains the proposal nets), oracle/ref_path.py on oracle/emer_oracle.c, torch {torch.get_num_threads()} "
                       f"threads + OpenMP; {dt:.1f} s"}
