@@ -52,27 +52,23 @@ __device__ __forceinline__ void stage_b(float *dst, int npad, const float *b, in
 // wl already points at this lane's (n = lane & 15, 4 * g) corner of the LDS matrix.
 template <int KT, int NT>
 __device__ __forceinline__ void tgemm(const float *wl, int pitch, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
-    // software pipelined by hand: the A fragments of input tile t + 1 are read while tile t is in the matrix pipe;
-    // the scheduling barrier keeps the compiler from hoisting ALL weight reads of the chain (it would otherwise
-    // trade ~100 VGPRs of fragments for latency it does not need to hide -- several waves share the SIMD)
-    f32x4 a[NT];
+    // software pipelined by hand: the A fragments of input tile t + 1 are read while tile t is in the matrix pipe
+    // (two fragment sets used alternately -- no register rotation); the scheduling barrier keeps the compiler from
+    // hoisting ALL weight reads of the chain (it would otherwise trade ~100 VGPRs of fragments for latency it does
+    // not need to hide -- several waves share the SIMD)
+    f32x4 a[2][NT];
 #pragma unroll
-    for (int p = 0; p < NT; ++p) a[p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch);
+    for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch);
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        f32x4 an[NT];
         if (t + 1 < KT) {
 #pragma unroll
-            for (int p = 0; p < NT; ++p) an[p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + (t + 1) * 16);
+            for (int p = 0; p < NT; ++p) a[(t + 1) & 1][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + (t + 1) * 16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int p = 0; p < NT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][i], in[t][i], acc[p], 0, 0, 0);
-        }
-        if (t + 1 < KT) {
-#pragma unroll
-            for (int p = 0; p < NT; ++p) a[p] = an[p];
+            for (int p = 0; p < NT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t & 1][p][i], in[t][i], acc[p], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -322,7 +318,7 @@ struct RgbFwdArgs {
     float *out;                        // [n][3]
 };
 
-__global__ __launch_bounds__(kFThreads, 3) void rgb_fwd_kernel(const RgbFwdArgs a) {
+__global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int P = 64 + 4;
     float *w0l = smem, *w1al = w0l + 64 * P, *w1gl = w1al + 64 * P, *w2l = w1gl + 64 * P, *b2l = w2l + 16 * P;
@@ -336,9 +332,9 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_fwd_kernel(const RgbFwdArgs 
     const int off = m * P + 4 * g;
     const int tpr = a.tiles_per_ray;
     for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
-        f32x4 r0[4], r1[4];
-        ld_rm<4>(a.rb0 + ray * a.ld_rb, true, g, r0);
-        ld_rm<4>(a.rb1 + ray * a.ld_rb, true, g, r1);
+        // the per-ray pre-activations are re-read for every tile (L1/L2 hits) instead of living in 32 VGPRs for the
+        // whole ray: the kernel then fits 128 VGPRs = 4 waves per SIMD
+        const float *rb0 = a.rb0 + ray * a.ld_rb, *rb1 = a.rb1 + ray * a.ld_rb;
         const int64_t row_base = ray * tpr * 16 + m;
         f32x4 xn[4];
         ld_rm<4>(a.geo + row_base * a.ld_geo, true, g, xn);
@@ -349,16 +345,14 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_fwd_kernel(const RgbFwdArgs 
             for (int t = 0; t < 4; ++t) x[t] = xn[t];
             if (j + 1 < tpr) ld_rm<4>(a.geo + (row + 16) * a.ld_geo, true, g, xn);
             f32x4 h[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) h[p] = r0[p];
+            ld_rm<4>(rb0, true, g, h);
             tgemm<4, 4>(w0l + off, P, x, h);
             relu<4>(h);
             st_rm<4>(a.a1 + row * 64, true, g, h);
             f32x4 h2[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) h2[p] = r1[p];
+            ld_rm<4>(rb1, true, g, h2);
+            tgemm<4, 4>(w1gl + off, P, x, h2);   // geo part first: x dies here
             tgemm<4, 4>(w1al + off, P, h, h2);
-            tgemm<4, 4>(w1gl + off, P, x, h2);
             relu<4>(h2);
             st_rm<4>(a.a2 + row * 64, true, g, h2);
             f32x4 o[1];
@@ -578,7 +572,7 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
     a.b2 = b2; a.a1 = a1; a.a2 = a2; a.out = out;
     const size_t lds = (size_t)(3 * 64 * 68 + 16 * 68 + 16) * sizeof(float);
     if (int rc = set_lds(rgb_fwd_kernel, lds, "rgb_head_fwd")) return rc;
-    hipLaunchKernelGGL(rgb_fwd_kernel, dim3(fused_grid(n_rays)), dim3(kFThreads), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(rgb_fwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_fwd");
 }
 
