@@ -36,6 +36,11 @@ inline int check_launch(const char *what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Raise a kernel's dynamic-LDS limit above 48 KiB.  Cached per (kernel, device): the attribute call is made once, not on
+// every launch -- it is not a stream operation, so it must not run while the launch stream is being captured into a
+// hipGraph (core.hip).
+int reserve_lds(const void *kernel, size_t bytes, const char *what);
+
 // ---- wave-level scans (DPP-backed __shfl; no LDS) ------------------------------------------
 __device__ __forceinline__ float wave_inclusive_sum(float v, int lane) {
 #pragma unroll

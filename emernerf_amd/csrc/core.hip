@@ -4,6 +4,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace emer {
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -11,6 +15,21 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int reserve_lds(const void *kernel, size_t bytes, const char *what) {
+    if (bytes <= 48 * 1024) return EMER_OK;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;  // (kernel, device) -> largest size reserved so far
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[{kernel, dev}];
+    if (have >= bytes) return EMER_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e)); return EMER_E_LAUNCH; }
+    have = bytes;
+    return EMER_OK;
 }
 }  // namespace emer
 

@@ -712,6 +712,17 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
   }
 }
 
+struct ZeroRegions {
+    float *p[EMER_MAX_LEVELS + 1];
+    uint32_t n[EMER_MAX_LEVELS + 1];
+    int32_t count;
+};
+__global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions z) {
+    float *__restrict__ p = z.p[blockIdx.y];
+    const uint32_t n = z.n[blockIdx.y];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) p[i] = 0.0f;
+}
+
 // Slice bitmaps for callers that did not get them from the forward pass.
 template <int D>
 __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_grid_desc g, const SlicePlan plan,
@@ -907,18 +918,20 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 LDS slices; use emer_hashgrid_bwd_params");
     uint32_t total_items = 0;
     for (int i = 0; i < 8; ++i) total_items += plan.items_per_xcd[i];
+    // Zero, in ONE launch, the levels that are merged with atomics and the work cursors (the 16 scratch words behind
+    // the bitmaps).  A kernel rather than hipMemsetAsync nodes: one launch instead of up to six, and hipGraph replays of
+    // memset nodes proved unreliable on ROCm 7.2 (gradients drifted after a few replays).
+    ZeroRegions zr;
+    zr.count = 0;
+    uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * 64 * (size_t)ceil_div(n, 64));
+    zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = 8; ++zr.count;
     for (uint32_t l = 0; l < g->n_levels; ++l) {
-        if (plan.n_ranges[l] > 1u) {  // levels merged with atomics start from zero (async memset node on the same stream)
-            hipError_t e = hipMemsetAsync(grad + (size_t)g->offset[l] * F, 0, (size_t)g->size[l] * F * sizeof(float), as_stream(stream));
-            if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
+        if (plan.n_ranges[l] > 1u) {
+            zr.p[zr.count] = grad + (size_t)g->offset[l] * F; zr.n[zr.count] = g->size[l] * F; ++zr.count;
         }
     }
-    // work cursors: the 16 scratch words behind the bitmaps
-    uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * 64 * (size_t)ceil_div(n, 64));
-    {
-        hipError_t e = hipMemsetAsync(work_ctr, 0, 8 * sizeof(uint32_t), as_stream(stream));
-        if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: memset failed: %s", hipGetErrorString(e)); return EMER_E_LAUNCH; }
-    }
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(64, (uint32_t)zr.count), dim3(256), 0, as_stream(stream), zr);
+    if (int rc = check_launch("hashgrid_bwd_params_sliced(zero)")) return rc;
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
     uint32_t n_blocks = 256;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
@@ -926,10 +939,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
-        if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { set_error("hashgrid_bwd_params_sliced: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
-        }
+        if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
         hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
                            slice_masks, work_ctr, grad, n);
         return check_launch("hashgrid_bwd_params_sliced");

@@ -413,7 +413,6 @@ static ChainLds chain_lds_plan(const emer_chain_desc *d) {
     return p;
 }
 
-constexpr int kChainWaves = 4;
 
 // One column group (NT tiles of 16 outputs) of one layer for a 16-row tile.
 // The reduction index is PERMUTED: lane group g = lane >> 4 owns the contiguous range k in [g*kq, (g+1)*kq),
@@ -888,10 +887,7 @@ extern "C" int emer_mlp_chain(const emer_chain_desc *d, int64_t n_rows, void *st
     while (n_waves > 4 && ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float) > 160 * 1024) n_waves -= 2;
     const size_t lds = ((size_t)lp.w_total + (size_t)n_waves * 16 * lp.P) * sizeof(float);
     EMER_REQUIRE(lds <= 160 * 1024, "mlp_chain: chain needs %zu B of LDS (> 160 KiB); split it", lds);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("mlp_chain: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
-    }
+    if (int rc = reserve_lds(reinterpret_cast<const void *>(mlp_chain_kernel), lds, "mlp_chain")) return rc;
     const int64_t n_tiles = ceil_div(n_rows, 16);
     int64_t grid = 256;  // persistent: one workgroup per CU
     if (grid > ceil_div(n_tiles, n_waves)) grid = ceil_div(n_tiles, n_waves);

@@ -452,11 +452,7 @@ static inline uint32_t fused_grid(int64_t work_items, int threads = kFThreads) {
 
 template <typename K>
 static int set_lds(K kern, size_t lds, const char *what) {
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("%s: cannot reserve %zu B of LDS: %s", what, lds, hipGetErrorString(e)); return EMER_E_LAUNCH; }
-    }
-    return EMER_OK;
+    return reserve_lds(reinterpret_cast<const void *>(kern), lds, what);
 }
 
 }  // namespace emer
