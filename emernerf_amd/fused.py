@@ -16,6 +16,7 @@ the shapes every shipped config uses: ``emer_neck_*``, ``emer_rgb_head_*``) and 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from ctypes import c_int32, c_int64, c_void_p
 from typing import Optional, Tuple
@@ -59,14 +60,18 @@ def _stream(t: Tensor):
 def seg(t: Tensor, col: int, width: int, ld: Optional[int] = None, row_div: int = 1, dst_col: Optional[int] = None) -> ChainSeg:
     """Row-major segment: value(row, c) = t[(row // row_div), c].  dst_col (wgrad only): where the segment's gradient
     columns land in the output matrix (default: its own position in the virtual concatenation)."""
-    return ChainSeg(ptr=_p(t), ld=ld if ld is not None else t.stride(-2), n_total=0, fix_a=None, fix_b=None, col=col,
-                    width=width, row_div=row_div, mode=0, f=1, dst_col=col if dst_col is None else dst_col)
+    s = ChainSeg(ptr=_p(t), ld=ld if ld is not None else t.stride(-2), n_total=0, fix_a=None, fix_b=None, col=col,
+                 width=width, row_div=row_div, mode=0, f=1, dst_col=col if dst_col is None else dst_col)
+    s._t = t  # keeps the tensor reachable (side-stream bookkeeping in wgrad)
+    return s
 
 
 def seg_lm(t: Tensor, col: int) -> ChainSeg:
     """Level-major grid encoding [L, N, F] as L*F columns."""
     L, N, F = t.shape
-    return ChainSeg(ptr=_p(t), ld=0, n_total=N, fix_a=None, fix_b=None, col=col, width=L * F, row_div=1, mode=1, f=F, dst_col=col)
+    s = ChainSeg(ptr=_p(t), ld=0, n_total=N, fix_a=None, fix_b=None, col=col, width=L * F, row_div=1, mode=1, f=F, dst_col=col)
+    s._t = t
+    return s
 
 
 def layer(w: Tensor, bias: Optional[Tensor], in_col: int, out_col: int, act: int = ACT_NONE, transposed: bool = False,
@@ -119,23 +124,47 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
     segment s lands at columns dst_col_s..).  Returns (dW or None, db or None)."""
     M, N = dpre.shape
     dev = dpre.device
+    # Weight gradients that go straight into gradient sinks have no consumer inside the backward pass, so they can run
+    # on a SIDE STREAM, concurrently with the data-gradient chain that continues on the main stream (neck backward,
+    # grid backward: VALU/LDS-bound kernels that leave HBM idle, while these kernels are HBM-bound).  The trainer joins
+    # the side stream before it touches the gradients (Trainer.train_step).
+    side = SIDE_STREAM if (out_w is not None and (out_b is not None or not want_bias)) else None
     with torch.cuda.device(dev):
-        n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, k_total))
-        ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
-        need_b = want_bias and out_b is None
-        if out_w is None or need_b:
-            buf = torch.zeros((N * (k_total if out_w is None else 0) + (N if need_b else 0),), device=dev, dtype=torch.float32)  # one fill
-        dw = buf[:N * k_total].view(N, k_total) if out_w is None else None
-        db = (buf[-N:] if need_b else None)
-        tw = dw if out_w is None else out_w
-        tb = out_b if out_b is not None else db
-        assert tw.stride(1) == 1 and tw.dtype == torch.float32 and (tb is None or tb.is_contiguous())
-        arr = (ChainSeg * MAX_SEGS)()
-        for i, s in enumerate(segs):
-            arr[i] = s
-        _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(col0), arr, len(segs), _p(ws), _p(tw), tw.stride(0),
-                  _p(tb) if want_bias else None, M, N, k_total, _stream(dpre))
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)  # operands were produced on the main stream
+            for t in [dpre, col0] + [getattr(sg, "_t", None) for sg in segs]:
+                if t is not None:
+                    t.record_stream(side)  # the caching allocator must not recycle them while the side stream reads
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = contextlib.nullcontext()
+        with ctx:
+            n_ws = int(_lib.load().emer_linear_bwd_workspace(M, N, k_total))
+            ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
+            need_b = want_bias and out_b is None
+            if out_w is None or need_b:
+                buf = torch.zeros((N * (k_total if out_w is None else 0) + (N if need_b else 0),), device=dev, dtype=torch.float32)  # one fill
+            dw = buf[:N * k_total].view(N, k_total) if out_w is None else None
+            db = (buf[-N:] if need_b else None)
+            tw = dw if out_w is None else out_w
+            tb = out_b if out_b is not None else db
+            assert tw.stride(1) == 1 and tw.dtype == torch.float32 and (tb is None or tb.is_contiguous())
+            arr = (ChainSeg * MAX_SEGS)()
+            for i, sg in enumerate(segs):
+                arr[i] = sg
+            _lib.call("emer_wgrad_segmented", _p(dpre), dpre.stride(0), _p(col0), arr, len(segs), _p(ws), _p(tw), tw.stride(0),
+                      _p(tb) if want_bias else None, M, N, k_total, _stream(dpre))
     return dw, db
+
+
+SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for the weight-gradient side stream (no-op when unused)."""
+    if SIDE_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(SIDE_STREAM)
 
 
 def _sink(p) -> Optional[Tensor]:

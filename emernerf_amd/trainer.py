@@ -163,6 +163,9 @@ class Trainer:
         # this trainer owns every gradient buffer (views of flat.grads, zeroed each step, no parameter hooks), so the
         # fused heads may accumulate weight gradients straight into .grad (fused._sink)
         fused.USE_GRAD_SINKS = True
+        # (fused.SIDE_STREAM -- weight gradients on a second stream, overlapping the grid backward -- is implemented and
+        # tested but OFF: measured 3 % slower on MI355X; the grid backward's workgroups fill the LDS of every CU, so
+        # the weight-gradient workgroups only delay them)
         self.m = torch.zeros_like(self.flat.params)
         self.v = torch.zeros_like(self.flat.params)
         self.opt_steps = {"main": 0, "prop": 0}
@@ -205,6 +208,7 @@ class Trainer:
             prop_loss.backward()
         loss = self.losses(results, data)
         (loss * self.loss_scale).backward()
+        fused.join_side_stream()  # weight gradients written on the side stream are complete from here on
         if self.world_size > 1:
             # the single RCCL collective of the step (sum; 1/W folded into Adam).  Proposal-net gradients exist only on
             # the steps that train them (same schedule on every rank), so the other steps exchange the main range only

@@ -168,9 +168,24 @@ def test_grad_sinks_equal_autograd_accumulation(hip_lib):
     fused.USE_GRAD_SINKS = True
     try:
         run(got)
+        fused.join_side_stream()  # a Trainer created earlier in this process may have enabled the wgrad side stream
     finally:
         fused.USE_GRAD_SINKS = False
     for k in ref:
         for i, (a, b) in enumerate(zip(got[k], ref[k])):
             assert a.grad.data_ptr() == pre[(k, i)], "gradient was not accumulated in place"
             _close(f"{k}{i}", a.grad - 0.25, b.grad, rtol=2e-4, scale_atol=5e-5)
+    # the same through the weight-gradient side stream
+    got2 = params()
+    for ps in got2.values():
+        for p in ps:
+            p.grad = torch.full_like(p, 0.25)
+    old_side, fused.SIDE_STREAM, fused.USE_GRAD_SINKS = fused.SIDE_STREAM, torch.cuda.Stream(), True
+    try:
+        run(got2)
+        fused.join_side_stream()
+    finally:
+        fused.SIDE_STREAM, fused.USE_GRAD_SINKS = old_side, False
+    for k in ref:
+        for i, (a, b) in enumerate(zip(got2[k], ref[k])):
+            _close(f"side {k}{i}", a.grad - 0.25, b.grad, rtol=2e-4, scale_atol=5e-5)
