@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // Placement only affects speed, never results.
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
-constexpr int kDrainK = 4;                            // hits per lane per drain (loads in flight)
+constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
 constexpr int kWaveQueue = 64 * kDrainK + 64;         // wave-private hit queue (sample ids): < 64*K left over + <= 64 pushed
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so

@@ -50,25 +50,33 @@ __device__ __forceinline__ void stage_b(float *dst, int npad, const float *b, in
 
 // acc[p] (output tile p) += sum over input tiles t, steps i of W[16p + n][16t + 4g + i] * in[t][i]
 // wl already points at this lane's (n = lane & 15, 4 * g) corner of the LDS matrix.
-template <int KT, int NT>
+template <int KT, int NT, bool PIPE = true>
 __device__ __forceinline__ void tgemm(const float *wl, int pitch, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
-    // software pipelined by hand: the A fragments of input tile t + 1 are read while tile t is in the matrix pipe
-    // (two fragment sets used alternately -- no register rotation); the scheduling barrier keeps the compiler from
-    // hoisting ALL weight reads of the chain (it would otherwise trade ~100 VGPRs of fragments for latency it does
-    // not need to hide -- several waves share the SIMD)
-    f32x4 a[2][NT];
+    // PIPE: software pipelined by hand -- the A fragments of input tile t + 1 are read while tile t is in the matrix
+    // pipe (two fragment sets used alternately, no register rotation).  !PIPE: one fragment set (16 VGPRs less), for
+    // kernels that hide the LDS latency with a fourth wave per SIMD instead.  Either way the scheduling barrier keeps
+    // the compiler from hoisting ALL weight reads of the chain (it would otherwise trade ~100 VGPRs of fragments for
+    // latency it does not need to hide -- several waves share the SIMD).
+    f32x4 a[PIPE ? 2 : 1][NT];
+    if (PIPE) {
 #pragma unroll
-    for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch);
+        for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch);
+    }
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        if (t + 1 < KT) {
+        if (PIPE) {
+            if (t + 1 < KT) {
 #pragma unroll
-            for (int p = 0; p < NT; ++p) a[(t + 1) & 1][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + (t + 1) * 16);
+                for (int p = 0; p < NT; ++p) a[(t + 1) & 1][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + (t + 1) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + t * 16);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int p = 0; p < NT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t & 1][p][i], in[t][i], acc[p], 0, 0, 0);
+            for (int p = 0; p < NT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PIPE ? (t & 1) : 0][p][i], in[t][i], acc[p], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -383,7 +391,7 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     return v;
 }
 
-__global__ __launch_bounds__(kFThreads, 3) void rgb_bwd_kernel(const RgbBwdArgs a) {
+__global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int P = 64 + 4, P2 = 16 + 4;
     float *w2l = smem, *w1al = w2l + 64 * P2, *w1gl = w1al + 64 * P, *w0l = w1gl + 64 * P;
@@ -401,9 +409,8 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_bwd_kernel(const RgbBwdArgs 
         const int64_t row_base = ray * tpr * 16 + m;
         for (int j = 0; j < tpr; ++j) {
             const int64_t row = row_base + (int64_t)j * 16;
-            f32x4 m2[4], m1[4];
+            f32x4 m2[4];
             ld_rm<4>(a.a2 + row * 64, true, g, m2);
-            ld_rm<4>(a.a1 + row * 64, true, g, m1);
             f32x4 d2[1];
             d2[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (g == 0) {
@@ -416,18 +423,20 @@ __global__ __launch_bounds__(kFThreads, 3) void rgb_bwd_kernel(const RgbBwdArgs 
             }
             f32x4 d1[4];
             zero<4>(d1);
-            tgemm<1, 4>(w2l + m * P2 + 4 * g, P2, d2, d1);
+            tgemm<1, 4, false>(w2l + m * P2 + 4 * g, P2, d2, d1);
             relu_mask<4>(d1, m2);
             st_rm<4>(a.dpre1 + row * 64, true, g, d1);
+            f32x4 m1[4];  // loaded here (behind tgemm's scheduling barrier): its live range does not overlap a2's mask
+            ld_rm<4>(a.a1 + row * 64, true, g, m1);
             f32x4 d0[4];
             zero<4>(d0);
-            tgemm<4, 4>(w1al + off, P, d1, d0);
+            tgemm<4, 4, false>(w1al + off, P, d1, d0);
             relu_mask<4>(d0, m1);
             st_rm<4>(a.dpre0 + row * 64, true, g, d0);
             f32x4 dg[4];
             zero<4>(dg);
-            tgemm<4, 4>(w1gl + off, P, d1, dg);
-            tgemm<4, 4>(w0l + off, P, d0, dg);
+            tgemm<4, 4, false>(w1gl + off, P, d1, dg);
+            tgemm<4, 4, false>(w0l + off, P, d0, dg);
             st_rm<4>(a.dgeo + row * 64, true, g, dg);
 #pragma unroll
             for (int p = 0; p < 4; ++p) { s1[p] += d1[p]; s0[p] += d0[p]; }
@@ -590,6 +599,6 @@ extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const floa
     a.dpre2 = dpre2; a.dpre1 = dpre1; a.dpre0 = dpre0; a.dgeo = dgeo; a.s1 = s1; a.s0 = s0;
     const size_t lds = (size_t)(64 * 20 + 3 * 64 * 68) * sizeof(float);
     if (int rc = set_lds(rgb_bwd_kernel, lds, "rgb_head_bwd")) return rc;
-    hipLaunchKernelGGL(rgb_bwd_kernel, dim3(fused_grid(n_rays)), dim3(kFThreads), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(rgb_bwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_bwd");
 }
