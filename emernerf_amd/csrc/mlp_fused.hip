@@ -354,18 +354,18 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
             if (j + 1 < tpr) ld_rm<4>(a.geo + (row + 16) * a.ld_geo, true, g, xn);
             f32x4 h[4];
             ld_rm<4>(rb0, true, g, h);
-            tgemm<4, 4>(w0l + off, P, x, h);
+            tgemm<4, 4, false>(w0l + off, P, x, h);
             relu<4>(h);
             st_rm<4>(a.a1 + row * 64, true, g, h);
             f32x4 h2[4];
             ld_rm<4>(rb1, true, g, h2);
-            tgemm<4, 4>(w1gl + off, P, x, h2);   // geo part first: x dies here
-            tgemm<4, 4>(w1al + off, P, h, h2);
+            tgemm<4, 4, false>(w1gl + off, P, x, h2);   // geo part first: x dies here
+            tgemm<4, 4, false>(w1al + off, P, h, h2);
             relu<4>(h2);
             st_rm<4>(a.a2 + row * 64, true, g, h2);
             f32x4 o[1];
             init_bias<1>(b2l, g, o);
-            tgemm<4, 1>(w2l + off, P, h2, o);
+            tgemm<4, 1, false>(w2l + off, P, h2, o);
             if (g == 0) {
                 float *op = a.out + row * 3;
 #pragma unroll
