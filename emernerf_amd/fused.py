@@ -503,3 +503,72 @@ class _RgbHeadFn(torch.autograd.Function):
 def rgb_head(hray: Tensor, geo: Tensor, samples_per_ray: int, w0, b0, w1, b1, w2, b2) -> Tensor:
     """sigmoid(MLP3-skip1([hray[ray] | geo])) -> [N, 3]; hray [R, Kh] per ray, geo [N, NG] per sample."""
     return _RgbHeadFn.apply(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2)
+
+
+# ------------------------------------------------------------------------- 3-layer skip MLP on row-major input
+class _SkipMLP3Fn(torch.autograd.Function):
+    """act(MLP(x)) for mlp.MLP(num_layers=3, skip_connections=[1]) (mlp.py:20-46) on a plain row-major input -- the
+    per-ray sky head (radiance_field.py:156-187,660-686).  One chain launch forward, one for the data gradients,
+    instead of three Linear launches each way with [rows, 64] round trips."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w0, b0, w1, b1, w2, b2, final_act: int):
+        ctx.set_materialize_grads(False)
+        X, W0, B0, W1, B1, W2, B2 = _c(x), _c(w0), _c(b0), _c(w1), _c(b1), _c(w2), _c(b2)
+        N, K0 = X.shape
+        H, C = W0.shape[0], W2.shape[0]
+        assert W0.shape[1] == K0 and W1.shape[1] == H + K0 and W2.shape[1] == H and H % 4 == 0
+        dev = X.device
+        a1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        out = torch.empty((N, C), device=dev, dtype=torch.float32)
+        c_x = H                     # [A1 | x] laid out exactly like torch.cat([x_hidden, input]) of mlp.py:42
+        c_o = c_x + _r4(K0)
+        run_chain([seg(X, c_x, K0)],
+                  [layer(W0, B0, c_x, 0, ACT_RELU, store=a1),
+                   layer(W1, B1, 0, 0, ACT_RELU, store=a2),     # A2 overwrites A1 in place (one column group)
+                   layer(W2, B2, 0, c_o, final_act, store=out)],
+                  c_o + _r4(C), N, X)
+        ctx.save_for_backward(X, W0, W1, W2, a1, a2, out)
+        ctx.final_act = final_act
+        ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Optional[Tensor]):
+        X, W0, W1, W2, a1, a2, out = ctx.saved_tensors
+        if dout is None:
+            return (None,) * 8
+        N, K0 = X.shape
+        H, C = W0.shape[0], W2.shape[0]
+        dev = X.device
+        d = _c(dout)
+        dpre2 = (d * out * (1.0 - out)).contiguous() if ctx.final_act == ACT_SIGMOID else d  # sigmoid' / identity
+        dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        dx = torch.empty((N, K0), device=dev, dtype=torch.float32)
+        c1 = _r4(C)                 # dA2 -> dPre1
+        cx = c1 + H                 # d[A1 | x]; dA1 -> dPre0 in place
+        run_chain([seg(dpre2, 0, C)],
+                  [layer(W2, None, 0, c1, transposed=True, mask=a2, store=dpre1),
+                   layer(W1, None, c1, cx, transposed=True, n_slice=(0, H), mask=a1, store=dpre0),
+                   layer(W1, None, c1, cx + H, transposed=True, n_slice=(H, H + K0)),
+                   layer(W0, None, cx, cx + H, transposed=True, accumulate=True, store=dx)],
+                  cx + H + _r4(K0), N, X)
+        sw0, sb0, sw1, sb1, sw2, sb2 = ctx.sinks
+        tw2, rw2 = _target(sw2, (C, H), dev)
+        tb2, rb2 = _target(sb2, (C,), dev)
+        tw1, rw1 = _target(sw1, (H, H + K0), dev)
+        tb1, rb1 = _target(sb1, (H,), dev)
+        tw0, rw0 = _target(sw0, (H, K0), dev)
+        tb0, rb0 = _target(sb0, (H,), dev)
+        wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
+        wgrad(dpre1, [seg(a1, 0, H), seg(X, H, K0)], H + K0, out_w=tw1, out_b=tb1)
+        wgrad(dpre0, [seg(X, 0, K0)], K0, out_w=tw0, out_b=tb0)
+        return dx, rw0, rb0, rw1, rb1, rw2, rb2, None
+
+
+def skip_mlp3(x: Tensor, w0, b0, w1, b1, w2, b2, final_act: int = ACT_SIGMOID) -> Tensor:
+    """final_act(MLP3-skip1(x)) for x [rows, K0]; final_act ACT_SIGMOID or ACT_NONE."""
+    assert final_act in (ACT_SIGMOID, ACT_NONE)
+    return _SkipMLP3Fn.apply(x, w0, b0, w1, b1, w2, b2, final_act)

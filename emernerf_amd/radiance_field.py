@@ -423,7 +423,12 @@ class RadianceField(nn.Module):
         emb = self._appearance(directions, data_dict)
         if emb is not None:
             dd = torch.cat([dd, emb], dim=-1)
-        results = {"rgb_sky": self.sky_head(dd, final_act="sigmoid")}
+        head = self.sky_head
+        if dd.dim() == 2 and len(head.layers) == 3 and list(head.skip_connections) == [1] and head.hidden_dims % 4 == 0:
+            lw = [p for l in head.layers for p in (l.weight, l.bias)]
+            results = {"rgb_sky": fused.skip_mlp3(dd, *lw)}  # one chain launch each way (per-ray head)
+        else:
+            results = {"rgb_sky": head(dd, final_act="sigmoid")}
         if self.enable_feature_head:
             results["dino_sky_feat"] = _run_sequential(self.dino_sky_head, dd)
         return results
