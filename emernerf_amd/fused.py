@@ -572,3 +572,83 @@ def skip_mlp3(x: Tensor, w0, b0, w1, b1, w2, b2, final_act: int = ACT_SIGMOID) -
     """final_act(MLP3-skip1(x)) for x [rows, K0]; final_act ACT_SIGMOID or ACT_NONE."""
     assert final_act in (ACT_SIGMOID, ACT_NONE)
     return _SkipMLP3Fn.apply(x, w0, b0, w1, b1, w2, b2, final_act)
+
+
+# ----------------------------------------------------------------- plain nn.Sequential heads (shadow / flow / dino)
+def seq_mlp_supported(weights) -> bool:
+    """2..4 Linear layers whose weights fit the chain kernel's LDS budget and column buffer."""
+    if not (2 <= len(weights) <= 4):
+        return False
+    lds = sum((-(-w.shape[0] // 16) * 16) * ((-(-w.shape[1] // 8) * 8) + 2) * 4 for w in weights)
+    cols = _r4(weights[0].shape[1]) + sum(_r4(w.shape[0]) for w in weights)
+    return lds <= 96 * 1024 and cols <= 500 and all(w.shape[0] <= 256 for w in weights)
+
+
+class _SeqMLPFn(torch.autograd.Function):
+    """final_act(Linear_n(ReLU(... ReLU(Linear_1(x))))) -- the shadow head (radiance_field.py:148-153), flow MLP
+    (:101-111) and dino heads (:192-198) as ONE chain launch forward and one for the data gradients."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, final_act: int, *wb):
+        ctx.set_materialize_grads(False)
+        X = _c(x)
+        Ws, Bs = [_c(w) for w in wb[0::2]], [None if b is None else _c(b) for b in wb[1::2]]
+        N, K0 = X.shape
+        dev = X.device
+        n = len(Ws)
+        cols = [0, _r4(K0)]
+        for w in Ws:
+            cols.append(cols[-1] + _r4(w.shape[0]))
+        acts = [torch.empty((N, w.shape[0]), device=dev, dtype=torch.float32) for w in Ws]
+        layers = [layer(Ws[i], Bs[i], cols[i], cols[i + 1], ACT_RELU if i + 1 < n else final_act, store=acts[i]) for i in range(n)]
+        run_chain([seg(X, 0, K0)], layers, cols[-1], N, X)
+        ctx.save_for_backward(X, *Ws, *acts)
+        ctx.n, ctx.final_act = n, final_act
+        ctx.sinks = tuple(_sink(p) for p in wb)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dout: Optional[Tensor]):
+        n = ctx.n
+        if dout is None:
+            return (None,) * (2 + 2 * n)
+        saved = ctx.saved_tensors
+        X, Ws, acts = saved[0], saved[1:1 + n], saved[1 + n:]
+        N, K0 = X.shape
+        dev = X.device
+        d = _c(dout)
+        out = acts[-1]
+        dlast = (d * out * (1.0 - out)).contiguous() if ctx.final_act == ACT_SIGMOID else d
+        dpre = [None] * n
+        dpre[n - 1] = dlast
+        cols = [0, _r4(Ws[n - 1].shape[0])]
+        layers = []
+        for i in range(n - 1, 0, -1):      # dA_{i-1} = dPre_i W_i, masked by relu'(act_{i-1}) -> dPre_{i-1}
+            dpre[i - 1] = torch.empty((N, Ws[i].shape[1]), device=dev, dtype=torch.float32)
+            cols.append(cols[-1] + _r4(Ws[i].shape[1]))
+            layers.append(layer(Ws[i], None, cols[-3], cols[-2], transposed=True, mask=acts[i - 1], store=dpre[i - 1]))
+        dx = None
+        if ctx.need_dx:
+            dx = torch.empty((N, K0), device=dev, dtype=torch.float32)
+            cols.append(cols[-1] + _r4(K0))
+            layers.append(layer(Ws[0], None, cols[-3], cols[-2], transposed=True, store=dx))
+        if layers:
+            run_chain([seg(dlast, 0, Ws[n - 1].shape[0])], layers, cols[-1], N, X)
+        grads = []
+        for i in range(n):
+            sw, sb = ctx.sinks[2 * i], ctx.sinks[2 * i + 1]
+            tw, rw = _target(sw, tuple(Ws[i].shape), dev)
+            has_b = ctx.needs_input_grad[2 + 2 * i + 1]
+            tb, rb = _target(sb, (Ws[i].shape[0],), dev) if has_b else (None, None)
+            operand = X if i == 0 else acts[i - 1]
+            wgrad(dpre[i], [seg(operand, 0, Ws[i].shape[1])], Ws[i].shape[1], want_bias=has_b, out_w=tw, out_b=tb)
+            grads += [rw, rb]
+        return (dx, None, *grads)
+
+
+def seq_mlp(x: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:
+    """Chain-fused nn.Sequential(Linear, ReLU, ..., Linear[, Sigmoid]); x [rows, K0] row-major."""
+    assert final_act in (ACT_NONE, ACT_SIGMOID)
+    wb = [t for pair in zip(weights, biases) for t in pair]
+    return _SeqMLPFn.apply(x, final_act, *wb)

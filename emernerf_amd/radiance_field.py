@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
-from . import fused, ops
+from . import _lib, fused, ops
 from .encodings import HashEncoder, SinusoidalEncoder, build_xyz_encoder_from_cfg
 
 logger = logging.getLogger()
@@ -28,6 +28,16 @@ logger = logging.getLogger()
 def _run_sequential(seq: nn.Sequential, x: Tensor, density_from_col0: bool = False):
     """Evaluate nn.Sequential(Linear, ReLU, ..., Linear[, Sigmoid]) with fused-activation HIP linears."""
     mods = list(seq)
+    lins = [m for m in mods if isinstance(m, nn.Linear)]
+    # plain Linear-ReLU-...-Linear[-Sigmoid] stacks on row-major input: one fused chain launch each way
+    body = mods[:-1] if isinstance(mods[-1], nn.Sigmoid) else mods
+    pattern_ok = len(body) % 2 == 1 and all(isinstance(m, nn.Linear if j % 2 == 0 else nn.ReLU) for j, m in enumerate(body))
+    if (pattern_ok and not density_from_col0 and x.is_cuda and all(l.bias is not None for l in lins)
+            and fused.seq_mlp_supported([l.weight for l in lins])):
+        lead = x.shape[:-1]
+        y = fused.seq_mlp(x.reshape(-1, x.shape[-1]), [l.weight for l in lins], [l.bias for l in lins],
+                          _lib.ACT_SIGMOID if isinstance(mods[-1], nn.Sigmoid) else _lib.ACT_NONE)
+        return y.view(*lead, -1)
     i, density = 0, None
     while i < len(mods):
         lin = mods[i]

@@ -220,3 +220,31 @@ def test_skip_mlp3(hip_lib, N, K0, act):
     assert bad_rows <= max(1, N // 4096), f"dx: {bad_rows} rows differ"
     for name, a, b in list(zip(("dx", "dW0", "db0", "dW1", "db1", "dW2", "db2"), t, r))[1:]:
         _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+
+
+@pytest.mark.parametrize("dims,sig,N", [((64, 64, 1), True, 1000), ((40, 64, 64, 6), False, 777), ((64, 64, 64, 64), False, 4096),
+                                        ((43, 32, 5), False, 17)])
+def test_seq_mlp(hip_lib, dims, sig, N):
+    """fused.seq_mlp (shadow / flow / dino heads) vs fp64 torch, including dx."""
+    from emernerf_amd import fused, _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(dims) + N + 3)
+    x = torch.randn(N, dims[0], generator=g)
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(len(dims) - 1)]
+    Bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(len(dims) - 1)]
+    assert fused.seq_mlp_supported(Ws)
+    t = [v.to(dev).requires_grad_(True) for v in [x] + Ws + Bs]
+    r = [v.double().requires_grad_(True) for v in [x] + Ws + Bs]
+    n = len(Ws)
+    out = fused.seq_mlp(t[0], t[1:1 + n], t[1 + n:], _lib.ACT_SIGMOID if sig else _lib.ACT_NONE)
+    h = r[0]
+    for i in range(n):
+        h = F.linear(h, r[1 + i], r[1 + n + i])
+        if i + 1 < n:
+            h = torch.relu(h)
+    ref = torch.sigmoid(h) if sig else h
+    _close("out", out, ref)
+    w = torch.randn(N, dims[-1], generator=g)
+    (out * w.to(dev)).sum().backward(); (ref * w.double()).sum().backward()
+    for i, (a, b) in enumerate(zip(t, r)):
+        _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
