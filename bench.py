@@ -26,6 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -217,6 +218,22 @@ def main():
         ach = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         both = (fwd_b + bwd_b) * N / ((f_avg + b_avg) * 1e-6) / 1e9 if (f_avg + b_avg) > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dominant, D, F, args)
+        # fp32-MFMA rooflines of the head kernels (static configuration only: hidden 64, geo 64): algorithmic flops of
+        # one launch / its average duration in the instrumented pass, vs the dense fp32 matrix peak
+        mfma = {}
+        if args.kind == "static":
+            k0 = L * F
+            n_out = trainer.model.base_mlp[2].out_features
+            flops = {"emer_neck_fwd": 2.0 * N * (k0 * 64 + 64 * n_out), "emer_neck_bwd": 2.0 * N * (64 * 64 + 64 * k0),
+                     "emer_rgb_head_fwd": 2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), "emer_rgb_head_bwd": 2.0 * N * (3 * 64 + 3 * 64 * 64)}
+            for kn, fl in flops.items():
+                v = [u for u in breakdown.elapsed_us().get(kn, [])]
+                if kn.startswith("emer_neck"):  # main-field launches only (the proposal nets are the short ones)
+                    v = sorted(v)[-max(1, breakdown_steps):]
+                if v:
+                    t = sum(v) / len(v)
+                    mfma[kn] = {"avg_us": t, "achieved": fl / (t * 1e-6) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         out = {
             "metric": "train rays/sec (8192-ray batch, 128 samples)",
             "value": world * args.rays * args.steps / elapsed,
@@ -241,6 +258,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
+            "roofline_mfma": mfma,
             "kernels": per_kernel,
             "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "
                             "timed region; the roofline kernels are timed with HIP events inside the timed region itself",
