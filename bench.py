@@ -141,7 +141,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from emernerf_amd import _build, _lib
-    if rank == 0 or not os.path.exists(_build.LIB_PATH):
+    if rank == 0:  # one builder; the others wait (a concurrent build would write the same object files)
         _build.build()
     if world > 1:
         dist.barrier()

@@ -1,10 +1,9 @@
-"""Which torch ops (and from which source lines) launch the small glue kernels of a training step."""
+"""Which small torch ops (by input shapes) make up the glue of a training step."""
 import os, sys, collections
 import torch
 from torch.profiler import profile, ProfilerActivity
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emernerf_amd.trainer import Trainer, synthetic_rays
-
 dev = torch.device("cuda:0")
 tr = Trainer(kind="static", device=dev)
 tr.step_count = 1001
@@ -14,17 +13,14 @@ data = synthetic_rays(8192, dev, seed=1000)
 for _ in range(8):
     tr.train_step(data)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(6):
         tr.train_step(data)
     torch.cuda.synchronize()
-want = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add_", "aten::add", "aten::cat", "aten::mul", "aten::sum", "aten::clone",
-        "aten::contiguous", "aten::zeros", "aten::index_select", "aten::embedding", "aten::addmm", "aten::mm")
-cnt = collections.Counter()
+cnt, tim = collections.Counter(), collections.Counter()
 for e in prof.events():
-    if e.name in want and e.device_time_total > 0 or (e.name in want and any(k.device_time > 0 for k in getattr(e, "kernels", []))):
-        frames = [f for f in (e.stack or []) if "/root/repo" in f or "emernerf_amd" in f]
-        where = frames[0].split("/")[-1] if frames else (e.stack[0] if e.stack else "?")
-        cnt[(e.name, where[:90])] += 1
-for (name, where), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{c / 6:6.1f}/step  {name:18s} {where}")
+    if e.name.startswith("aten::") and e.device_time > 0:
+        key = (e.name, str(e.input_shapes)[:110])
+        cnt[key] += 1; tim[key] += e.device_time
+for key, t in sorted(tim.items(), key=lambda kv: -kv[1])[:45]:
+    print(f"{cnt[key] / 6:5.1f}/step {t / 6:7.1f} us/step  {key[0]:28s} {key[1]}")
