@@ -856,7 +856,7 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     uint32_t blocks = 0;
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice masks requested but a level needs more than 64 LDS slices");
+    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice bitmaps requested but a level needs more than 64 x 64 LDS slices");
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
         if (param_dtype == EMER_F32)
@@ -908,7 +908,7 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(x && slice_masks, "hashgrid_slice_masks: null pointer");
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 64 LDS slices");
+    EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 64 x 64 LDS slices");
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
     uint32_t blocks = 0;
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
@@ -930,7 +930,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 LDS slices; use emer_hashgrid_bwd_params");
+    EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 x 64 LDS slices; use emer_hashgrid_bwd_params");
     uint32_t total_items = 0;
     for (int i = 0; i < 8; ++i) total_items += plan.items_per_xcd[i];
     // Zero, in ONE launch, the levels that are merged with atomics and the work cursors (the 16 scratch words behind

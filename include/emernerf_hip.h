@@ -101,7 +101,8 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
                                     float *grad, int64_t n, void *stream);
 int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
                               uint64_t *slice_masks, int64_t n, void *stream);
-/* 1 when every level of the grid fits <= 64 LDS slices (128 KiB of double accumulators each) (else use emer_hashgrid_bwd_params). */
+/* 1 when the owner-computes backward covers the grid: every level cuts into LDS slices (128 KiB of double accumulators
+ * each) that share at most 64 bitmaps, i.e. up to 4096 slices per level -- every shipped grid.  Else use emer_hashgrid_bwd_params. */
 int emer_hashgrid_sliced_supported(const emer_grid_desc *host_desc);
 
 /* dX[n, d] = sum_l scale_l sum_f dOut * d(interp)/dx.  Replaces the input path of native.bwd
