@@ -124,6 +124,7 @@ def main():
                     "proposal schedule: 1 step in 6 trains the proposal nets, nerfacc_prop_net.py:280-296)")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the forward+backward of a step as a captured hipGraph")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the HIP runtime starts
@@ -147,7 +148,8 @@ def main():
         dist.barrier()
     from emernerf_amd.trainer import Trainer, synthetic_rays
 
-    trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init)
+    trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
+                      use_graph=args.graph)
     trainer.step_count = args.start_step
     # advance the proposal schedule to its state at start_step
     fn = trainer.requires_grad_fn
@@ -166,7 +168,9 @@ def main():
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
                               "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_rgb_head_fwd", "emer_rgb_head_bwd"]
-    timer = _lib.KernelTimer(grid_names) if rank == 0 else None
+    # (graph replay launches no kernel from Python, so there is nothing to bracket inside the timed region: with --graph
+    # the roofline kernels are timed in the eager instrumented pass below instead)
+    timer = _lib.KernelTimer(grid_names) if (rank == 0 and not args.graph) else None
     _lib.TIMER = timer
 
     if world > 1:
@@ -189,10 +193,14 @@ def main():
     if rank == 0:  # untimed: per-kernel breakdown with every entry point instrumented
         breakdown = _lib.KernelTimer(all_names)
         _lib.TIMER = breakdown
+        graphed, trainer.use_graph = trainer.use_graph, False  # the instrumented pass launches eagerly
         for _ in range(breakdown_steps):
             trainer.train_step(data)
         torch.cuda.synchronize()
+        trainer.use_graph = graphed
         _lib.TIMER = None
+        if timer is None:
+            timer = breakdown
     if world > 1:
         dist.barrier()
 
@@ -253,7 +261,8 @@ def main():
                                    "proposal rounds 128+64, full optimizer step (Adam)",
                        "kind": args.kind, "rays_per_gpu": args.rays, "samples": args.samples,
                        "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
-                       "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4"},
+                       "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4",
+                       "launch_mode": "hipGraph replay of forward+backward" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,

@@ -137,7 +137,7 @@ class Trainer:
 
     def __init__(self, kind: str = "static", device="cuda:0", num_samples: int = 128, prop_samples=(128, 64), lr: float = 0.01,
                  weight_decay: float = 1e-5, num_iters: int = 25000, loss_scale: float = 1024.0, seed: int = 0,
-                 world_size: int = 1, table_init: Optional[float] = None):
+                 world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False):
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial parameters on every rank
         self.cfg = model_config(kind)
@@ -171,6 +171,7 @@ class Trainer:
         self.opt_steps = {"main": 0, "prop": 0}
         self.lr, self.wd, self.num_iters, self.loss_scale = lr, weight_decay, num_iters, loss_scale
         self.world_size = world_size
+        self.use_graph, self._graphs, self._static_data = use_graph, {}, None
         self.requires_grad_fn = get_proposal_requires_grad_fn()
         self.step_count = 0
         self.model.train(); self.estimator.train()
@@ -197,9 +198,8 @@ class Trainer:
         ops.adam_step(self.flat.params[a:b], self.flat.grads[a:b], self.m[a:b], self.v[a:b], lr, 0.9, 0.99, 1e-15, self.wd,
                       1.0 / self.world_size, self.opt_steps[group])
 
-    def train_step(self, data: Dict[str, Tensor]) -> Dict[str, float]:
-        step = self.step_count
-        prop_grad = self.requires_grad_fn(step)
+    def _forward_backward(self, data: Dict[str, Tensor], prop_grad: bool) -> Tensor:
+        """zero grads -> render -> losses -> backward (everything of a step that is the same from step to step)."""
         self.flat.zero_grad()
         results = render_rays(radiance_field=self.model, proposal_estimator=self.estimator, proposal_networks=self.props,
                               data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad)
@@ -209,6 +209,48 @@ class Trainer:
         loss = self.losses(results, data)
         (loss * self.loss_scale).backward()
         fused.join_side_stream()  # weight gradients written on the side stream are complete from here on
+        return loss.detach()
+
+    def _graphed_forward_backward(self, data: Dict[str, Tensor], prop_grad: bool) -> Tensor:
+        """hipGraph replay of _forward_backward: one graph per step type (with / without proposal-net training),
+        captured on first use after a short side-stream warm-up; inputs are copied into static buffers.  The stratified
+        jitter still differs from replay to replay (graph-safe Philox offsets).  All launches go through the stream
+        torch hands out, so the ctypes kernel launches are captured like torch's own; nothing in the step synchronises."""
+        if self._static_data is None:
+            self._static_data = {k: v.clone() for k, v in data.items()}
+        elif data is not self._static_data:
+            for k, v in data.items():
+                if v.data_ptr() != self._static_data[k].data_ptr():
+                    self._static_data[k].copy_(v)
+        sd = self._static_data
+        if prop_grad not in self._graphs:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):  # allocator and lazy-init warm-up outside the capture
+                    self._forward_backward(sd, prop_grad)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward_backward(sd, prop_grad)
+            self._graphs[prop_grad] = (g, out)
+        g, out = self._graphs[prop_grad]
+        g.replay()
+        return out
+
+    def train_step(self, data: Dict[str, Tensor]) -> Dict[str, float]:
+        step = self.step_count
+        prop_grad = self.requires_grad_fn(step)
+        if self.use_graph:
+            try:
+                loss = self._graphed_forward_backward(data, prop_grad)
+            except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, once
+                import warnings
+                warnings.warn(f"hipGraph capture failed ({e!r}); continuing with eager launches")
+                self.use_graph = False
+                loss = self._forward_backward(data, prop_grad)
+        else:
+            loss = self._forward_backward(data, prop_grad)
         if self.world_size > 1:
             # the single RCCL collective of the step (sum; 1/W folded into Adam).  Proposal-net gradients exist only on
             # the steps that train them (same schedule on every rank), so the other steps exchange the main range only
@@ -220,4 +262,4 @@ class Trainer:
             self._adam("prop", lr)
         self._adam("main", lr)
         self.step_count += 1
-        return {"loss": loss.detach(), "prop_grad": prop_grad}
+        return {"loss": loss, "prop_grad": prop_grad}
