@@ -49,7 +49,7 @@ SIGNATURES = {
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
     "emer_contract_bwd": [_P, _P, c_int, _P, _P, c_int64, _P],
     "emer_ray_points": [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int64, c_int32, _P],
-    "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, c_float, c_float, c_int, _P],
+    "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P],
     "emer_stot": [_P, c_int64, c_float, c_float, c_int, _P, _P],
     "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P],
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],

@@ -38,7 +38,7 @@ constexpr int kRaysPerBlock = 4;  // 4 waves per workgroup
 __global__ __launch_bounds__(256) void importance_sample_kernel(const float *__restrict__ vals, const float *__restrict__ cdfs,
                                                                 int64_t R, int32_t m, int32_t n,
                                                                 const float *__restrict__ jitter, float *__restrict__ s_out,
-                                                                float *__restrict__ t_out, float s_min, float s_max, int type) {
+                                                                float *__restrict__ t_out, float *__restrict__ t_ends, float s_min, float s_max, int type) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wave;
@@ -68,7 +68,15 @@ __global__ __launch_bounds__(256) void importance_sample_kernel(const float *__r
         else s = (u - cp) * ((vq - vp) / d) + vp;
         const int64_t o = r * (int64_t)(n + 1) + k;
         s_out[o] = s;
-        if (t_out) t_out[o] = stot_apply(type, s, s_min, s_max);
+        if (t_out) {
+            const float t = stot_apply(type, s, s_min, s_max);
+            if (t_ends) {  // interval form: t_out = starts [R,n], t_ends = ends [R,n] (edge k starts interval k and ends k-1)
+                if (k < n) t_out[r * (int64_t)n + k] = t;
+                if (k > 0) t_ends[r * (int64_t)n + k - 1] = t;
+            } else {
+                t_out[o] = t;
+            }
+        }
     }
 }
 
@@ -83,17 +91,18 @@ __global__ __launch_bounds__(256) void stot_kernel(const float *__restrict__ s, 
 using namespace emer;
 
 extern "C" int emer_importance_sample(const float *vals, const float *cdfs, int64_t R, int32_t m, int32_t n,
-                                      const float *jitter, float *s_out, float *t_out, float t_min, float t_max,
-                                      int stot_type, void *stream) {
+                                      const float *jitter, float *s_out, float *t_out, float *t_ends, float t_min,
+                                      float t_max, int stot_type, void *stream) {
     EMER_REQUIRE(R >= 0 && n >= 1, "importance_sample: bad sizes R=%lld n=%d", (long long)R, n);
     EMER_REQUIRE(m >= 2 && m <= 4096, "importance_sample: m=%d edges per ray not in 2..4096", m);
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(vals && cdfs && s_out, "importance_sample: null pointer");
+    EMER_REQUIRE(!t_ends || t_out, "importance_sample: t_ends needs t_out (the interval starts)");
     EMER_REQUIRE(stot_type >= 0 && stot_type <= 2, "importance_sample: unknown stot_type %d", stot_type);
     const float s_min = stot_fwd_map(stot_type, t_min), s_max = stot_fwd_map(stot_type, t_max);
     const size_t lds = (size_t)kRaysPerBlock * 2 * m * sizeof(float);
     hipLaunchKernelGGL(importance_sample_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlock)), dim3(256), lds, as_stream(stream),
-                       vals, cdfs, R, m, n, jitter, s_out, t_out, s_min, s_max, stot_type);
+                       vals, cdfs, R, m, n, jitter, s_out, t_out, t_ends, s_min, s_max, stot_type);
     return check_launch("importance_sample");
 }
 

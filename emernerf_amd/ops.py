@@ -239,21 +239,27 @@ def ray_points(origins: Tensor, dirs: Tensor, t_starts: Tensor, t_ends: Tensor, 
 
 # ---------------------------------------------------------------------------------- sampler
 def importance_sample(vals: Tensor, cdfs: Tensor, n_intervals: int, jitter: Optional[Tensor] = None,
-                      stot: Optional[Tuple[float, float, str]] = None) -> Tuple[Tensor, Optional[Tensor]]:
-    """nerfacc.pdf.importance_sampling (batched).  Returns (s_edges [R,n+1], t_edges | None)."""
+                      stot: Optional[Tuple[float, float, str]] = None, intervals: bool = False):
+    """nerfacc.pdf.importance_sampling (batched).  Returns (s_edges [R,n+1], t_edges | None), or with
+    ``intervals=True`` (s_edges, t_starts [R,n], t_ends [R,n]) written directly by the kernel (no slicing copies)."""
     _check_cuda(vals, cdfs)
     v, c = _f32c(vals), _f32c(cdfs)
     R, m = v.shape
     j = None if jitter is None else _f32c(jitter).view(-1)
     if j is not None:
         assert j.numel() == R
+    assert not intervals or stot is not None
     with torch.cuda.device(v.device):
         s_out = torch.empty((R, n_intervals + 1), device=v.device, dtype=torch.float32)
-        t_out = torch.empty_like(s_out) if stot is not None else None
+        if intervals:
+            t_out = torch.empty((R, n_intervals), device=v.device, dtype=torch.float32)
+            t_end = torch.empty_like(t_out)
+        else:
+            t_out, t_end = (torch.empty_like(s_out) if stot is not None else None), None
         t_min, t_max, typ = stot if stot is not None else (0.0, 1.0, "uniform")
-        _lib.call("emer_importance_sample", _ptr(v), _ptr(c), R, m, n_intervals, _ptr(j), _ptr(s_out), _ptr(t_out),
+        _lib.call("emer_importance_sample", _ptr(v), _ptr(c), R, m, n_intervals, _ptr(j), _ptr(s_out), _ptr(t_out), _ptr(t_end),
                   float(t_min), float(t_max), STOT_TYPES[typ], _stream(v))
-    return s_out, t_out
+    return (s_out, t_out, t_end) if intervals else (s_out, t_out)
 
 
 def stot(s: Tensor, t_min: float, t_max: float, transform_type: str) -> Tensor:

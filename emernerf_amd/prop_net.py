@@ -83,8 +83,7 @@ class PropNetEstimator(AbstractEstimator):
         stot = (float(near_plane), float(far_plane), sampling_type)
         for i, (level_fn, level_samples) in enumerate(zip(prop_sigma_fns, prop_samples)):
             jitter = self.jitter_fn(n_rays, dev) if stratified else None
-            s_vals, t_vals = ops.importance_sample(s_vals, cdfs, level_samples, jitter, stot=stot)
-            t_starts, t_ends = t_vals[..., :-1], t_vals[..., 1:]
+            s_vals, t_starts, t_ends = ops.importance_sample(s_vals, cdfs, level_samples, jitter, stot=stot, intervals=True)
             with torch.set_grad_enabled(requires_grad):
                 sigmas = level_fn(t_starts, t_ends)["density"].squeeze(-1)
                 assert sigmas.shape == t_starts.shape
@@ -93,10 +92,10 @@ class PropNetEstimator(AbstractEstimator):
                     self.prop_cache.append((RayIntervals(vals=s_vals), cdfs, i))
             cdfs = cdfs.detach() if not requires_grad else cdfs
         jitter = self.jitter_fn(n_rays, dev) if stratified else None
-        s_vals, t_vals = ops.importance_sample(s_vals, cdfs.detach(), num_samples, jitter, stot=stot)
+        s_vals, t_starts, t_ends = ops.importance_sample(s_vals, cdfs.detach(), num_samples, jitter, stot=stot, intervals=True)
         if requires_grad:
             self.prop_cache.append((RayIntervals(vals=s_vals), None, None))
-        return t_vals[..., :-1], t_vals[..., 1:]
+        return t_starts, t_ends
 
     @torch.enable_grad()
     def compute_loss(self, trans: Tensor, loss_scaler: float = 1.0) -> Tensor:

@@ -139,11 +139,14 @@ int emer_ray_points(const float *origins, const float *dirs, const float *t_star
  * Proposal sampler (replaces nerfacc.pdf.importance_sampling + _transform_stot:
  *   third_party/nerfacc_prop_net.py:153,156,172-173,299-339).  Frozen spec: SURVEY.md A.2.
  * ---------------------------------------------------------------------------------------------- */
-/* vals/cdfs [R,m] -> s_out [R,n+1] (sorted edges in s) and, if t_out != NULL, t_out = stot(s_out).
+/* vals/cdfs [R,m] -> s_out [R,n+1] (sorted edges in s) and, if t_out != NULL, t = stot(s_out):
+ *   t_ends == NULL: t_out [R,n+1] = the edges;
+ *   t_ends != NULL: t_out [R,n] = interval starts, t_ends [R,n] = interval ends (what PropNetEstimator.sampling
+ *                   returns, nerfacc_prop_net.py:176-179, without slicing copies).
  * jitter: NULL (centre of bin) or [R] U(0,1) per ray (stratified). Bit-exact vs the oracle. */
 int emer_importance_sample(const float *vals, const float *cdfs, int64_t n_rays, int32_t m,
                            int32_t n_intervals, const float *jitter, float *s_out, float *t_out,
-                           float t_min, float t_max, int stot_type, void *stream);
+                           float *t_ends, float t_min, float t_max, int stot_type, void *stream);
 int emer_stot(const float *s, int64_t n, float t_min, float t_max, int stot_type, float *t,
               void *stream);
 

@@ -171,6 +171,23 @@ def _torch_render(ts, te, sg):
     return T * a, T, a
 
 
+def test_importance_sample_interval_outputs(hip_lib):
+    """intervals=True: the kernel's (t_starts, t_ends) are bit-identical to slicing its edge output."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    R, m, n = 37, 65, 128
+    vals = torch.sort(torch.rand(R, m, generator=g), -1).values
+    cdf = torch.cumsum(torch.rand(R, m, generator=g), -1)
+    cdf = (cdf - cdf[:, :1]) / (cdf[:, -1:] - cdf[:, :1])
+    jit = torch.rand(R, generator=g)
+    stot = (0.1, 1000.0, "uniform_lindisp")
+    s0, t = ops.importance_sample(vals.to(dev), cdf.to(dev), n, jit.to(dev), stot=stot)
+    s1, ts, te = ops.importance_sample(vals.to(dev), cdf.to(dev), n, jit.to(dev), stot=stot, intervals=True)
+    assert torch.equal(s0, s1) and ts.is_contiguous() and te.is_contiguous()
+    assert torch.equal(ts, t[:, :-1]) and torch.equal(te, t[:, 1:])
+
+
 @pytest.mark.parametrize("R,S", [(1, 1), (3, 64), (50, 128), (7, 130), (4, 333)])
 def test_render_weights(hip_lib, oracle, R, S):
     from emernerf_amd import ops
