@@ -449,7 +449,6 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // Placement only affects speed, never results.
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
-constexpr int kHeavyBits = 8;                         // hashed scan: words with at least this many hits are unpacked whole
 constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
 constexpr int kWaveQueue = 64 * kDrainK + 64;         // wave-private hit queue (sample ids): < 64*K left over + <= 64 pushed
 
@@ -565,24 +564,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             if ((wt >> lane) & 1ull) wq[qn + (uint32_t)__popcll(wt & lt_mask)] = (uint32_t)(n0 + lane);
             qn += (uint32_t)__popcll(wt);
         } else {
-            // Coarse hashed levels make BURSTY bitmaps (consecutive samples of a ray share a cell, hence a slice): a few
-            // words hold most of the bits, and peeling one bit per lane per iteration would take max-popcount iterations
-            // at low lane utilisation.  So a word with many bits is unpacked the dense way (one iteration: lane i tests
-            // bit i), and only the light words are peeled lane-parallel.
-            const unsigned long long heavy = __ballot(__popcll(wv) >= kHeavyBits);
-            if (heavy) {
-                const int t = __ffsll((long long)heavy) - 1;
-                const uint64_t wt = (uint64_t)__shfl((unsigned long long)wv, t, kWave);  // wave-uniform
-                const int64_t n0 = (wi + (int64_t)(t - lane)) << 6;                      // lane t's word index is wi + (t - lane)
-                if ((wt >> lane) & 1ull) wq[qn + (uint32_t)__popcll(wt & lt_mask)] = (uint32_t)(n0 + lane);
-                qn += (uint32_t)__popcll(wt);
-                if (lane == t) wv = 0ull;
-            } else {
-                const bool hit = wv != 0ull;
-                if (hit) wq[qn + (uint32_t)__popcll(live & lt_mask)] = (uint32_t)((wi << 6) + (__ffsll((long long)wv) - 1));
-                wv &= wv - 1ull;
-                qn += (uint32_t)__popcll(live);  // wave-private push: prefix by popcount, no atomics, no barrier
-            }
+            // (Unpacking words with many hits whole -- as the dense branch does -- was tried for the bursty bitmaps of
+            // coarse hashed levels and measured 3 % slower on the training distribution; tools/ab_bench.py.)
+            const bool hit = wv != 0ull;
+            if (hit) wq[qn + (uint32_t)__popcll(live & lt_mask)] = (uint32_t)((wi << 6) + (__ffsll((long long)wv) - 1));
+            wv &= wv - 1ull;
+            qn += (uint32_t)__popcll(live);  // wave-private push: prefix by popcount, no atomics, no barrier
         }
         // single drain site: kDrainK * 64 queued hits at a time on dense lanes (everything that is left once the
         // scan is done).  The x / dout loads of all kDrainK groups are issued before any is consumed: a wave's
