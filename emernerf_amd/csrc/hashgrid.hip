@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
 constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
-constexpr int kWaveQueue = 64 * kDrainK + 64;         // wave-private hit queue (sample ids): < 64*K left over + <= 64 pushed
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
 // they form RUNS that share one cell (and therefore all 2^D corner entries).  Values are reduced per run
@@ -468,6 +467,29 @@ __device__ __forceinline__ void run_reduce(float (&v)[NV], int run_start, int la
         }
     }
 }
+
+
+// ---- analytic hit compaction (used by the owner-computes backward) ----------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, off, kWave);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// position of the k-th (0-based) set bit of w; k < popcount(w)
+__device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
+    uint32_t x = (uint32_t)w, base = 0, c = (uint32_t)__popc((uint32_t)w);
+    if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
+    c = (uint32_t)__popc(x & 0xFFFFu); if (k >= c) { k -= c; x >>= 16; base += 16; }
+    c = (uint32_t)__popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
+    c = (uint32_t)__popc(x & 0xFu);    if (k >= c) { k -= c; x >>= 4;  base += 4; }
+    c = (uint32_t)__popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  base += 2; }
+    if (k >= (x & 1u)) base += 1;
+    return base;
+}
+constexpr int kScanWords = 64 + 64 + 32;  // per-wave LDS scratch of the compaction, in u64: words, head bit-vector, offsets
 
 template <int D, int F>
 __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kernel(const emer_grid_desc g, const SlicePlan plan,
@@ -520,10 +542,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const int64_t w_end = (w_begin + words_per_range < n_words) ? w_begin + words_per_range : n_words;
 
     double *acc = smem;                                                                // [max_local * F] (ds_add_f64)
-    uint32_t *queue = reinterpret_cast<uint32_t *>(smem + (size_t)plan.max_local * F); // [waves][kWaveQueue]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *wq = queue + (size_t)wave * kWaveQueue;
-    uint32_t qn = 0;  // wave-uniform fill level of this wave's queue
+    // wave-private scratch of the hit compaction, behind the accumulators
+    uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)wave * kScanWords;
+    uint64_t *Wl = scratch;
+    unsigned long long *Hv = reinterpret_cast<unsigned long long *>(scratch + 64);  // (one type for plain and atomic accesses)
+    uint32_t *El = reinterpret_cast<uint32_t *>(scratch + 128);
 
     for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
@@ -532,56 +556,61 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + (slice >> plan.gsub[level])) * n_words;  // 1 bit per sample
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    // Every lane holds one 64-sample word of the bitmap; a trip of the workgroup covers 1024 words.  The next
-    // trip's word is loaded while the current one is consumed.
-    //   hashed levels: order is irrelevant -> all lanes peel the lowest set bit of their word together;
-    //   dense levels: the queue must stay in SAMPLE ORDER (runs of one ray share a cell, see run_reduce) ->
-    //                 the wave walks its non-empty words one at a time, lane i testing bit i.
-    int64_t wbase = w_begin;       // first word of the NEXT trip
-    int64_t wi = 0;                // this lane's current word index
-    uint64_t wv = 0;               // this lane's current word (remaining bits)
-    unsigned long long nz = 0;     // dense: lanes of this wave whose word is still to be walked
-    // word of a trip held by this lane: hashed = thread id; dense = interleaved over the waves so that short ranges
-    // still occupy all 16 waves (lane t of wave w holds word t * 16 + w; words of a wave stay in increasing order)
+    // Every lane holds one 64-sample word of the bitmap; a trip of the workgroup covers 1024 words and the next trip's
+    // word is loaded while the current one is consumed.  The hits of a wave's 64 words are COMPACTED ANALYTICALLY --
+    // no per-bit peeling, whose iteration count is the largest popcount in the wave (bursty bitmaps: a few words hold
+    // most bits) at a few per cent lane utilisation, and no LDS queue:
+    //   p_i = popcount(word_i); an exclusive wave scan gives every word its offset E_i in the wave's hit list;
+    //   the non-empty words are packed to the front of an LDS array (ballot prefix), and a 4096-bit "head" vector gets
+    //   bit E_i set for each of them.  Hit number j then belongs to packed word rank(j) = (#head bits at positions <= j)
+    //   - 1, a popcount over one head word plus a scanned base, and is the (j - E)-th set bit of that word (select64).
+    // So lane l of chunk c materialises hit 64 c + l directly: 64 hits per ~45 instructions at full lane utilisation,
+    // already in sample order (which the dense levels' run reduction needs).
+    // Word of a trip held by this lane: hashed = thread id; dense = interleaved over the waves so that short ranges
+    // still occupy all 16 waves (lane t of wave w holds word t * 16 + w; words of a wave stay in increasing order).
     const int64_t my_word = dense ? (int64_t)lane * kSliceWaves + wave : (int64_t)threadIdx.x;
-    uint64_t pre = (wbase + my_word < w_end) ? bm[wbase + my_word] : 0ull;
-    bool done = false;
-    while (!done) {
-        const unsigned long long live = dense ? nz : __ballot(wv != 0ull);
-        if (!live) {
-            if (wbase < w_end) {
-                wv = pre; wi = wbase + my_word; wbase += kSliceThreads;
-                pre = (wbase + my_word < w_end) ? bm[wbase + my_word] : 0ull;
-                nz = __ballot(wv != 0ull);
-                continue;
-            }
-            done = true;
-        } else if (dense) {
-            const int t = __ffsll((long long)nz) - 1;
-            nz &= nz - 1ull;
-            const uint64_t wt = (uint64_t)__shfl((unsigned long long)wv, t, kWave);  // wave-uniform
-            const int64_t n0 = (wi + (int64_t)(t - lane) * kSliceWaves) << 6;
-            if ((wt >> lane) & 1ull) wq[qn + (uint32_t)__popcll(wt & lt_mask)] = (uint32_t)(n0 + lane);
-            qn += (uint32_t)__popcll(wt);
-        } else {
-            // (Unpacking words with many hits whole -- as the dense branch does -- was tried for the bursty bitmaps of
-            // coarse hashed levels and measured 3 % slower on the training distribution; tools/ab_bench.py.)
-            const bool hit = wv != 0ull;
-            if (hit) wq[qn + (uint32_t)__popcll(live & lt_mask)] = (uint32_t)((wi << 6) + (__ffsll((long long)wv) - 1));
-            wv &= wv - 1ull;
-            qn += (uint32_t)__popcll(live);  // wave-private push: prefix by popcount, no atomics, no barrier
+    const int64_t lane_word_step = dense ? kSliceWaves : 1, wave_word0 = dense ? wave : wave * 64;
+    uint64_t pre = (w_begin + my_word < w_end) ? bm[w_begin + my_word] : 0ull;
+    for (int64_t wbase = w_begin; wbase < w_end; wbase += kSliceThreads) {
+        const uint64_t wv = pre;
+        pre = (wbase + kSliceThreads + my_word < w_end) ? bm[wbase + kSliceThreads + my_word] : 0ull;
+        const uint32_t p = (uint32_t)__popcll(wv);
+        const uint32_t incl = wave_inclusive_sum_u32(p, lane);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, kWave);
+        if (total == 0u) continue;
+        const uint32_t excl = incl - p;
+        const unsigned long long nzm = __ballot(p != 0u);
+        Hv[lane] = 0ull;
+        if (p != 0u) {
+            const uint32_t rk = (uint32_t)__popcll(nzm & lt_mask);
+            Wl[rk] = wv;
+            El[rk] = excl | ((uint32_t)lane << 16);
+            atomicOr(Hv + (excl >> 6), 1ull << (excl & 63u));  // ds_or_b64
         }
-        // single drain site: kDrainK * 64 queued hits at a time on dense lanes (everything that is left once the
-        // scan is done).  The x / dout loads of all kDrainK groups are issued before any is consumed: a wave's
-        // drains form a serial latency chain, so the loads in flight per drain set the speed.
-        while (qn >= 64u * kDrainK || (done && qn > 0u)) {
-            const uint32_t take = qn < 64u * kDrainK ? qn : 64u * kDrainK;
-            const uint32_t qbase = qn - take;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the packed words / head bits of all lanes are visible
+        const uint64_t hv = Hv[lane];
+        const uint32_t hp = (uint32_t)__popcll(hv);
+        const uint32_t hexcl = wave_inclusive_sum_u32(hp, lane) - hp;  // head bits before this lane's head word
+        const uint32_t n_chunks = (total + 63u) >> 6;
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += kDrainK) {
+            const uint32_t take = (total - 64u * c0) < 64u * kDrainK ? (total - 64u * c0) : 64u * kDrainK;
             float xs[kDrainK][D], go[kDrainK][F];
 #pragma unroll
             for (int k = 0; k < kDrainK; ++k) {
-                const uint32_t e = (uint32_t)(k * 64 + lane);
-                const uint32_t n = wq[qbase + (e < take ? e : 0u)];
+                uint32_t c = c0 + (uint32_t)k;
+                c = c < n_chunks ? c : n_chunks - 1u;                               // wave-uniform
+                const uint32_t hr_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, (int)c);
+                const uint32_t hr_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), (int)c);
+                const uint32_t hx = (uint32_t)__builtin_amdgcn_readlane((int)hexcl, (int)c);
+                const uint64_t hr = ((uint64_t)hr_hi << 32) | hr_lo;
+                uint32_t j = 64u * c + (uint32_t)lane;
+                j = j < total ? j : total - 1u;                                      // tail lanes repeat the last hit (masked below)
+                const uint64_t upto = ((j & 63u) == 63u) ? ~0ull : ((2ull << (j & 63u)) - 1ull);
+                const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
+                const uint64_t wq = Wl[rank];
+                const uint32_t el = El[rank];
+                const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
+                const uint32_t n = (uint32_t)(((wbase + wave_word0 + (int64_t)(el >> 16) * lane_word_step) << 6) + bit);
                 load_x<D>(x, (int64_t)n, xs[k]);
                 if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
                 else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
@@ -655,28 +684,34 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         if ((((gi[0] ^ h) & (li.size - 1u)) >> shift) == slice) match |= 1u << m;
                     }
                     if (!valid) match = 0u;
-                    while (__ballot(match != 0u)) {
-                        if (match != 0u) {
-                            const uint32_t m = (uint32_t)__ffs((int)match) - 1u;
-                            match &= match - 1u;
-                            uint32_t h = 0;
-                            float wa = 1.0f - w[0], wb = w[0];  // same product order as the generic path: ((t0*t1)*t2)*t3
+                    auto pair_body = [&]() {  // every lane: its next matching pair (if any)
+                        const bool has = match != 0u;
+                        const uint32_t m = has ? (uint32_t)__ffs((int)match) - 1u : 0u;
+                        match &= match - 1u;  // (0 stays 0)
+                        uint32_t h = 0;
+                        float wa = 1.0f - w[0], wb = w[0];  // same product order as the generic path: ((t0*t1)*t2)*t3
 #pragma unroll
-                            for (int d = 1; d < D; ++d) {
-                                const bool bit = (m >> (d - 1)) & 1u;
-                                h ^= bit ? hd[d][1] : hd[d][0];
-                                const float t = bit ? w[d] : 1.0f - w[d];
-                                wa *= t; wb *= t;
-                            }
-                            const uint32_t idx0 = (gi[0] ^ h) & (li.size - 1u);
-                            const uint32_t idx1 = ((gi[0] + 1u) ^ h) & (li.size - 1u);
+                        for (int d = 1; d < D; ++d) {
+                            const bool bit = (m >> (d - 1)) & 1u;
+                            h ^= bit ? hd[d][1] : hd[d][0];
+                            const float t = bit ? w[d] : 1.0f - w[d];
+                            wa *= t; wb *= t;
+                        }
+                        const uint32_t idx0 = (gi[0] ^ h) & (li.size - 1u);
+                        const uint32_t idx1 = ((gi[0] + 1u) ^ h) & (li.size - 1u);
+                        if (has) {
 #pragma unroll
                             for (int f = 0; f < F; ++f) {
                                 atomicAdd(acc + (size_t)(idx0 - first) * F + f, (double)(wa * go[k][f]));  // ds_add_f64
                                 atomicAdd(acc + (size_t)(idx1 - first) * F + f, (double)(wb * go[k][f]));
                             }
                         }
-                    }
+                    };
+                    // a hit has one matching pair, sometimes two: two straight-line rounds (no wave-level loop, so the
+                    // scheduler can overlap them and the neighbouring groups), then the rare rest
+                    pair_body();
+                    pair_body();
+                    while (__ballot(match != 0u)) pair_body();
                 } else {
 #pragma unroll
                     for (uint32_t m = 0; m < (1u << D); ++m) {
@@ -695,7 +730,6 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                     }
                 }
             }
-            qn -= take;
         }
     }
     __syncthreads();
@@ -937,7 +971,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
     uint32_t n_blocks = 256;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
-    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kWaveQueue * sizeof(uint32_t);
+    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kScanWords * sizeof(uint64_t);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
