@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // Placement only affects speed, never results.
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
+constexpr uint32_t kStridedHitsMaxRes = 420;          // hashed levels up to this resolution spread a wave's hits over distant samples
 constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
@@ -489,7 +490,7 @@ __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
     if (k >= (x & 1u)) base += 1;
     return base;
 }
-constexpr int kScanWords = 64 + 64 + 32;  // per-wave LDS scratch of the compaction, in u64: words, head bit-vector, offsets
+constexpr int kScanWords = 64 + 64 + 32 + 32;  // per-wave LDS scratch of the compaction, in u64: words, head bit-vector, offsets, head bases
 
 template <int D, int F>
 __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kernel(const emer_grid_desc g, const SlicePlan plan,
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     }
     const LevelInfo li = level_info(g, level);
     const bool dense = !li.hashed;
+    const bool consecutive = dense || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const bool pairable = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
     const uint32_t first = slice << shift;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     uint64_t *scratch = reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)wave * kScanWords;
     uint64_t *Wl = scratch;
     unsigned long long *Hv = reinterpret_cast<unsigned long long *>(scratch + 64);  // (one type for plain and atomic accesses)
-    uint32_t *El = reinterpret_cast<uint32_t *>(scratch + 128);
+    uint32_t *El = reinterpret_cast<uint32_t *>(scratch + 128), *Hx = reinterpret_cast<uint32_t *>(scratch + 160);
 
     for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
@@ -591,26 +593,41 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         const uint64_t hv = Hv[lane];
         const uint32_t hp = (uint32_t)__popcll(hv);
         const uint32_t hexcl = wave_inclusive_sum_u32(hp, lane) - hp;  // head bits before this lane's head word
+        if (!consecutive) { Hx[lane] = hexcl; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
         const uint32_t n_chunks = (total + 63u) >> 6;
         for (uint32_t c0 = 0; c0 < n_chunks; c0 += kDrainK) {
             const uint32_t take = (total - 64u * c0) < 64u * kDrainK ? (total - 64u * c0) : 64u * kDrainK;
             float xs[kDrainK][D], go[kDrainK][F];
+            bool vld[kDrainK];
 #pragma unroll
             for (int k = 0; k < kDrainK; ++k) {
                 uint32_t c = c0 + (uint32_t)k;
                 c = c < n_chunks ? c : n_chunks - 1u;                               // wave-uniform
-                const uint32_t hr_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, (int)c);
-                const uint32_t hr_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), (int)c);
-                const uint32_t hx = (uint32_t)__builtin_amdgcn_readlane((int)hexcl, (int)c);
-                const uint64_t hr = ((uint64_t)hr_hi << 32) | hr_lo;
-                uint32_t j = 64u * c + (uint32_t)lane;
-                j = j < total ? j : total - 1u;                                      // tail lanes repeat the last hit (masked below)
+                // Lane l takes hit 64 c + l (sample order) on dense levels -- the run reduction needs it -- and on FINE hashed
+                // levels, where neighbouring hits share x / dout cache lines.  On COARSE hashed levels consecutive samples
+                // of a ray share cells and would serialise on the same LDS address: there lane l takes hit l * n_chunks +
+                // c, so the lanes of one instruction work on hits far apart (different rays).
+                uint32_t j = consecutive ? 64u * c + (uint32_t)lane : (uint32_t)lane * n_chunks + c;
+                const bool in_range = j < total;
+                j = in_range ? j : total - 1u;                                       // out-of-range lanes repeat the last hit (masked below)
+                uint64_t hr;
+                uint32_t hx;
+                if (consecutive) {
+                    const uint32_t hr_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, (int)c);
+                    const uint32_t hr_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), (int)c);
+                    hx = (uint32_t)__builtin_amdgcn_readlane((int)hexcl, (int)c);
+                    hr = ((uint64_t)hr_hi << 32) | hr_lo;
+                } else {
+                    hr = Hv[j >> 6];
+                    hx = Hx[j >> 6];
+                }
                 const uint64_t upto = ((j & 63u) == 63u) ? ~0ull : ((2ull << (j & 63u)) - 1ull);
                 const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
                 const uint64_t wq = Wl[rank];
                 const uint32_t el = El[rank];
                 const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
                 const uint32_t n = (uint32_t)(((wbase + wave_word0 + (int64_t)(el >> 16) * lane_word_step) << 6) + bit);
+                vld[k] = in_range && (c0 + (uint32_t)k) < n_chunks;
                 load_x<D>(x, (int64_t)n, xs[k]);
                 if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
                 else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #pragma unroll
             for (int k = 0; k < kDrainK; ++k) {
                 if ((uint32_t)(k * 64) >= take) break;  // wave-uniform
-                const bool valid = (uint32_t)(k * 64 + lane) < take;
+                const bool valid = vld[k];
                 float w[D];
                 uint32_t gi[D];
                 cell_of<D>(li, xs[k], gi, w);
