@@ -181,7 +181,10 @@ struct SlicePlan {
     uint32_t n_ranges[EMER_MAX_LEVELS];  // dense levels: the sample stream is also cut in ranges (2-D decomposition)
     uint32_t max_local;                  // largest slice (entries)
     uint32_t ok;                         // 0 when some level would need more than 64 bitmap groups of 64 slices
-    uint8_t xcd_of[EMER_MAX_LEVELS];     // backward: the XCD (0..7) that owns each level (cost-balanced)
+    // (32-bit on purpose: a uint8_t array in this by-value kernel argument, indexed in a loop, was read back wrong by
+    // the device code -- hipcc 7.2)
+    uint32_t xcd_of[EMER_MAX_LEVELS];    // backward: the XCD (0..7) that owns each level (cost-balanced)
+    uint32_t order[EMER_MAX_LEVELS];     // backward: levels in the order an XCD's list walks them (heaviest items first)
     uint32_t items_per_xcd[8];           // backward work items ((level, slice, range) triples) on each XCD's list
 };
 
@@ -210,10 +213,14 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             p.n_ranges[l] = 1;
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
-            // use as FEW slices as the LDS allows and cut the sample stream instead (~128 workgroups per level)
+            // use as FEW slices as the LDS allows and cut the sample stream instead
             while ((1u << (k + 1)) <= max_entries && (1u << k) < size) ++k;
             const uint32_t ns = (uint32_t)ceil_div(size, 1ll << k);
-            uint32_t nr = 128u / (ns ? ns : 1u);
+            // ~256 work items per dense level (at most 128 ranges): a flat scene puts most samples into two or three
+            // slabs, and ONE slab-range item must not become the critical path of the whole kernel (with 128 items the
+            // heaviest item of level 4 alone took as long as the kernel: tools/probe_levels_train.py)
+            uint32_t nr = 256u / (ns ? ns : 1u);
+            if (nr > 128u) nr = 128u;
             p.n_ranges[l] = nr < 1u ? 1u : nr;
         }
         p.shift[l] = k;
@@ -242,9 +249,17 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         }
         int x = 0;
         for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
-        placed[best] = true; p.xcd_of[best] = (uint8_t)x; load[x] += best_cost; nblk[x] += p.n_slices[best] * p.n_ranges[best];
+        placed[best] = true; p.xcd_of[best] = (uint32_t)x; load[x] += best_cost; nblk[x] += p.n_slices[best] * p.n_ranges[best];
     }
     for (int i = 0; i < 8; ++i) p.items_per_xcd[i] = nblk[i];
+    // within a list: levels with the most expensive single items first, so the longest items start early
+    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.order[l] = l;
+    for (uint32_t a = 0; a + 1 < g->n_levels; ++a)
+        for (uint32_t b = a + 1; b < g->n_levels; ++b) {
+            const float ca = level_cost(g, p, p.order[a]) / (float)(p.n_slices[p.order[a]] * p.n_ranges[p.order[a]]);
+            const float cb = level_cost(g, p, p.order[b]) / (float)(p.n_slices[p.order[b]] * p.n_ranges[p.order[b]]);
+            if (cb > ca) { const uint32_t t = p.order[a]; p.order[a] = p.order[b]; p.order[b] = t; }
+        }
     return p;
 }
 
@@ -524,7 +539,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const uint32_t xcd = item >> 24;
     uint32_t j = item & 0xFFFFFFu;
     uint32_t level = 0, slice = 0, range = 0;
-    for (; level < g.n_levels; ++level) {
+    for (uint32_t oi = 0; oi < g.n_levels; ++oi) {
+        level = plan.order[oi];
         if (plan.xcd_of[level] != xcd) continue;
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
         if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; break; }
