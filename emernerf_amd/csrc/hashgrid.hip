@@ -196,6 +196,14 @@ static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l)
     return (0.22f + 0.13f * log2f(1.0f + (float)p.n_slices[l])) * rescans;
 }
 
+// worst-case work of ONE item of a level, in units of the sample count: a hashed slice sees ~4/64 of the samples
+// (more on coarse levels, see level_cost); a dense slab-range item may see ALL samples of its range (flat scenes
+// concentrate in two or three slabs)
+static float item_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
+    if (g->hashed[l]) return (4.0f / 64.0f) * (0.28f + 36.0f / (float)g->res[l]) / 0.3f * (float)(1u << p.gsub[l]) / (float)p.n_ranges[l];
+    return 2.0f / (float)p.n_ranges[l];
+}
+
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     SlicePlan p;
     const uint32_t F = g->n_features;
@@ -210,7 +218,7 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             // over all samples each
             while ((1ull << k) * 64ull < size) ++k;
             while ((1u << k) > max_entries) --k;
-            p.n_ranges[l] = 1;
+            p.n_ranges[l] = 1;  // (cutting the sample stream of coarse hashed levels as well was measured neutral)
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
             // use as FEW slices as the LDS allows and cut the sample stream instead
@@ -256,8 +264,7 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.order[l] = l;
     for (uint32_t a = 0; a + 1 < g->n_levels; ++a)
         for (uint32_t b = a + 1; b < g->n_levels; ++b) {
-            const float ca = level_cost(g, p, p.order[a]) / (float)(p.n_slices[p.order[a]] * p.n_ranges[p.order[a]]);
-            const float cb = level_cost(g, p, p.order[b]) / (float)(p.n_slices[p.order[b]] * p.n_ranges[p.order[b]]);
+            const float ca = item_cost(g, p, p.order[a]), cb = item_cost(g, p, p.order[b]);
             if (cb > ca) { const uint32_t t = p.order[a]; p.order[a] = p.order[b]; p.order[b] = t; }
         }
     return p;
