@@ -15,7 +15,7 @@ EMER_MAX_LEVELS = 32
 
 F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TRUNC_EXP = 0, 1, 2, 3
-STOT_TYPES = {"uniform": 0, "uniform_lindisp": 1, "lindisp": 2}
+STOT_TYPES = {"uniform": 0, "uniform_lindisp": 1, "lindisp": 2, "sqrt": 3, "log": 4, "uniform_lindisp_0": 5}  # TRANSFROM_DICT, nerfacc_prop_net.py:298-314
 
 
 class GridDesc(ctypes.Structure):
@@ -52,7 +52,7 @@ SIGNATURES = {
     "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P],
     "emer_stot": [_P, c_int64, c_float, c_float, c_int, _P, _P],
     "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P],
-    "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
+    "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
     "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P, _P],

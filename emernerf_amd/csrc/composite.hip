@@ -75,12 +75,14 @@ __global__ __launch_bounds__(256) void render_weights_fwd_kernel(const float *__
 }
 
 // Reverse mode.  With a_i = sigma_i*dt_i, T_i = exp(-sum_{j<i} a_j), w_i = T_i (1 - exp(-a_i)):
-//   dL/da_i = gw_i * T_{i+1} - sum_{k>i} (gw_k w_k + gT_k T_k),   T_{i+1} = T_i exp(-a_i)
-// with gw_i = d_weights_i + g(sum w) + g(sum w*mid) * mid_i.
+//   dL/da_i = gw_i * T_{i+1} - sum_{k>i} (gw_k w_k + gT_k T_k) + galpha_i * exp(-a_i),   T_{i+1} = T_i exp(-a_i)
+// with gw_i = d_weights_i + g(sum w) + g(sum w*mid) * mid_i (alpha_i = 1 - exp(-a_i) is a differentiable output too:
+// the reference's render_utils.py:73-77 forms weights = trans * alphas itself).
 __global__ __launch_bounds__(256) void render_weights_bwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
                                                                  const float *__restrict__ sigma,
                                                                  const float *__restrict__ d_weights,
                                                                  const float *__restrict__ d_trans,
+                                                                 const float *__restrict__ d_alphas,
                                                                  const float *__restrict__ d_ray_stats, int64_t R, int32_t S,
                                                                  float *__restrict__ d_sigma) {
     __shared__ float chunk_base[kRaysPerBlockC][64];  // per-wave exclusive prefix of each 64-chunk (S <= 4096)
@@ -118,10 +120,11 @@ __global__ __launch_bounds__(256) void render_weights_bwd_kernel(const float *__
         float gw = (ok && d_weights) ? d_weights[i] : 0.0f;
         gw += g0 + g1 * ((a + b) / 2.0f);
         const float gT = (ok && d_trans) ? d_trans[i] : 0.0f;
+        const float gA = (ok && d_alphas) ? d_alphas[i] : 0.0f;
         const float term = ok ? gw * w + gT * T : 0.0f;
         const float sfx_incl = wave_inclusive_suffix_sum(term, lane);
         const float later = suffix + (sfx_incl - term);  // strictly-later samples
-        if (ok) d_sigma[i] = dt * (gw * T * e - later);
+        if (ok) d_sigma[i] = dt * (gw * T * e - later + gA * e);
         suffix += __shfl(sfx_incl, 0, kWave);
     }
 }
@@ -234,13 +237,13 @@ extern "C" int emer_render_weights_fwd(const float *ts, const float *te, const f
 }
 
 extern "C" int emer_render_weights_bwd(const float *ts, const float *te, const float *sigma, const float *d_weights,
-                                       const float *d_trans, const float *d_ray_stats, int64_t R, int32_t S,
-                                       float *d_sigma, void *stream) {
+                                       const float *d_trans, const float *d_alphas, const float *d_ray_stats, int64_t R,
+                                       int32_t S, float *d_sigma, void *stream) {
     EMER_REQUIRE(R >= 0 && S >= 1 && S <= 4096, "render_weights_bwd: bad sizes R=%lld S=%d (S <= 4096)", (long long)R, S);
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(ts && te && sigma && d_sigma, "render_weights_bwd: null pointer");
     hipLaunchKernelGGL(render_weights_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream),
-                       ts, te, sigma, d_weights, d_trans, d_ray_stats, R, S, d_sigma);
+                       ts, te, sigma, d_weights, d_trans, d_alphas, d_ray_stats, R, S, d_sigma);
     return check_launch("render_weights_bwd");
 }
 

@@ -280,7 +280,8 @@ extern "C" int emer_layout_transpose(const float *src, float *dst, int32_t n_lev
     EMER_REQUIRE(n >= 0 && n_levels >= 1 && n_features >= 1 && n_levels * n_features <= 512, "layout_transpose: bad sizes");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(src && dst && src != dst, "layout_transpose: null or aliased pointers");
-    const size_t lds = (size_t)64 * (n_levels * n_features + 1) * sizeof(float);
+    const size_t lds = (size_t)64 * (n_levels * n_features + 1) * sizeof(float);  // up to 128.25 KiB at L*F = 512
+    if (int rc = reserve_lds(reinterpret_cast<const void *>(layout_transpose_kernel), lds, "layout_transpose")) return rc;
     hipLaunchKernelGGL(layout_transpose_kernel, dim3((uint32_t)ceil_div(n, 64)), dim3(256), lds, as_stream(stream), src, dst,
                        n_levels, n, n_features, to_row_major);
     return check_launch("layout_transpose");

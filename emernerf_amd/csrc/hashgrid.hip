@@ -705,10 +705,13 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                             for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
                         }
                     }
-                } else if (pairable) {
+                } else if (pairable && !__ballot(valid && gi[0] >= li.res)) {
                     // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
                     // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
-                    // slice.  Every lane first finds WHICH of its 2^(D-1) pairs live in this slice (usually one), then
+                    // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
+                    // (tcnn semantics) and may put the two x-corners in different slices: a wave holding such a hit
+                    // takes the generic per-corner path below (wave-uniform test, never taken by EmerNeRF's own inputs).
+                    // Every lane first finds WHICH of its 2^(D-1) pairs live in this slice (usually one), then
                     // the wave loops over "next matching pair of each lane": ~2 pair bodies per hit instead of 2^(D-1)
                     // mostly-masked ones.
                     const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};

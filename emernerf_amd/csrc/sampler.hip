@@ -21,12 +21,18 @@ namespace emer {
 __host__ __device__ __forceinline__ float stot_fwd_map(int type, float t) {
     if (type == EMER_STOT_UNIFORM_LINDISP) return t < 200.0f ? t / 400.0f : 1.0f - 1.0f / (2.0f * t / 200.0f);
     if (type == EMER_STOT_LINDISP) return 1.0f / t;
+    if (type == EMER_STOT_SQRT) return sqrtf(t);
+    if (type == EMER_STOT_LOG) return logf(t);
+    if (type == EMER_STOT_UNIFORM_LINDISP_0) return t < 1.0f ? t / 2.0f : 1.0f - 1.0f / (2.0f * t);
     return t;
 }
 __device__ __forceinline__ float stot_inv_map(int type, float s) {
     // torch evaluates `200 / (2 - 2*x)` (nerfacc_prop_net.py:308) as (2 - 2*x).reciprocal() * 200
     if (type == EMER_STOT_UNIFORM_LINDISP) return s < 0.5f ? s * 400.0f : (1.0f / (2.0f - 2.0f * s)) * 200.0f;
     if (type == EMER_STOT_LINDISP) return 1.0f / s;
+    if (type == EMER_STOT_SQRT) return s * s;
+    if (type == EMER_STOT_LOG) return expf(s);  // (libm-dependent last bit: compared by tolerance, not bit-exact)
+    if (type == EMER_STOT_UNIFORM_LINDISP_0) return s < 0.5f ? 2.0f * s : 1.0f / (2.0f - 2.0f * s);
     return s;
 }
 __device__ __forceinline__ float stot_apply(int type, float s, float s_min, float s_max) {
@@ -98,7 +104,7 @@ extern "C" int emer_importance_sample(const float *vals, const float *cdfs, int6
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(vals && cdfs && s_out, "importance_sample: null pointer");
     EMER_REQUIRE(!t_ends || t_out, "importance_sample: t_ends needs t_out (the interval starts)");
-    EMER_REQUIRE(stot_type >= 0 && stot_type <= 2, "importance_sample: unknown stot_type %d", stot_type);
+    EMER_REQUIRE(stot_type >= 0 && stot_type <= 5, "importance_sample: unknown stot_type %d", stot_type);
     const float s_min = stot_fwd_map(stot_type, t_min), s_max = stot_fwd_map(stot_type, t_max);
     const size_t lds = (size_t)kRaysPerBlock * 2 * m * sizeof(float);
     hipLaunchKernelGGL(importance_sample_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlock)), dim3(256), lds, as_stream(stream),
@@ -110,7 +116,7 @@ extern "C" int emer_stot(const float *s, int64_t n, float t_min, float t_max, in
     EMER_REQUIRE(n >= 0, "stot: negative n");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(s && t, "stot: null pointer");
-    EMER_REQUIRE(stot_type >= 0 && stot_type <= 2, "stot: unknown stot_type %d", stot_type);
+    EMER_REQUIRE(stot_type >= 0 && stot_type <= 5, "stot: unknown stot_type %d", stot_type);
     const float s_min = stot_fwd_map(stot_type, t_min), s_max = stot_fwd_map(stot_type, t_max);
     const uint32_t blocks = (uint32_t)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
     hipLaunchKernelGGL(stot_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s, n, s_min, s_max, stot_type, t);

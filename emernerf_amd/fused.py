@@ -170,9 +170,12 @@ def join_side_stream() -> None:
 def _sink(p) -> Optional[Tensor]:
     """The tensor a parameter's gradient may be accumulated into directly: its existing fp32 ``.grad`` with unit
     column stride.  This is what autograd's AccumulateGrad would do after the backward (``grad += dW``), fused into
-    the weight-gradient reduction -- it saves a zero-fill and an add launch per parameter.  Opt-in (``USE_GRAD_SINKS``):
-    parameter hooks are bypassed, so only a trainer that owns its gradient buffers should enable it."""
-    if not USE_GRAD_SINKS:
+    the weight-gradient reduction -- it saves a zero-fill and an add launch per parameter.  Opt-in and SCOPED
+    (``with grad_sinks():`` around a forward+backward): parameter hooks are bypassed, so only a trainer that owns its
+    gradient buffers enables it, and only for its own step.  Parameters that do not require grad never get a sink."""
+    if not _USE_GRAD_SINKS:
+        return None
+    if not getattr(p, "requires_grad", False):
         return None
     g = getattr(p, "grad", None)
     if g is None or g.dtype != torch.float32 or not g.is_cuda or g.stride(-1) != 1:
@@ -180,7 +183,19 @@ def _sink(p) -> Optional[Tensor]:
     return g
 
 
-USE_GRAD_SINKS = False
+_USE_GRAD_SINKS = False
+
+
+@contextlib.contextmanager
+def grad_sinks(enabled: bool = True):
+    """Enable direct accumulation into ``.grad`` for the heads whose FORWARD runs inside this block (the decision is
+    recorded per autograd node at forward time, so the matching backward may run inside or outside the block)."""
+    global _USE_GRAD_SINKS
+    prev, _USE_GRAD_SINKS = _USE_GRAD_SINKS, bool(enabled)
+    try:
+        yield
+    finally:
+        _USE_GRAD_SINKS = prev
 
 
 def _target(sink: Optional[Tensor], shape, dev):

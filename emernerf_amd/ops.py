@@ -274,7 +274,7 @@ def stot(s: Tensor, t_min: float, t_max: float, transform_type: str) -> Tensor:
 
 # ------------------------------------------------------------------------------- compositing
 class _RenderWeightsFn(torch.autograd.Function):
-    """(weights, trans, alphas, cdfs, ray_stats) from density; grads flow to sigma only."""
+    """(weights, trans, alphas, cdfs, ray_stats) from density; grads flow to sigma only (from every output)."""
 
     @staticmethod
     def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigma: Tensor):
@@ -288,7 +288,6 @@ class _RenderWeightsFn(torch.autograd.Function):
             _lib.call("emer_render_weights_fwd", _ptr(ts), _ptr(te), _ptr(sg), R, S, _ptr(w), _ptr(T), _ptr(a), _ptr(cdfs),
                       _ptr(stats), _stream(sg))
         ctx.save_for_backward(ts, te, sg)
-        ctx.mark_non_differentiable(a)
         return w, T, a, cdfs, stats
 
     @staticmethod
@@ -302,12 +301,13 @@ class _RenderWeightsFn(torch.autograd.Function):
             g = -_f32c(dcdfs)[:, :S]
             gT = g.contiguous() if gT is None else gT + g
         gw = None if dw is None else _f32c(dw)
+        ga = None if da is None else _f32c(da)
         gs = None if dstats is None else _f32c(dstats)[:, :2].contiguous()
-        if gw is None and gT is None and gs is None:
+        if gw is None and gT is None and gs is None and ga is None:
             return None, None, None
         with torch.cuda.device(sg.device):
             dsig = torch.empty_like(sg)
-            _lib.call("emer_render_weights_bwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(gw), _ptr(gT), _ptr(gs), R, S, _ptr(dsig),
+            _lib.call("emer_render_weights_bwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(gw), _ptr(gT), _ptr(ga), _ptr(gs), R, S, _ptr(dsig),
                       _stream(sg))
         return None, None, dsig
 

@@ -159,10 +159,13 @@ class Trainer:
         for p in self.props:
             p.to(self.device)
         self.estimator = PropNetEstimator(None, None).to(self.device)
-        self.flat = FlatParams({"main": [self.model], "prop": self.props}, self.device)
+        # The reference's late-binding closures make every proposal level query the LAST proposal network
+        # (render_utils.py:356-358); the earlier ones never receive a gradient, their .grad stays None and torch's Adam
+        # skips them (no weight decay, no moment update).  They live in their own range so the fused Adam skips them too.
+        self.flat = FlatParams({"main": [self.model], "prop": self.props[-1:], "prop_idle": self.props[:-1]}, self.device)
         # this trainer owns every gradient buffer (views of flat.grads, zeroed each step, no parameter hooks), so the
-        # fused heads may accumulate weight gradients straight into .grad (fused._sink)
-        fused.USE_GRAD_SINKS = True
+        # fused heads may accumulate weight gradients straight into .grad: enabled around ITS forward+backward only
+        # (fused.grad_sinks), never process-wide
         # (fused.SIDE_STREAM -- weight gradients on a second stream, overlapping the grid backward -- is implemented and
         # tested but OFF: measured 3 % slower on MI355X; the grid backward's workgroups fill the LDS of every CU, so
         # the weight-gradient workgroups only delay them)
@@ -201,13 +204,14 @@ class Trainer:
     def _forward_backward(self, data: Dict[str, Tensor], prop_grad: bool) -> Tensor:
         """zero grads -> render -> losses -> backward (everything of a step that is the same from step to step)."""
         self.flat.zero_grad()
-        results = render_rays(radiance_field=self.model, proposal_estimator=self.estimator, proposal_networks=self.props,
-                              data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad)
-        if prop_grad:
-            prop_loss = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
-            prop_loss.backward()
-        loss = self.losses(results, data)
-        (loss * self.loss_scale).backward()
+        with fused.grad_sinks(True):
+            results = render_rays(radiance_field=self.model, proposal_estimator=self.estimator, proposal_networks=self.props,
+                                  data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad)
+            if prop_grad:
+                prop_loss = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
+                prop_loss.backward()
+            loss = self.losses(results, data)
+            (loss * self.loss_scale).backward()
         fused.join_side_stream()  # weight gradients written on the side stream are complete from here on
         return loss.detach()
 
@@ -256,7 +260,9 @@ class Trainer:
             # the steps that train them (same schedule on every rank), so the other steps exchange the main range only
             # (50 MB instead of 90 MB at the metric configuration)
             a, b = self.flat.ranges["main"]
-            dist.all_reduce(self.flat.grads if prop_grad else self.flat.grads[a:b])
+            if prop_grad:
+                b = self.flat.ranges["prop"][1]  # main and the trained proposal net are adjacent in the flat buffer
+            dist.all_reduce(self.flat.grads[a:b])
         lr = self.lr * lr_factor(step, self.num_iters)
         if prop_grad:
             self._adam("prop", lr)

@@ -41,6 +41,9 @@ extern "C" {
 #define EMER_STOT_UNIFORM 0
 #define EMER_STOT_UNIFORM_LINDISP 1
 #define EMER_STOT_LINDISP 2
+#define EMER_STOT_SQRT 3
+#define EMER_STOT_LOG 4
+#define EMER_STOT_UNIFORM_LINDISP_0 5
 
 const char *emer_last_error(void);
 int emer_version(void);
@@ -163,11 +166,13 @@ int emer_stot(const float *s, int64_t n, float t_min, float t_max, int stot_type
 int emer_render_weights_fwd(const float *t_starts, const float *t_ends, const float *sigma,
                             int64_t n_rays, int32_t n_samples, float *weights, float *trans,
                             float *alphas, float *cdfs, float *ray_stats, void *stream);
-/* Given dL/dweights, dL/dtrans (either may be NULL) and dL/d(sum w), dL/d(sum w*mid) per ray
- * (d_ray_stats [R,2], may be NULL) produce dL/dsigma. */
+/* Given dL/dweights, dL/dtrans, dL/dalphas (any may be NULL) and dL/d(sum w), dL/d(sum w*mid) per ray
+ * (d_ray_stats [R,2], may be NULL) produce dL/dsigma.  alphas is a differentiable output because the
+ * reference forms weights = trans * alphas itself (render_utils.py:73-77). */
 int emer_render_weights_bwd(const float *t_starts, const float *t_ends, const float *sigma,
-                            const float *d_weights, const float *d_trans, const float *d_ray_stats,
-                            int64_t n_rays, int32_t n_samples, float *d_sigma, void *stream);
+                            const float *d_weights, const float *d_trans, const float *d_alphas,
+                            const float *d_ray_stats, int64_t n_rays, int32_t n_samples, float *d_sigma,
+                            void *stream);
 /* out[r,c] = sum_s w[r,s] * values[r,s,c]   (values == NULL: C = 1, out[r] = sum_s w). */
 int emer_accumulate_fwd(const float *weights, const float *values, int64_t n_rays,
                         int32_t n_samples, int32_t n_channels, float *out, void *stream);

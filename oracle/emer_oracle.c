@@ -263,15 +263,21 @@ void orc_importance_sample(const float *vals, const float *cdfs, int64_t R, int3
 /* ---- s -> t transform -------------------------------------------------------
  * third_party/nerfacc_prop_net.py:299-339 (_transform_stot / TRANSFROM_DICT).
  * type 0 = "uniform", 1 = "uniform_lindisp" (linear to 200 m, disparity beyond),
- * 2 = "lindisp".  Operation order follows the torch lambdas. */
+ * 2 = "lindisp", 3 = "sqrt", 4 = "log", 5 = "uniform_lindisp_0".  Operation order follows the torch lambdas. */
 static inline float orc_fwd_map(int type, float t) {
     if (type == 1) return t < 200.0f ? t / 400.0f : 1.0f - 1.0f / (2.0f * t / 200.0f);
     if (type == 2) return 1.0f / t;
+    if (type == 3) return sqrtf(t);
+    if (type == 4) return logf(t);
+    if (type == 5) return t < 1.0f ? t / 2.0f : 1.0f - 1.0f / (2.0f * t);
     return t;
 }
 static inline float orc_inv_map(int type, float s) {
     if (type == 1) return s < 0.5f ? s * 400.0f : (1.0f / (2.0f - 2.0f * s)) * 200.0f; /* torch: scalar / tensor == tensor.reciprocal() * scalar */
     if (type == 2) return 1.0f / s;
+    if (type == 3) return s * s;
+    if (type == 4) return expf(s);
+    if (type == 5) return s < 0.5f ? 2.0f * s : 1.0f / (2.0f - 2.0f * s);
     return s;
 }
 void orc_stot(const float *s, int64_t n, float t_min, float t_max, int type, float *t) {

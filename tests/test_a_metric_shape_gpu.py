@@ -1,0 +1,353 @@
+"""Parity at the BENCHMARKED shape (collected first on purpose: the file name sorts before the other GPU tests).
+
+The kernel tests in test_kernels_gpu.py run a few thousand samples, which never reaches the code the benchmark
+exercises: at N = 8192 x 128 = 1 048 576 samples the owner-computes grid backward makes 16 trips over its bitmap per
+work item (prefetched words), dense levels use 128-word ranges merged with atomics, tables larger than 64 LDS slices
+share bitmaps (``gsub > 0``), the fused heads run 4096-row weight-gradient blocks.  Here every hot kernel is compared
+with the CPU oracle (oracle/emer_oracle.c, OpenMP) at that size on the BASELINE.json grids, on uniform AND on
+proposal-resampled ("training") sample positions, and one full optimizer step's gradients are compared with
+oracle/ref_path.py parameter by parameter.
+
+Tolerances (same as the small tests): grid forward 2e-6 abs; grid gradients 2e-5 x max; step gradients 2e-3 x max.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_METRIC = 8192 * 128
+
+GRIDS = {
+    # name: (D, L, base, max, log2T, F)            reference
+    "cfg2_static": (3, 16, 16, 2048, 19, 2),       # HashEncoder defaults, encodings.py:110-118 (BASELINE configs[1])
+    "default_static": (3, 10, 16, 8192, 20, 4),    # default_config.yaml:62-69  (256 LDS slices -> shared bitmaps)
+    "dynamic_xyzt": (4, 10, 32, 8192, 18, 4),      # default_config.yaml:70-77
+    "prop1": (3, 8, 16, 2048, 20, 1),              # default_config.yaml:51-58 (second proposal net)
+}
+
+_CACHE = {}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _training_positions():
+    """Contracted sample positions of a REAL proposal-resampled training batch (8192 rays x 128 samples): what
+    PropNetEstimator.sampling + emer_ray_points hand to the main grid inside a step (clustered along each ray)."""
+    if "x" not in _CACHE:
+        from emernerf_amd.trainer import Trainer, synthetic_rays
+        dev = _dev()
+        tr = Trainer(kind="static", device=dev, table_init=0.5, seed=11)
+        data = synthetic_rays(8192, dev, seed=1000)
+        cap = {}
+        orig = tr.model.contract_points
+
+        def hook(p):
+            out = orig(p)
+            cap["x"] = out.detach().reshape(-1, 3).contiguous()
+            return out
+        tr.model.contract_points = hook
+        tr.train_step(data)
+        torch.cuda.synchronize()
+        _CACHE["x"] = cap["x"].cpu()
+        _CACHE["t"] = data["normed_timestamps"].cpu()
+        del tr
+        torch.cuda.empty_cache()
+    return _CACHE["x"], _CACHE["t"]
+
+
+def _positions(dist: str, D: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    if dist == "uniform":
+        x = torch.rand(N_METRIC, D, generator=g)
+        # edge cases of the small tests, plus coordinates OUTSIDE [0, 1] (tcnn wraps them through the index
+        # arithmetic; ADVICE r1: the paired-corner fast path must not assume in-range cells)
+        x[0] = 0.0
+        x[1] = 1.0 - 2 ** -24
+        x[2] = 2 ** -20
+        x[3, 0] = 0.9671
+        x[4] = 1.0
+        x[5, 0] = -0.37
+        x[6, 0] = 1.61
+        x[7] = torch.tensor([2.5, -1.25, 0.5, 0.3][:D])
+        x[70000:70064, 0] = -0.013  # a whole wave of out-of-range hits somewhere in the middle of the stream
+        return x
+    x3, t = _training_positions()
+    assert x3.shape[0] == N_METRIC
+    if D == 3:
+        return x3.clone()
+    tt = t[:, None].expand(-1, 128).reshape(-1, 1)
+    return torch.cat([x3, tt], -1).contiguous()
+
+
+def _mk(oracle, name):
+    from emernerf_amd import _lib
+    D, L, base, mx, T, F = GRIDS[name]
+    meta = oracle.grid_meta_from_encoder_args(D, L, base, mx, T, F)
+    desc = _lib.make_grid_desc(D, L, F, T, base, meta.per_level_scale)
+    return meta, desc
+
+
+@pytest.mark.parametrize("dist", ["uniform", "training"])
+@pytest.mark.parametrize("name", list(GRIDS))
+def test_hashgrid_metric_shape(hip_lib, oracle, name, dist):
+    """fwd, owner-computes bwd_params (through the bitmaps the forward emitted) and bwd_input at N = 1 048 576."""
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    D, L, F = meta.n_dims, meta.n_levels, meta.n_features
+    assert ops.sliced_supported(desc), "every shipped grid must take the owner-computes backward"
+    x = _positions(dist, D, seed=21)
+    g = torch.Generator().manual_seed(22)
+    p = torch.rand(meta.n_params, generator=g) - 0.5
+    dout = torch.randn(N_METRIC, L * F, generator=g)
+    dout[9] = 0.0
+    dev = _dev()
+    xd = x.to(dev).requires_grad_(D == 4)   # the xyzt grids are the ones that need input gradients (flow configs)
+    pd = p.to(dev).requires_grad_(True)
+    # level-major tensors, exactly what the fused heads exchange with the grid kernels inside a step
+    lm = ops.hashgrid_encode_lm(xd, pd, desc)
+    dlm = dout.view(N_METRIC, L, F).permute(1, 0, 2).contiguous().to(dev)
+    lm.backward(dlm)
+    torch.cuda.synchronize()
+    got_fwd = lm.detach().permute(1, 0, 2).reshape(N_METRIC, L * F).cpu().numpy()
+    ref_fwd = oracle.hashgrid_fwd(meta, x, p)
+    np.testing.assert_allclose(got_fwd, ref_fwd, rtol=0, atol=2e-6)
+    del got_fwd, ref_fwd
+    ref_dp = oracle.hashgrid_bwd_params(meta, x, dout)
+    got_dp = pd.grad.cpu().numpy()
+    scale = np.abs(ref_dp).max()
+    err = np.abs(got_dp - ref_dp)
+    assert err.max() <= 2e-5 * scale, f"{name}/{dist}: grid gradient max err {err.max():.3e} vs scale {scale:.3e} at {err.argmax()}"
+    # per level too: a coarse level's large sums must not hide a broken fine level
+    for l in range(L):
+        a, b = int(meta.offset[l]) * F, (int(meta.offset[l]) + int(meta.size[l])) * F
+        sl = np.abs(ref_dp[a:b]).max()
+        assert np.abs(got_dp[a:b] - ref_dp[a:b]).max() <= 2e-5 * max(sl, 1e-30), f"{name}/{dist}: level {l}"
+    if D == 4:
+        ref_dx = oracle.hashgrid_bwd_input(meta, x, p, dout)
+        sx = np.abs(ref_dx).max()
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), ref_dx, rtol=0, atol=2e-5 * sx)
+
+
+def test_hashgrid_sliced_is_run_to_run_stable(hip_lib, oracle):
+    """Two launches of the owner-computes backward on the same inputs agree to the last few ulp (accumulation is in
+    double inside the LDS; only the fp32 rounding of differently ordered double sums can differ)."""
+    from emernerf_amd import _lib, ops
+    meta, desc = _mk(oracle, "cfg2_static")
+    L, F = meta.n_levels, meta.n_features
+    dev = _dev()
+    x = _positions("training", 3, 0).to(dev)
+    g = torch.Generator().manual_seed(5)
+    p = (torch.rand(meta.n_params, generator=g) - 0.5).to(dev)
+    dlm = torch.randn(L, N_METRIC, F, generator=g).to(dev)
+    _, mk = ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=True)
+    outs = []
+    for _ in range(2):
+        grad = torch.empty(meta.n_params, device=dev)
+        _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N_METRIC * F, ops._ptr(mk),
+                  ops._ptr(grad), N_METRIC, ops._stream(x))
+        outs.append(grad)
+    torch.cuda.synchronize()
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert d <= 1e-6 * outs[0].abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------ fused heads
+def test_heads_metric_rows(hip_lib):
+    """neck / rgb head forward, data gradients and weight gradients at 1 048 576 rows (8192 rays x 128 samples)
+    against fp64 torch on a strided subset of rows (outputs, data gradients) and on ALL rows (weight gradients,
+    computed in fp64 on the GPU)."""
+    from emernerf_amd import fused
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    R, S, Kh, L, Fe = 8192, 128, 49, 16, 2
+    N = R * S
+    rnd = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(dev)  # noqa: E731
+    enc = rnd(L, N, Fe)
+    wn = [rnd(64, L * Fe, s=0.2), rnd(64, s=0.1), rnd(128, 64, s=0.1), rnd(128, s=0.1)]
+    hray = rnd(R, Kh)
+    wc = [rnd(64, Kh + 64, s=0.1), rnd(64, s=0.1), rnd(64, 64 + Kh + 64, s=0.1), rnd(64, s=0.1), rnd(3, 64, s=0.1), rnd(3, s=0.1)]
+    gw = rnd(N, 3)
+    gd = rnd(N, s=0.1)
+    for t in wn + wc + [enc, hray]:
+        t.requires_grad_(True)
+    geo, sem, dens = fused.neck(enc, *wn)
+    rgb = fused.rgb_head(hray, geo, S, *wc)
+    ((rgb * gw).sum() + (dens * gd).sum()).backward()
+    torch.cuda.synchronize()
+
+    # fp64 reference on the GPU through plain torch ops (checker only; the product never calls these)
+    e64 = enc.detach().double().permute(1, 0, 2).reshape(N, L * Fe).requires_grad_(True)
+    wn64 = [t.detach().double().requires_grad_(True) for t in wn]
+    wc64 = [t.detach().double().requires_grad_(True) for t in wc]
+    h64 = hray.detach().double().requires_grad_(True)
+    h1 = torch.relu(e64 @ wn64[0].T + wn64[1])
+    feats = h1 @ wn64[2].T + wn64[3]
+    geo64 = feats[:, :64]
+    dens64 = torch.exp(geo64[:, 0] - 1)
+    hs = h64[:, None, :].expand(R, S, Kh).reshape(N, Kh)
+    inp = torch.cat([hs, geo64], -1)
+    a1 = torch.relu(inp @ wc64[0].T + wc64[1])
+    a2 = torch.relu(torch.cat([a1, inp], -1) @ wc64[2].T + wc64[3])
+    rgb64 = torch.sigmoid(a2 @ wc64[4].T + wc64[5])
+    ((rgb64 * gw.double()).sum() + (dens64 * gd.double()).sum()).backward()
+
+    def close(name, a, b, rtol=2e-4, sa=5e-5):
+        a, b = a.detach().double(), b.detach().double()
+        scale = b.abs().max().item()
+        err = (a - b).abs()
+        bad = err > (sa * scale + rtol * b.abs())
+        assert not bad.any().item(), f"{name}: max err {err.max().item():.3e} (scale {scale:.3e}), {int(bad.sum())} outside"
+
+    close("rgb", rgb, rgb64, rtol=1e-4, sa=2e-5)
+    close("density", dens, dens64, rtol=1e-4, sa=2e-5)
+    close("geo", geo, geo64, rtol=1e-4, sa=2e-5)
+    close("denc", enc.grad.permute(1, 0, 2).reshape(N, L * Fe), e64.grad)
+    close("dhray", hray.grad, h64.grad)
+    for i, (a, b) in enumerate(zip(wn, wn64)):  # (the semantic half has no consumer here: exact zeros on both sides)
+        close(f"neck dW{i}", a.grad, b.grad)
+    for i, (a, b) in enumerate(zip(wc, wc64)):
+        close(f"rgb dW{i}", a.grad, b.grad)
+
+
+# ------------------------------------------------------------------------------------------ whole step
+def _ref_from_trainer(oracle, tr):
+    from oracle.ref_path import RefPath
+    from emernerf_amd.trainer import AABB, PROP_KW
+    c = tr.cfg
+    x = c.xyz_encoder
+    grids = {"model/xyz_encoder": oracle.grid_meta_from_encoder_args(3, x.n_levels, x.base_resolution, x.max_resolution,
+                                                                       x.log2_hashmap_size, x.n_features_per_level)}
+    if tr.model.dynamic_xyz_encoder is not None:
+        d = c.dynamic_xyz_encoder
+        grids["model/dynamic_xyz_encoder"] = oracle.grid_meta_from_encoder_args(4, d.n_levels, d.base_resolution, d.max_resolution,
+                                                                                d.log2_hashmap_size, d.n_features_per_level)
+    for i, kw in enumerate(PROP_KW):
+        grids[f"prop{i}/xyz_encoder"] = oracle.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
+                                                                           kw["log2_hashmap_size"], kw["n_features_per_level"])
+    ms = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    ps = [{k: v.detach().cpu() for k, v in p.state_dict().items()} for p in tr.props]
+    return RefPath(ms, ps, grids, AABB, time_diff=1 / c.num_train_timesteps)
+
+
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
+    """One optimizer step's gradients at 2048 rays x 128 samples (proposal rounds 128 + 64, proposal nets training):
+    every parameter's gradient in Trainer.flat.grads vs oracle/ref_path.py (torch-CPU autograd on the C oracle) with
+    the stratified jitter replayed on both sides.  Same losses as Trainer.losses."""
+    import torch.nn.functional as Fn
+    from oracle.ref_path import prop_loss
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = _dev()
+    R, S = 2048, 128
+    tr = Trainer(kind=kind, device=dev, num_samples=S, prop_samples=(128, 64), table_init=0.3, seed=7)
+    ref = _ref_from_trainer(oracle, tr)
+    data = synthetic_rays(R, dev, seed=77)
+    cpu = {k: v.cpu() for k, v in data.items()}
+    g = torch.Generator().manual_seed(9)
+    jit = [torch.rand(R, generator=g) for _ in range(3)]
+    it = iter([j.to(dev) for j in jit])
+    tr.estimator.jitter_fn = lambda n, d: next(it)
+    loss_hip = tr._forward_backward(data, prop_grad=True)
+    torch.cuda.synchronize()
+
+    res = ref.render_rays(cpu, S, [128, 64], jitters=jit, requires_grad=True)
+    pl = prop_loss(ref.cache, res["extras"]["trans"], 1024.0)
+    pl.backward()
+    loss = Fn.mse_loss(res["rgb"], cpu["pixels"]) + 0.001 * Fn.binary_cross_entropy(res["opacity"].squeeze(-1), 1 - cpu["sky_masks"].float())
+    if "dynamic_density" in res["extras"]:
+        loss = loss + 0.01 * res["extras"]["dynamic_density"].mean()
+    if "shadow_ratio" in res:
+        loss = loss + 0.01 * res["shadow_ratio"].mean()
+    (loss * 1024.0).backward()
+    np.testing.assert_allclose(float(loss_hip), float(loss), rtol=1e-4)
+
+    checked = 0
+    for prefix, mod in [("model/", tr.model)] + [(f"prop{i}/", p) for i, p in enumerate(tr.props)]:
+        for k, q in mod.named_parameters():
+            want = ref.t[prefix + k].grad
+            got = q.grad.detach().cpu()
+            if want is None:  # never reached by the graph (e.g. proposal net 0: the reference's late-binding lambda)
+                assert float(got.abs().max()) == 0.0, f"{prefix + k}: gradient where the reference has none"
+                continue
+            scale = float(want.abs().max())
+            err = float((got - want).abs().max())
+            assert err <= 2e-3 * max(scale, 1e-20), f"{prefix + k}: max err {err:.3e} vs scale {scale:.3e}"
+            checked += 1
+    assert checked >= 15
+
+
+# ------------------------------------------------------------------------------- INTEGRATION.md section 2 shims
+def test_nerfacc_compat_against_oracle(hip_lib, oracle):
+    """The reference-side binding points (emernerf_amd.nerfacc_compat: what INTEGRATION.md section 2 swaps in for
+    `import nerfacc`) called directly, the way the reference calls them (render_utils.py:35-43,73-77,103-105;
+    nerfacc_prop_net.py:153,165-172): values vs the C oracle, and the gradient of the reference's own
+    ``weights = trans * alphas`` formulation vs fp64 autograd."""
+    from emernerf_amd import nerfacc_compat as NC
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    R, S = 513, 128
+    e = torch.sort(torch.rand(R, S + 1, generator=g) * 40, -1).values
+    ts, te = e[:, :-1].contiguous(), e[:, 1:].contiguous()
+    sg = torch.rand(R, S, generator=g) * 0.5
+    rw, rT, ra = oracle.render_weights(ts, te, sg)
+    sgd = sg.to(dev).requires_grad_(True)
+    trans, alphas = NC.render_transmittance_from_density(ts.to(dev), te.to(dev), sgd)
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), rT, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(alphas.detach().cpu().numpy(), ra, rtol=2e-5, atol=1e-7)
+    weights = trans * alphas  # render_utils.py:73-77
+    vals = torch.rand(R, S, 3, generator=g)
+    rgb = NC.accumulate_along_rays(weights, values=vals.to(dev))
+    opa = NC.accumulate_along_rays(weights, values=None)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), oracle.accumulate(rw, vals), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(opa.detach().cpu().numpy(), oracle.accumulate(rw), rtol=1e-4, atol=1e-6)
+    gr, go = torch.randn(R, 3, generator=g), torch.randn(R, 1, generator=g)
+    ((rgb * gr.to(dev)).sum() + (opa * go.to(dev)).sum()).backward()
+    s64 = sg.double().requires_grad_(True)
+    sdt = s64 * (te - ts).double()
+    cum = torch.cumsum(sdt, -1)
+    T64 = torch.exp(-torch.cat([torch.zeros_like(cum[:, :1]), cum[:, :-1]], -1))
+    w64 = T64 * (1 - torch.exp(-sdt))
+    (((w64[..., None] * vals.double()).sum(1) * gr.double()).sum() + (w64.sum(1, keepdim=True) * go.double()).sum()).backward()
+    got, want = sgd.grad.cpu().double(), s64.grad
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max()), "d(trans*alphas)/dsigma through the shim"
+    w2, T2, a2 = NC.render_weight_from_density(ts.to(dev), te.to(dev), sg.to(dev))
+    np.testing.assert_allclose(w2.cpu().numpy(), rw, rtol=2e-5, atol=1e-7)
+
+    # importance_sampling / searchsorted (nerfacc_prop_net.py:148-175,349-359)
+    m, n = 129, 64
+    w = torch.rand(R, m - 1, generator=g) ** 4 + 1e-3
+    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(w, -1)], -1)
+    cdf = cdf / cdf[:, -1:]
+    vals_s = torch.sort(torch.rand(R, m, generator=g), -1).values
+    jit = torch.rand(R, generator=g)
+    iv, smp = NC.importance_sampling(NC.RayIntervals(vals=vals_s.to(dev)), cdf.to(dev), n, stratified=True, jitter=jit.to(dev))
+    ref_s = oracle.importance_sample(vals_s, cdf, n, jit)
+    assert np.array_equal(iv.vals.cpu().numpy().view(np.uint32), ref_s.view(np.uint32)), "sample offsets must be bit-exact"
+    np.testing.assert_allclose(smp.vals.cpu().numpy(), (ref_s[:, :-1] + ref_s[:, 1:]) * 0.5, rtol=1e-6)
+    iv0, _ = NC.importance_sampling(NC.RayIntervals(vals=vals_s.to(dev)), cdf.to(dev), n, stratified=False)
+    assert np.array_equal(iv0.vals.cpu().numpy().view(np.uint32), oracle.importance_sample(vals_s, cdf, n, None).view(np.uint32))
+    il, ir = NC.searchsorted(NC.RayIntervals(vals=vals_s.to(dev)), iv)
+    q, key = iv.vals.cpu().numpy(), vals_s.numpy()
+    want_r = np.stack([np.searchsorted(key[r], q[r], side="right") for r in range(R)])
+    assert np.array_equal(ir.cpu().numpy(), np.clip(want_r, 0, m - 1))
+    assert np.array_equal(il.cpu().numpy(), np.clip(want_r - 1, 0, m - 1))
+
+
+@pytest.mark.parametrize("typ", ["uniform", "lindisp", "uniform_lindisp", "sqrt", "log", "uniform_lindisp_0"])
+def test_stot_all_transforms(hip_lib, oracle, typ):
+    """Every entry of the reference's TRANSFROM_DICT (nerfacc_prop_net.py:298-314): bit-exact vs the oracle except
+    "log" (libm exp/log: 4 ulp)."""
+    from emernerf_amd import ops
+    s = torch.rand(4096, generator=torch.Generator().manual_seed(8))
+    got = ops.stot(s.to(_dev()), 0.5, 300.0, typ).cpu().numpy()
+    want = oracle.stot(s, 0.5, 300.0, typ)
+    if typ == "log":
+        np.testing.assert_allclose(got, want, rtol=5e-7)
+    else:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

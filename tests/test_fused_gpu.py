@@ -132,7 +132,7 @@ def test_rgb_head(hip_lib, R, S, Kh, NG, ld):
 
 
 def test_grad_sinks_equal_autograd_accumulation(hip_lib):
-    """fused.USE_GRAD_SINKS: weight gradients accumulated straight into an existing .grad == what autograd's
+    """fused.grad_sinks(): weight gradients accumulated straight into an existing .grad == what autograd's
     AccumulateGrad produces (old .grad + dW), for the neck, the proposal density MLP and the rgb head."""
     from emernerf_amd import fused
     dev = torch.device("cuda:0")
@@ -165,12 +165,10 @@ def test_grad_sinks_equal_autograd_accumulation(hip_lib):
         for i, p in enumerate(ps):
             p.grad = torch.full_like(p, 0.25)  # a pre-existing gradient the sinks must ADD to
             pre[(k, i)] = p.grad.data_ptr()
-    fused.USE_GRAD_SINKS = True
-    try:
+    with fused.grad_sinks(True):
         run(got)
         fused.join_side_stream()  # a Trainer created earlier in this process may have enabled the wgrad side stream
-    finally:
-        fused.USE_GRAD_SINKS = False
+    assert not fused._USE_GRAD_SINKS, "the sink opt-in must not leak out of its scope"
     for k in ref:
         for i, (a, b) in enumerate(zip(got[k], ref[k])):
             assert a.grad.data_ptr() == pre[(k, i)], "gradient was not accumulated in place"
@@ -180,12 +178,13 @@ def test_grad_sinks_equal_autograd_accumulation(hip_lib):
     for ps in got2.values():
         for p in ps:
             p.grad = torch.full_like(p, 0.25)
-    old_side, fused.SIDE_STREAM, fused.USE_GRAD_SINKS = fused.SIDE_STREAM, torch.cuda.Stream(), True
+    old_side, fused.SIDE_STREAM = fused.SIDE_STREAM, torch.cuda.Stream()
     try:
-        run(got2)
-        fused.join_side_stream()
+        with fused.grad_sinks(True):
+            run(got2)
+            fused.join_side_stream()
     finally:
-        fused.SIDE_STREAM, fused.USE_GRAD_SINKS = old_side, False
+        fused.SIDE_STREAM = old_side
     for k in ref:
         for i, (a, b) in enumerate(zip(got2[k], ref[k])):
             _close(f"side {k}{i}", a.grad - 0.25, b.grad, rtol=2e-4, scale_atol=5e-5)
