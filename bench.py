@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+N_BATCHES = 8  # seeded ray batches rotated through the steps (a new batch every step)
 
 
 def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
@@ -95,18 +96,23 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
 
 
 def pmc_traffic(dominant: str, D: int, F: int, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE and WRITE_SIZE
-    need separate profiler passes, tools/profile_round.sh, so they cannot be collected inside this process).  Only
-    valid for the default workload the summary was recorded on; null otherwise."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
-    if not os.path.exists(path) or (args.rays, args.samples, args.kind) != (8192, 128, "static"):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/r*_hbm_traffic.json).  FETCH_SIZE and WRITE_SIZE need separate profiler passes of this command
+    (tools/profile_round.sh), so they cannot be collected inside this process; the file name is reported next to the
+    number.  Only valid for the default workload the summary was recorded on; null otherwise."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    files = sorted(glob.glob(os.path.join(root, "r*_hbm_traffic.json")))
+    if not files or (args.rays, args.samples, args.kind) != (8192, 128, "static"):
         return None, None
+    path = files[-1]
     try:
         j = json.load(open(path))
         kern = {"emer_hashgrid_bwd_params_sliced": f"hashgrid_bwd_params_sliced_kernel<{D}, {F}>",
                 "emer_hashgrid_fwd": f"hashgrid_fwd_kernel<{D}, {F}, float>"}[dominant]
-        return j["kernels"][kern]["hbm_bytes"], ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
-                                                 f"of this command, reads x{j['read_correction']:.2f} (gfx950 correction, calibrated)")
+        return j["kernels"][kern]["hbm_bytes"], (f"profiles/{os.path.basename(path)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                                                 f"passes) of this command, reads x{j['read_correction']:.2f} (gfx950 correction, calibrated); "
+                                                 "recorded by tools/profile_round.sh, not in this run")
     except Exception:
         return None, None
 
@@ -125,6 +131,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--init-steps", type=int, default=48, help="untimed set-up steps before the warm-up (allocator, clocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-state", action="store_true", help="skip the trained-like (table_init 0.3) roofline pass")
     ap.add_argument("--graph", action="store_true", help="replay the forward+backward of a step as a captured hipGraph")
     args = ap.parse_args()
 
@@ -156,15 +163,23 @@ def main():
     fn = trainer.requires_grad_fn
     for s in range(args.start_step):
         fn(s)
-    data = synthetic_rays(args.rays, dev, seed=1000 + rank)  # each rank its own rays (weak scaling)
+    # each rank its own rays (weak scaling), and a NEW batch every step: N_BATCHES seeded batches resident in HBM, rotated
+    batches = [synthetic_rays(args.rays, dev, seed=1000 + 64 * rank + i) for i in range(N_BATCHES)]
+    it = {"i": 0}
 
-    # Setup, before the W warm-up steps the contract asks for: a fixed number of extra untimed steps so that the caching
-    # allocator has seen both step types (with / without proposal-net training) and the GPU clocks have ramped --
-    # otherwise a short --warmup measures start-up effects (first ~50 steps run ~15 % slower), not the step.
+    def next_batch():
+        b = batches[it["i"] % N_BATCHES]
+        it["i"] += 1
+        return b
+
+    # Setup, before the W warm-up steps the contract asks for: a fixed number of extra untimed steps (reported as
+    # config.init_steps) so that the caching allocator has seen both step types (with / without proposal-net training)
+    # and the GPU clocks have ramped -- otherwise a short --warmup measures start-up effects (the first ~50 steps run
+    # ~15 % slower), not the step.
     for _ in range(args.init_steps):
-        trainer.train_step(data)
+        trainer.train_step(next_batch())
     for _ in range(args.warmup):
-        trainer.train_step(data)
+        trainer.train_step(next_batch())
 
     # HIP events inside the timed region only around the roofline kernels (the grid encode + its backward: five
     # launches per step).  Timing every entry point costs ~1.4 ms/step in event records, so the full per-kernel
@@ -184,7 +199,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step(data)
+        trainer.train_step(next_batch())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -201,12 +216,30 @@ def main():
         _lib.TIMER = breakdown
         graphed, trainer.use_graph = trainer.use_graph, False  # the instrumented pass launches eagerly
         for _ in range(breakdown_steps):
-            trainer.train_step(data)
+            trainer.train_step(next_batch())
         torch.cuda.synchronize()
         trainer.use_graph = graphed
         _lib.TIMER = None
         if timer is None:
             timer = breakdown
+    # Second parameter state ("trained-like"): tables ~U(-0.3, 0.3) make the density vary by orders of
+    # magnitude along a ray, so the proposal sampler clusters the 128 samples -- the distribution the owner-computes
+    # backward is sensitive to.  Same model, same rays, grid kernels timed with HIP events over 12 steps.
+    clustered = None
+    if rank == 0 and args.table_init is None and not args.no_second_state:
+        t2 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_init=0.3)
+        t2.step_count = args.start_step
+        for s_ in range(args.start_step):
+            t2.requires_grad_fn(s_)
+        for _ in range(18):
+            t2.train_step(next_batch())
+        clustered = _lib.KernelTimer(grid_names)
+        _lib.TIMER = clustered
+        for _ in range(12):
+            t2.train_step(next_batch())
+        torch.cuda.synchronize()
+        _lib.TIMER = None
+        del t2
     if world > 1:
         dist.barrier()
 
@@ -232,6 +265,18 @@ def main():
         ach = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         both = (fwd_b + bwd_b) * N / ((f_avg + b_avg) * 1e-6) / 1e9 if (f_avg + b_avg) > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dominant, D, F, args)
+        roof2 = None
+        if clustered is not None:
+            us2, tg2 = clustered.elapsed_us(), clustered.tags
+            f2 = [u for u, tg in zip(us2["emer_hashgrid_fwd"], tg2["emer_hashgrid_fwd"]) if tg == (L, F)]
+            b2 = [u for u, tg in zip(us2["emer_hashgrid_bwd_params_sliced"], tg2["emer_hashgrid_bwd_params_sliced"]) if tg == (L, F)]
+            if f2 and b2:
+                fa, ba = sum(f2) / len(f2), sum(b2) / len(b2)
+                roof2 = {"table_init": 0.3, "bound": "hbm", "kernel": "emer_hashgrid_bwd_params_sliced", "avg_us": ba,
+                         "achieved": bwd_b * N / (ba * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bwd_b * N / (ba * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                         "grid_encode_plus_bwd": {"fwd_avg_us": fa, "bwd_avg_us": ba,
+                                                  "frac": (fwd_b + bwd_b) * N / ((fa + ba) * 1e-6) / 1e9 / HBM_PEAK_GBPS}}
         # fp32-MFMA rooflines of the head kernels (static configuration only: hidden 64, geo 64): algorithmic flops of
         # one launch / its average duration in the instrumented pass, vs the dense fp32 matrix peak
         mfma = {}
@@ -267,12 +312,14 @@ def main():
                                    "proposal rounds 128+64, full optimizer step (Adam)",
                        "kind": args.kind, "rays_per_gpu": args.rays, "samples": args.samples,
                        "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
+                       "init_steps": args.init_steps, "ray_batches_rotated": N_BATCHES,
                        "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4",
                        "launch_mode": "hipGraph replay of forward+backward" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
+            "roofline_trained_like": roof2,
             "roofline_mfma": mfma,
             "kernels": per_kernel,
             "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "

@@ -469,6 +469,11 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // Work items are dealt XCD-aware (block b -> XCD b % 8): an XCD finishes all slices of one level
 // before starting its next level, so the streamed inputs of that level stay L2-resident.
 // Placement only affects speed, never results.
+#ifdef EMER_SLICED_TRACE
+// Debug build only (tools/trace_sliced.py): per-work-item timeline of the owner-computes backward.
+// trace[0] = item counter; record i at trace[8 + 4 i] = {level | slice << 8 | range << 24 | block << 40, start, end, hits}
+__device__ unsigned long long *g_sliced_trace = nullptr;
+#endif
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
 constexpr uint32_t kStridedHitsMaxRes = 420;          // hashed levels up to this resolution spread a wave's hits over distant samples
@@ -554,6 +559,10 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         j -= nb;
     }
     const LevelInfo li = level_info(g, level);
+#ifdef EMER_SLICED_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    unsigned long long trace_hits = 0;
+#endif
     const bool dense = !li.hashed;
     const bool consecutive = dense || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const bool pairable = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
@@ -603,6 +612,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         const uint32_t incl = wave_inclusive_sum_u32(p, lane);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, kWave);
         if (total == 0u) continue;
+#ifdef EMER_SLICED_TRACE
+        if (lane == 0) trace_hits += total;
+#endif
         const uint32_t excl = incl - p;
         const unsigned long long nzm = __ballot(p != 0u);
         Hv[lane] = 0ull;
@@ -788,6 +800,14 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         }
     }
     __syncthreads();  // the accumulators are re-zeroed by the next item
+#ifdef EMER_SLICED_TRACE
+    if (g_sliced_trace && threadIdx.x == 0) {
+        const unsigned long long slot = atomicAdd(g_sliced_trace, 1ull);
+        unsigned long long *rec = g_sliced_trace + 8 + 4 * slot;
+        rec[0] = (unsigned long long)level | ((unsigned long long)slice << 8) | ((unsigned long long)range << 24) | ((unsigned long long)blockIdx.x << 40);
+        rec[1] = trace_t0; rec[2] = wall_clock64(); rec[3] = trace_hits;  // (hits of wave 0 only: 1/16 of the item's)
+    }
+#endif
   }
 }
 
@@ -1024,6 +1044,12 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }
+
+#ifdef EMER_SLICED_TRACE
+extern "C" int emer_debug_sliced_trace(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sliced_trace), &buf, sizeof(buf)) == hipSuccess ? EMER_OK : EMER_E_LAUNCH;
+}
+#endif
 
 extern "C" int emer_hashgrid_bwd_input(const emer_grid_desc *g, const float *x, const void *params, int param_dtype,
                                        const float *dout, int64_t sn, int64_t sl, float *dx, int64_t n, void *stream) {

@@ -272,6 +272,47 @@ def stot(s: Tensor, t_min: float, t_max: float, transform_type: str) -> Tensor:
     return t
 
 
+# ------------------------------------------------------------------------- proposal supervision
+class _PropLevelLossFn(torch.autograd.Function):
+    """One proposal level of PropNetEstimator.compute_loss (nerfacc_prop_net.py:181-238): scalar loss (already
+    multiplied by ``scale``) with its gradient w.r.t. the level's cdf computed in the same launch."""
+
+    @staticmethod
+    def forward(ctx, s_final: Tensor, trans: Tensor, s_prop: Tensor, cdf_prop: Tensor, pulse: float, anti_aliased: bool,
+                scale: float):
+        sf, tr, sp, cp = _f32c(s_final), _f32c(trans), _f32c(s_prop), _f32c(cdf_prop)
+        R, n = tr.shape
+        m = cp.shape[1] - 1
+        assert sf.shape == (R, n + 1) and sp.shape == (R, m + 1)
+        want_grad = ctx.needs_input_grad[3]
+        with torch.cuda.device(tr.device):
+            rays = torch.empty((R,), device=tr.device, dtype=torch.float32)
+            loss = torch.empty((), device=tr.device, dtype=torch.float32)
+            dcp = torch.empty_like(cp) if want_grad else None
+            _lib.call("emer_prop_loss", _ptr(sf), _ptr(tr), n, _ptr(sp), _ptr(cp), m, float(pulse), int(anti_aliased), R, float(scale),
+                      _ptr(rays), _ptr(loss), 0, _ptr(dcp), _stream(tr))
+        ctx.save_for_backward(dcp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (dcp,) = ctx.saved_tensors
+        if dcp is None:
+            return (None,) * 7
+        gc = _f32c(g).reshape(1)
+        with torch.cuda.device(dcp.device):
+            out = torch.empty_like(dcp)
+            _lib.call("emer_scale", _ptr(dcp), _ptr(gc), 1.0, _ptr(out), dcp.numel(), _stream(dcp))
+        return None, None, None, out, None, None, None
+
+
+def prop_level_loss(s_final: Tensor, trans: Tensor, s_prop: Tensor, cdf_prop: Tensor, pulse: float, anti_aliased: bool,
+                    scale: float) -> Tensor:
+    """scale * sum over rays and intervals of the interlevel loss of one proposal level (0-dim tensor)."""
+    _check_cuda(s_final, trans, s_prop, cdf_prop)
+    return _PropLevelLossFn.apply(s_final, trans, s_prop, cdf_prop, pulse, anti_aliased, scale)
+
+
 # ------------------------------------------------------------------------------- compositing
 class _RenderWeightsFn(torch.autograd.Function):
     """(weights, trans, alphas, cdfs, ray_stats) from density; grads flow to sigma only (from every output)."""

@@ -154,6 +154,30 @@ int emer_stot(const float *s, int64_t n, float t_min, float t_max, int stot_type
               void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Proposal-network supervision (replaces PropNetEstimator.compute_loss and its helpers:
+ *   third_party/nerfacc_prop_net.py:22-34 blur_stepfun, :37-60 sorted_interp_quad, :181-238 compute_loss,
+ *   :342-362 _pdf_loss).  One launch per proposal level computes the loss AND its gradient.
+ * ---------------------------------------------------------------------------------------------- */
+/* s_final [R,n+1] sample edges of the final level (s space), trans [R,n] its transmittance (cdf = 1 - [trans, 0],
+ * no gradient); s_prop / cdf_prop [R,m+1] edges and cdf of one proposal level.
+ *   anti_aliased != 0: zip-NeRF loss with blur half-width pulse_width:
+ *       sum_rays sum_j max(w_s - w_p, 0)^2 / (w_p + 1e-5),  w_p = diff(cdf_prop),
+ *       w_s = diff(quadratic interpolation of the blurred final histogram at s_prop);
+ *   anti_aliased == 0: _pdf_loss, sum over the n final intervals of max(w - w_outer, 0)^2 / (w + 1e-7).
+ * loss_rays [R] (may be NULL) = per-ray sums * scale; loss_out (may be NULL; needs loss_rays) = their sum in a fixed
+ * order (accumulate != 0: added to the value already there); d_cdf_prop [R,m+1] (may be NULL) = d(scale * sum)/d cdf_prop.
+ * The caller passes scale = loss_scaler / (R * m) (resp. R * n) for the reference's .mean() * loss_scaler. */
+int emer_prop_loss(const float *s_final, const float *trans, int32_t n_final, const float *s_prop,
+                   const float *cdf_prop, int32_t n_prop, float pulse_width, int anti_aliased, int64_t n_rays,
+                   float scale, float *loss_rays, float *loss_out, int accumulate, float *d_cdf_prop,
+                   void *stream);
+/* out[0] = (accumulate ? out[0] : 0) + sum(x[0..n)): one workgroup, fixed order, double accumulation. */
+int emer_reduce_sum(const float *x, int64_t n, int accumulate, float *out, void *stream);
+/* y = x * dev_scalar[0] * host_scale (dev_scalar may be NULL): gradients scaled by an upstream 0-dim gradient
+ * without a host round trip. */
+int emer_scale(const float *x, const float *dev_scalar, float host_scale, float *y, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Dense volume rendering (replaces nerfacc.render_transmittance_from_density /
  *   render_weight_from_density / accumulate_along_rays on (R,S) tensors:
  *   radiance_fields/render_utils.py:35-43,73-77,103-115,159-282; nerfacc_prop_net.py:165-168).

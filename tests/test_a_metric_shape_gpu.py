@@ -197,8 +197,22 @@ def test_heads_metric_rows(hip_lib):
     rgb64 = torch.sigmoid(a2 @ wc64[4].T + wc64[5])
     ((rgb64 * gw.double()).sum() + (dens64 * gd.double()).sum()).backward()
 
-    def close(name, a, b, rtol=2e-4, sa=5e-5):
+    # ReLU hinges: a hidden pre-activation within rounding distance of zero may take the other branch in fp32, which
+    # changes that row's data gradients by O(1) of their size (not a kernel error).  With 3 x 64M pre-activations a few
+    # dozen rows are affected: they are identified on the fp64 side and left out of the per-row comparisons; their
+    # contribution to the weight gradients (sums over 1M rows) is far below tolerance.
+    pre1 = e64.detach() @ wn64[0].detach().T + wn64[1].detach()
+    prea1 = inp.detach() @ wc64[0].detach().T + wc64[1].detach()
+    prea2 = torch.cat([a1.detach(), inp.detach()], -1) @ wc64[2].detach().T + wc64[3].detach()
+    risky = ((pre1.abs() < 5e-6).any(1) | (prea1.abs() < 5e-6).any(1) | (prea2.abs() < 5e-6).any(1))
+    assert int(risky.sum()) < 4000
+    keep = ~risky
+    keep_ray = keep.view(R, S).all(1)
+
+    def close(name, a, b, rtol=2e-4, sa=5e-5, rows=None):
         a, b = a.detach().double(), b.detach().double()
+        if rows is not None:
+            a, b = a[rows], b[rows]
         scale = b.abs().max().item()
         err = (a - b).abs()
         bad = err > (sa * scale + rtol * b.abs())
@@ -207,8 +221,8 @@ def test_heads_metric_rows(hip_lib):
     close("rgb", rgb, rgb64, rtol=1e-4, sa=2e-5)
     close("density", dens, dens64, rtol=1e-4, sa=2e-5)
     close("geo", geo, geo64, rtol=1e-4, sa=2e-5)
-    close("denc", enc.grad.permute(1, 0, 2).reshape(N, L * Fe), e64.grad)
-    close("dhray", hray.grad, h64.grad)
+    close("denc", enc.grad.permute(1, 0, 2).reshape(N, L * Fe), e64.grad, rows=keep)
+    close("dhray", hray.grad, h64.grad, rows=keep_ray)
     for i, (a, b) in enumerate(zip(wn, wn64)):  # (the semantic half has no consumer here: exact zeros on both sides)
         close(f"neck dW{i}", a.grad, b.grad)
     for i, (a, b) in enumerate(zip(wc, wc64)):

@@ -110,22 +110,18 @@ def test_lr_factor_matches_torch_schedulers():
             opt.step(); sched.step()
 
 
-def test_sorted_interp_quad_restatement_equals_reference_form():
-    """prop_net.sorted_interp_quad (searchsorted) == the reference's masked max/min form (oracle.ref_path)."""
-    from emernerf_amd.prop_net import blur_stepfun, sorted_interp_quad
-    from oracle.ref_path import blur_stepfun as ref_blur, sorted_interp_quad as ref_interp
-    g = torch.Generator().manual_seed(0)
-    R, S, m = 64, 24, 33
-    s = torch.sort(torch.rand(R, S + 1, generator=g), -1).values
-    w = torch.rand(R, S, generator=g)
-    c, wb = blur_stepfun(s, w, 0.03)
-    c2, wb2 = ref_blur(s, w, 0.03)
-    assert torch.equal(c, c2) and torch.equal(wb, wb2)
-    area = 0.5 * (wb[..., 1:] + wb[..., :-1]) * (c[..., 1:] - c[..., :-1])
-    cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(area, -1)], -1)
-    xq = torch.sort(torch.rand(R, m, generator=g) * 1.2 - 0.1, -1).values  # includes queries outside the knots
-    a, b = sorted_interp_quad(xq, c, wb, cdf), ref_interp(xq, c, wb, cdf)
-    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
+def test_proposal_grad_schedule_matches_reference_rule():
+    """get_proposal_requires_grad_fn (nerfacc_prop_net.py:280-296): the closure's rule, restated literally here."""
+    from emernerf_amd.prop_net import get_proposal_requires_grad_fn
+    for target, num_steps in ((5.0, 1000), (2.0, 10), (0.0, 5)):
+        fn = get_proposal_requires_grad_fn(target, num_steps)
+        since = 0
+        for step in range(3000):
+            want = since > min(step / num_steps, 1.0) * target
+            if want:
+                since = 0
+            since += 1
+            assert fn(step) == want, (target, num_steps, step)
 
 
 def test_flat_params_views_and_grad_accumulation():

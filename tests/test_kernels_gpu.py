@@ -373,3 +373,79 @@ def test_cpu_tensor_is_rejected(hip_lib):
     from emernerf_amd import _lib, ops
     with pytest.raises(_lib.EmerError):
         ops.linear(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+# ------------------------------------------------------------------------------------- proposal supervision
+def _prop_inputs(R, n, m, seed):
+    """Final-level edges / transmittance and one proposal level (edges, cdf) shaped like a training step's cache."""
+    g = torch.Generator().manual_seed(seed)
+    s_fin = torch.sort(torch.rand(R, n + 1, generator=g), -1).values
+    s_fin[:, 0], s_fin[:, -1] = 0.0, 1.0
+    dens = torch.rand(R, n, generator=g) ** 3 * 40
+    dt = s_fin[:, 1:] - s_fin[:, :-1]
+    cum = torch.cumsum(dens * dt, -1)
+    trans = torch.exp(-torch.cat([torch.zeros(R, 1), cum[:, :-1]], -1))
+    s_p = torch.sort(torch.rand(R, m + 1, generator=g), -1).values
+    s_p[:, 0], s_p[:, -1] = 0.0, 1.0
+    if R > 3:
+        s_p[3, 1] = s_p[3, 2]  # a zero-width proposal interval
+    w = torch.rand(R, m, generator=g) ** 2 + 1e-4
+    c_p = torch.cat([torch.zeros(R, 1), torch.cumsum(w, -1)], -1)
+    c_p = c_p / c_p[:, -1:] * (0.6 + 0.4 * torch.rand(R, 1, generator=g))
+    return s_fin, trans, s_p, c_p
+
+
+@pytest.mark.parametrize("R,n,m,level", [(8192, 128, 128, 0), (8192, 128, 64, 1), (37, 48, 64, 0), (5, 16, 16, 1), (3, 200, 300, 1)])
+def test_prop_loss_matches_oracle(hip_lib, oracle, R, n, m, level):
+    """emer_prop_loss (anti-aliased interlevel loss, value + gradient) vs oracle/ref_path.prop_loss -- the reference's
+    formulation with torch.sort and the [R, 2S+2, m] masks (third_party/nerfacc_prop_net.py:22-60,181-238) -- at the
+    metric shape R = 8192, S = 128 (oracle evaluated in 512-ray chunks: the loss is a mean over rays)."""
+    from emernerf_amd import ops
+    from oracle.ref_path import prop_loss
+    pulses = (0.03, 0.003)
+    s_fin, trans, s_p, c_p = _prop_inputs(R, n, m, seed=R + n + m)
+    dev = _dev()
+    cd = c_p.to(dev).requires_grad_(True)
+    scaler = 1024.0
+    loss = ops.prop_level_loss(s_fin.to(dev), trans.to(dev), s_p.to(dev), cd, pulses[level], True, scaler / (R * m))
+    (loss * 0.5).backward()  # a non-trivial upstream gradient
+    want_loss, want_grad = 0.0, torch.zeros_like(c_p)
+    for a in range(0, R, 512):
+        b = min(a + 512, R)
+        cp = c_p[a:b].clone().requires_grad_(True)
+        cache = [(s_p[a:b], cp, level), (s_fin[a:b], None, None)]
+        l = prop_loss(cache, trans[a:b], scaler, pulse=pulses) * ((b - a) / R)
+        (l * 0.5).backward()
+        want_loss += float(l)
+        want_grad[a:b] = cp.grad
+    assert abs(float(loss) - want_loss) <= 2e-4 * abs(want_loss) + 1e-12
+    got = cd.grad.cpu()
+    scale = float(want_grad.abs().max())
+    err = (got - want_grad).abs()
+    # individual entries sit on hinges (max(w_s - w_p, 0)): allow a handful of entries whose hinge flips on rounding
+    bad = err > 2e-4 * scale + 2e-3 * want_grad.abs()
+    assert int(bad.sum()) <= max(2, got.numel() // 20000), f"{int(bad.sum())} gradient entries off; max err {float(err.max()):.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("R,n,m", [(513, 128, 64), (7, 32, 48)])
+def test_pdf_loss_matches_torch_form(hip_lib, R, n, m):
+    """emer_prop_loss(anti_aliased=0) vs the reference's _pdf_loss (nerfacc_prop_net.py:342-362) restated in torch with
+    nerfacc.searchsorted's bracketing rule."""
+    from emernerf_amd import ops
+    s_fin, trans, s_p, c_p = _prop_inputs(R, n, m, seed=11 * R + n)
+    cdf_q = 1.0 - torch.cat([trans, torch.zeros(R, 1)], -1)
+    cp = c_p.clone().requires_grad_(True)
+    ir = torch.searchsorted(s_p.contiguous(), s_fin.contiguous(), right=True)
+    il = (ir - 1).clamp(0, m)
+    ir = ir.clamp(0, m)
+    w = cdf_q[:, 1:] - cdf_q[:, :-1]
+    w_outer = cp.gather(-1, ir[:, 1:]) - cp.gather(-1, il[:, :-1])
+    want = (torch.clip(w - w_outer, min=0) ** 2 / (w + 1e-7)).mean() * 7.0
+    want.backward()
+    dev = _dev()
+    cd = c_p.to(dev).requires_grad_(True)
+    got = ops.prop_level_loss(s_fin.to(dev), trans.to(dev), s_p.to(dev), cd, 0.0, False, 7.0 / (R * n))
+    got.backward()
+    assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want)) + 1e-12
+    sc = float(cp.grad.abs().max())
+    assert float((cd.grad.cpu() - cp.grad).abs().max()) <= 2e-4 * sc + 1e-12
