@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libemernerf_hip.so")
@@ -54,8 +54,12 @@ SIGNATURES = {
     "emer_prop_loss": [_P, _P, c_int32, _P, _P, c_int32, c_float, c_int, c_int64, c_float, _P, _P, c_int, _P, _P],
     "emer_reduce_sum": [_P, c_int64, c_int, _P, _P],
     "emer_scale": [_P, _P, c_float, _P, c_int64, _P],
-    "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P],
+    "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
+    "emer_ray_epilogue_fwd": [_P, _P, _P, c_int64, _P, _P, _P, _P, _P],
+    "emer_ray_epilogue_bwd": [_P, _P, _P, _P, _P, c_int64, _P, _P, _P],
+    "emer_pixel_loss_fwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],
+    "emer_pixel_loss_bwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
     "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P, _P],
@@ -71,6 +75,10 @@ SIGNATURES = {
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
+    "emer_sample_uniform": [_P, c_uint64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P],
+    "emer_sample_importance": [_P, c_int64, _P, c_uint64, c_int64, _P, _P, _P],
+    "emer_buffer_to_pixels": [_P, c_int64, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, c_uint64, _P, _P, _P, _P],
+    "emer_gen_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, _P],
 }
 

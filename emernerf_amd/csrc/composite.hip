@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void render_weights_fwd_kernel(const float *__
                                                                  const float *__restrict__ sigma, int64_t R, int32_t S,
                                                                  float *__restrict__ weights, float *__restrict__ trans,
                                                                  float *__restrict__ alphas, float *__restrict__ cdfs,
-                                                                 float *__restrict__ ray_stats) {
+                                                                 float *__restrict__ ray_stats, float *__restrict__ t_mid,
+                                                                 float *__restrict__ t_dist) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
     if (r >= R) return;
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(256) void render_weights_fwd_kernel(const float *__
             if (trans) trans[i] = T;
             if (alphas) alphas[i] = al;
             if (cdfs) cdfs[r * (int64_t)(S + 1) + s] = 1.0f - T;
+            if (t_mid) t_mid[i] = (a + b) / 2.0f;  // extras["t_vals"], extras["t_dist"] of rendering (render_utils.py:84-85)
+            if (t_dist) t_dist[i] = b - a;
         }
         carry += __shfl(incl, kWave - 1, kWave);
         if (ray_stats) {
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(256) void render_weights_bwd_kernel(const float *__
     }
     __syncthreads();
     if (!active) return;
-    const float g0 = d_ray_stats ? d_ray_stats[r * 2 + 0] : 0.0f;
-    const float g1 = d_ray_stats ? d_ray_stats[r * 2 + 1] : 0.0f;
+    const float g0 = d_ray_stats ? d_ray_stats[r * 4 + 0] : 0.0f;  // [R,4] like ray_stats (columns 2, 3 carry no gradient)
+    const float g1 = d_ray_stats ? d_ray_stats[r * 4 + 1] : 0.0f;
     float suffix = 0.0f;  // sum over later chunks of (gw w + gT T)
     for (int32_t c = n_chunks - 1; c >= 0; --c) {
         const int32_t s = c * kWave + lane;
@@ -227,12 +230,12 @@ using namespace emer;
 
 extern "C" int emer_render_weights_fwd(const float *ts, const float *te, const float *sigma, int64_t R, int32_t S,
                                        float *weights, float *trans, float *alphas, float *cdfs, float *ray_stats,
-                                       void *stream) {
+                                       float *t_mid, float *t_dist, void *stream) {
     EMER_REQUIRE(R >= 0 && S >= 1, "render_weights_fwd: bad sizes R=%lld S=%d", (long long)R, S);
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(ts && te && sigma, "render_weights_fwd: null input");
     hipLaunchKernelGGL(render_weights_fwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream),
-                       ts, te, sigma, R, S, weights, trans, alphas, cdfs, ray_stats);
+                       ts, te, sigma, R, S, weights, trans, alphas, cdfs, ray_stats, t_mid, t_dist);
     return check_launch("render_weights_fwd");
 }
 

@@ -186,8 +186,10 @@ struct SlicePlan {
     uint32_t xcd_of[EMER_MAX_LEVELS];    // backward: the XCD (0..7) that owns each level (cost-balanced)
     uint32_t order[EMER_MAX_LEVELS];     // backward: levels in the order an XCD's list walks them (heaviest items first)
     uint32_t items_per_xcd[8];           // backward work items ((level, slice, range) triples) on each XCD's list
+    uint32_t total_items;
 };
 
+constexpr uint32_t kSchedBlock = 32;  // consecutive work items dealt to one XCD (= its CU count: one round)
 static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
     // fitted to tools/kbench.py --per-level on MI355X (1M samples, ms on one XCD): coarse levels pay for
     // same-address LDS adds (many samples per cell), dense levels for the ordered scan + run reduction
@@ -204,6 +206,15 @@ static float item_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) 
     return 2.0f / (float)p.n_ranges[l];
 }
 
+#ifndef EMER_HASHED_SPLIT_RES
+#define EMER_HASHED_SPLIT_RES 0
+#endif
+#ifndef EMER_HASHED_SPLIT
+#define EMER_HASHED_SPLIT 2
+#endif
+#ifndef EMER_DENSE_ITEMS
+#define EMER_DENSE_ITEMS 512  // work items per dense level (slabs x sample ranges): 256 -> 512 -3 %, 1024 +8 % (merge atomics) on MI355X
+#endif
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     SlicePlan p;
     const uint32_t F = g->n_features;
@@ -218,7 +229,11 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             // over all samples each
             while ((1ull << k) * 64ull < size) ++k;
             while ((1u << k) > max_entries) --k;
-            p.n_ranges[l] = 1;  // (cutting the sample stream of coarse hashed levels as well was measured neutral)
+            // Coarse hashed levels: rays share cells, so some slices hold hot entries whose LDS adds serialise -- single
+            // items of level 5 (res 81) take 2.5x the level's mean (tools/trace_sliced.py) and, started in a second round,
+            // set the kernel's tail.  Cutting THEIR sample stream in ranges (merged with atomics, like the dense levels)
+            // bounds the longest item.
+            p.n_ranges[l] = (g->res[l] <= (uint32_t)EMER_HASHED_SPLIT_RES) ? (uint32_t)EMER_HASHED_SPLIT : 1u;
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
             // use as FEW slices as the LDS allows and cut the sample stream instead
@@ -227,7 +242,7 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             // ~256 work items per dense level (at most 128 ranges): a flat scene puts most samples into two or three
             // slabs, and ONE slab-range item must not become the critical path of the whole kernel (with 128 items the
             // heaviest item of level 4 alone took as long as the kernel: tools/probe_levels_train.py)
-            uint32_t nr = 256u / (ns ? ns : 1u);
+            uint32_t nr = (uint32_t)EMER_DENSE_ITEMS / (ns ? ns : 1u);
             if (nr > 128u) nr = 128u;
             p.n_ranges[l] = nr < 1u ? 1u : nr;
         }
@@ -240,27 +255,24 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         if (local > max_entries || p.gsub[l] > 6u) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
     }
-    // Levels -> XCDs, longest-processing-time first.  A level stays on ONE XCD so that its streamed inputs
-    // (x, dout, bitmaps) are fetched into a single L2.  Relative costs measured on MI355X at 1M samples
-    // (tools/probe_bwd.py): hashed level ~1, dense levels between 0.4 and 1.9 growing with the slab count; a level
-    // whose slices share bitmaps re-examines every candidate 2^gsub times.
-    float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t nblk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool placed[EMER_MAX_LEVELS] = {};
-    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.xcd_of[l] = 0xFF;
-    for (uint32_t it = 0; it < g->n_levels; ++it) {
-        int best = -1; float best_cost = -1.0f;
-        for (uint32_t l = 0; l < g->n_levels; ++l) {
-            if (placed[l]) continue;
-            const float c = level_cost(g, p, l);
-            if (c > best_cost) { best_cost = c; best = (int)l; }
-        }
-        int x = 0;
-        for (int i = 1; i < 8; ++i) if (load[i] < load[x]) x = i;
-        placed[best] = true; p.xcd_of[best] = (uint32_t)x; load[x] += best_cost; nblk[x] += p.n_slices[best] * p.n_ranges[best];
+    // Scheduling.  ONE global order of work items -- levels sorted by the cost of a single item, heaviest first (below) --
+    // dealt to the eight XCD lists in blocks of kSchedBlock consecutive items (block b -> XCD b % 8).  A block is one
+    // "round" of an XCD's 32 CUs working on the same level (shared x / dout lines in that L2), a level's 64 slices
+    // spread over two XCDs, and -- what matters most -- EVERY XCD starts with the long items (coarse hashed levels,
+    // ~200 us each) and ends with the short ones (dense slab-range items, ~20 us), so the tail of the kernel is filled
+    // with small work.  (Round 1 kept whole levels on one XCD: with 16 levels of unequal cost on 8 lists the heaviest
+    // list (levels 6 + 12) alone took the kernel's whole duration and long items were still being STARTED after 300 us,
+    // tools/trace_sliced.py.)
+    uint32_t total_items = 0;
+    for (uint32_t l = 0; l < g->n_levels; ++l) total_items += p.n_slices[l] * p.n_ranges[l];
+    p.total_items = total_items;
+    for (int i = 0; i < 8; ++i) p.items_per_xcd[i] = 0;
+    for (uint32_t blk = 0; blk * kSchedBlock < total_items; ++blk) {
+        const uint32_t left = total_items - blk * kSchedBlock;
+        p.items_per_xcd[blk & 7u] += left < kSchedBlock ? left : kSchedBlock;
     }
-    for (int i = 0; i < 8; ++i) p.items_per_xcd[i] = nblk[i];
-    // within a list: levels with the most expensive single items first, so the longest items start early
+    for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.xcd_of[l] = 0;  // (unused: kept for layout stability of the argument struct)
+    // the global order: levels with the most expensive single items first
     for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.order[l] = l;
     for (uint32_t a = 0; a + 1 < g->n_levels; ++a)
         for (uint32_t b = a + 1; b < g->n_levels; ++b) {
@@ -476,8 +488,60 @@ __device__ unsigned long long *g_sliced_trace = nullptr;
 #endif
 constexpr int kSliceThreads = 1024;
 constexpr int kSliceWaves = kSliceThreads / 64;
-constexpr uint32_t kStridedHitsMaxRes = 420;          // hashed levels up to this resolution spread a wave's hits over distant samples
+#ifndef EMER_STRIDED_MAX_RES
+#define EMER_STRIDED_MAX_RES 420
+#endif
+constexpr uint32_t kStridedHitsMaxRes = EMER_STRIDED_MAX_RES;          // hashed levels up to this resolution spread a wave's hits over distant samples
 constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
+
+
+// ---- DPP wave scans (gfx9 data-parallel primitives: a VALU operand modifier, no LDS round trip) -------------------
+// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source lane does not exist, or whose row is
+// masked off, keep `old`.  row_shr:n = 0x110 + n (inside a 16-lane row), row_bcast15 = 0x142 (lane 15 of each row to
+// the next row), row_bcast31 = 0x143 (lane 31 to rows 2 and 3), wave_shr:1 = 0x138, wave_shl:1 = 0x130.
+#ifndef EMER_DPP_SCANS
+#define EMER_DPP_SCANS 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t src, uint32_t old = 0u) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+// value of the previous / next lane of the wave (lane 0 / lane 63 get `edge`)
+__device__ __forceinline__ uint32_t wave_prev_u32(uint32_t v, uint32_t edge) { return dpp_u32<0x138, 0xF>(v, edge); }
+__device__ __forceinline__ uint32_t wave_next_u32(uint32_t v, uint32_t edge) { return dpp_u32<0x130, 0xF>(v, edge); }
+
+// Segmented inclusive wave scan with shared segment heads: step masks first (one set per 64 lanes), then one
+// multiply-add per value and step.  The scan operator on (head flag, value) pairs is
+// (f1, v1) (+) (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2); keep[s] = 1.0 where the lane still ACCEPTS the partner's value
+// at step s (no head seen so far between the partner and itself), else 0.0.
+struct RunMasks { float keep[6]; };
+__device__ __forceinline__ RunMasks run_masks(bool head) {
+    RunMasks m;
+    uint32_t f = head ? 1u : 0u;
+    m.keep[0] = f ? 0.0f : 1.0f; f |= dpp_u32<0x111, 0xF>(f);
+    m.keep[1] = f ? 0.0f : 1.0f; f |= dpp_u32<0x112, 0xF>(f);
+    m.keep[2] = f ? 0.0f : 1.0f; f |= dpp_u32<0x114, 0xF>(f);
+    m.keep[3] = f ? 0.0f : 1.0f; f |= dpp_u32<0x118, 0xF>(f);
+    m.keep[4] = f ? 0.0f : 1.0f; f |= dpp_u32<0x142, 0xA>(f);
+    m.keep[5] = f ? 0.0f : 1.0f;
+    return m;
+}
+template <int NV>
+__device__ __forceinline__ void run_reduce_dpp(float (&v)[NV], const RunMasks &m) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = fmaf(dpp_f32<0x111, 0xF>(v[i]), m.keep[0], v[i]);
+        v[i] = fmaf(dpp_f32<0x112, 0xF>(v[i]), m.keep[1], v[i]);
+        v[i] = fmaf(dpp_f32<0x114, 0xF>(v[i]), m.keep[2], v[i]);
+        v[i] = fmaf(dpp_f32<0x118, 0xF>(v[i]), m.keep[3], v[i]);
+        v[i] = fmaf(dpp_f32<0x142, 0xA>(v[i]), m.keep[4], v[i]);
+        v[i] = fmaf(dpp_f32<0x143, 0xC>(v[i]), m.keep[5], v[i]);
+    }
+}
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
 // they form RUNS that share one cell (and therefore all 2^D corner entries).  Values are reduced per run
@@ -499,12 +563,23 @@ __device__ __forceinline__ void run_reduce(float (&v)[NV], int run_start, int la
 
 // ---- analytic hit compaction (used by the owner-computes backward) ----------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v, int lane) {
+#if EMER_DPP_SCANS
+    (void)lane;
+    v += dpp_u32<0x111, 0xF>(v);
+    v += dpp_u32<0x112, 0xF>(v);
+    v += dpp_u32<0x114, 0xF>(v);
+    v += dpp_u32<0x118, 0xF>(v);
+    v += dpp_u32<0x142, 0xA>(v);
+    v += dpp_u32<0x143, 0xC>(v);
+    return v;
+#else
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)v, off, kWave);
         if (lane >= off) v += o;
     }
     return v;
+#endif
 }
 // position of the k-th (0-based) set bit of w; k < popcount(w)
 __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
@@ -517,6 +592,108 @@ __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
     if (k >= (x & 1u)) base += 1;
     return base;
 }
+// the same with the last three levels replaced by one LDS byte look-up: lut[byte * 8 + k] = position of the k-th set bit
+// of `byte` (2 KiB per workgroup, filled once): 21 VALU instead of 42 per 64 hits in the hottest loop of the backward
+#ifndef EMER_SELECT_LUT
+#define EMER_SELECT_LUT 1
+#endif
+constexpr uint32_t kSelectLutBytes = EMER_SELECT_LUT ? 2048u : 0u;
+__device__ __forceinline__ uint32_t select64_lut(uint64_t w, uint32_t k, const uint8_t *lut) {
+    uint32_t x = (uint32_t)w, base = 0, c = (uint32_t)__popc((uint32_t)w);
+    if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
+    c = (uint32_t)__popc(x & 0xFFFFu); if (k >= c) { k -= c; x >>= 16; base += 16; }
+    c = (uint32_t)__popc(x & 0xFFu);   if (k >= c) { k -= c; x >>= 8;  base += 8; }
+    return base + lut[((x & 0xFFu) << 3) | (k & 7u)];
+}
+
+// ---- pair helpers of the owner-computes backward (hashed power-of-two levels) -------------------------------------
+#ifndef EMER_PAIR_QUEUE
+#define EMER_PAIR_QUEUE 1
+#endif
+#ifdef EMER_QUEUE_DEBUG
+__device__ uint32_t g_queue_dbg[8];   // [0] bad ids read back, [1] appended, [2] drained, [4..6] last bad entry / head / count
+__device__ int64_t g_queue_dbg_n;
+#endif
+constexpr uint32_t kPairQueue = 72;        // ring capacity per wave (words): drain threshold - 1 + one chunk of 64
+constexpr uint32_t kPairQueueDrain = 8;    // drain once this many second pairs wait (they are rare: ~1 per 1000 hits)
+constexpr uint32_t kPairQueueShift = 24;   // entry = sample id << 8 | remaining pair mask: ids below 2^24, masks up to 8 bits (D <= 4)
+// hash contributions of the non-x dimensions for both corner values: hd[d][b] = (gi[d] + b) * prime_d
+template <int D>
+__device__ __forceinline__ void hash_terms(const uint32_t (&gi)[D], uint32_t (&hd)[D][2]) {
+    const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+    hd[0][0] = hd[0][1] = 0u;
+#pragma unroll
+    for (int d = 1; d < D; ++d) { hd[d][0] = gi[d] * primes[d]; hd[d][1] = hd[d][0] + primes[d]; }
+}
+// bit m set iff pair m (corner bits of dims 1..D-1) lives in the slice: the x index only touches bits below the slice
+// bits, so the test is on the hash alone: ((h ^ slice_first) & slice_bits) == 0
+template <int D>
+__device__ __forceinline__ uint32_t pair_matches(const uint32_t (&hd)[D][2], uint32_t slice_want, uint32_t slice_bits) {
+    uint32_t match = 0;
+    const uint32_t y0 = hd[1][0] ^ slice_want, y1 = hd[1][1] ^ slice_want;
+#pragma unroll
+    for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+        uint32_t h = (m & 1u) ? y1 : y0;
+#pragma unroll
+        for (int d = 2; d < D; ++d) h ^= hd[d][(m >> (d - 1)) & 1u];
+        if ((h & slice_bits) == 0u) match |= 1u << m;
+    }
+    return match;
+}
+// every lane adds its lowest matching pair (if any) and clears it from `match`
+template <int D, int F>
+__device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], const float (&w)[D], const uint32_t (&hd)[D][2],
+                                         const float (&go)[F], uint32_t &match, uint32_t local_mask) {
+    const bool has = match != 0u;
+    const uint32_t m = has ? (uint32_t)__ffs((int)match) - 1u : 0u;
+    match &= match - 1u;  // (0 stays 0)
+    uint32_t h = 0;
+    float wa = 1.0f - w[0], wb = w[0];  // same product order as the generic path: ((t0*t1)*t2)*t3
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+        const bool bit = (m >> (d - 1)) & 1u;
+        h ^= bit ? hd[d][1] : hd[d][0];
+        const float t = bit ? w[d] : 1.0f - w[d];
+        wa *= t; wb *= t;
+    }
+    const uint32_t l0 = (gi[0] ^ h) & local_mask, l1 = ((gi[0] + 1u) ^ h) & local_mask;  // offsets inside the slice
+    if (has) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            atomicAdd(acc + (size_t)l0 * F + f, (double)(wa * go[f]));  // ds_add_f64
+            atomicAdd(acc + (size_t)l1 * F + f, (double)(wb * go[f]));
+        }
+    }
+}
+// Queued second pairs: lane l takes entry l, reloads the sample (cache hits: it was loaded a moment ago), and adds the
+// queued pairs.
+template <int D, int F>
+__device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &li, const float *__restrict__ x, const float *__restrict__ dl,
+                                                 int64_t sn, const uint32_t *Qw, uint32_t q_head, uint32_t count, uint32_t slice_want,
+                                                 uint32_t slice_bits, uint32_t local_mask, int lane) {
+    (void)slice_want; (void)slice_bits;
+    const bool on = (uint32_t)lane < count;
+    const uint32_t e = on ? Qw[(q_head + (uint32_t)lane) % kPairQueue] : 0u;
+    uint32_t n = e >> 8;
+    uint32_t match = e & 0xFFu;
+    // hipcc 7.2 (gfx950) folded the former `id = e & 0xFFFFFF` INTO the x address as `e * 12` (mask dropped: memory
+    // fault); the id is made opaque here so the address arithmetic cannot be rewritten across the unpacking
+    asm volatile("" : "+v"(n));
+#ifdef EMER_QUEUE_DEBUG
+    if (on) atomicAdd(g_queue_dbg + 2, 1u);
+    if (n >= (uint32_t)g_queue_dbg_n) { atomicAdd(g_queue_dbg + 0, 1u); g_queue_dbg[4] = e; g_queue_dbg[5] = q_head; g_queue_dbg[6] = count; n = 0; match = 0; }
+#endif
+    float xv[D], go[F], w[D];
+    uint32_t gi[D], hd[D][2];
+    load_x<D>(x, (int64_t)n, xv);
+#pragma unroll
+    for (int f = 0; f < F; ++f) go[f] = dl[(int64_t)n * sn + f];
+    cell_of<D>(li, xv, gi, w);
+    hash_terms<D>(gi, hd);
+    add_pair<D, F>(acc, gi, w, hd, go, match, local_mask);
+    while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go, match, local_mask);
+}
+
 constexpr int kScanWords = 64 + 64 + 32 + 32;  // per-wave LDS scratch of the compaction, in u64: words, head bit-vector, offsets, head bases
 
 template <int D, int F>
@@ -533,6 +710,18 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // workgroup whose own list is exhausted steals from the other XCDs' lists, which absorbs whatever the static cost
     // model got wrong for the actual sample distribution.  Placement only affects speed, never results.
     const uint32_t my_xcd = blockIdx.x & 7u;
+#if EMER_SELECT_LUT
+    // byte-select table behind everything else in the LDS: lut[b * 8 + k] = index of the k-th set bit of b (0 if none)
+    uint8_t *sel_lut = reinterpret_cast<uint8_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
+                       + (size_t)kSliceWaves * kPairQueue * sizeof(uint32_t);
+    for (uint32_t e = threadIdx.x; e < 2048u; e += kSliceThreads) {
+        uint32_t b = e >> 3, k = e & 7u, pos = 0;
+        for (uint32_t i = 0; i < 8u; ++i)
+            if ((b >> i) & 1u) { if (k == 0u) { pos = i; break; } --k; }
+        sel_lut[e] = (uint8_t)pos;
+    }
+    __syncthreads();
+#endif
   for (;;) {
     if (threadIdx.x == 0) {
         uint32_t it = 0xFFFFFFFFu;
@@ -549,11 +738,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     __syncthreads();  // s_item may be rewritten by thread 0 right after the item is finished
     if (item == 0xFFFFFFFFu) return;
     const uint32_t xcd = item >> 24;
+    // local index on the XCD's list -> global item index (blocks of kSchedBlock dealt round-robin) -> (level, slice, range)
     uint32_t j = item & 0xFFFFFFu;
+    j = ((j / kSchedBlock) * 8u + xcd) * kSchedBlock + (j % kSchedBlock);
     uint32_t level = 0, slice = 0, range = 0;
     for (uint32_t oi = 0; oi < g.n_levels; ++oi) {
         level = plan.order[oi];
-        if (plan.xcd_of[level] != xcd) continue;
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
         if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; break; }
         j -= nb;
@@ -585,6 +775,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 
     for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
+    // second-pair queue (pairable levels): wave-private ring of kPairQueue words behind the compaction scratch
+    uint32_t *Qw = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
+                   + (size_t)wave * kPairQueue;
+    uint32_t q_head = 0, q_len = 0;
+    const bool use_queue = EMER_PAIR_QUEUE && pairable && N <= (1ll << kPairQueueShift) && (1u << (D - 1)) <= 8u;
+    const uint32_t slice_bits = (li.size - 1u) & ~((1u << shift) - 1u), slice_want = first, local_mask = (1u << shift) - 1u;
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
     const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + (slice >> plan.gsub[level])) * n_words;  // 1 bit per sample
@@ -603,7 +799,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // Word of a trip held by this lane: hashed = thread id; dense = interleaved over the waves so that short ranges
     // still occupy all 16 waves (lane t of wave w holds word t * 16 + w; words of a wave stay in increasing order).
     const int64_t my_word = dense ? (int64_t)lane * kSliceWaves + wave : (int64_t)threadIdx.x;
-    const int64_t lane_word_step = dense ? kSliceWaves : 1, wave_word0 = dense ? wave : wave * 64;
+    const int64_t wave_word0 = dense ? wave : wave * 64;
+    const uint32_t lane_word_shift = dense ? 4u : 0u;  // log2 of the word stride between neighbouring lanes (kSliceWaves = 16)
+    static_assert(kSliceWaves == 16, "lane_word_shift assumes 16 waves");
     uint64_t pre = (w_begin + my_word < w_end) ? bm[w_begin + my_word] : 0ull;
     for (int64_t wbase = w_begin; wbase < w_end; wbase += kSliceThreads) {
         const uint64_t wv = pre;
@@ -634,6 +832,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             const uint32_t take = (total - 64u * c0) < 64u * kDrainK ? (total - 64u * c0) : 64u * kDrainK;
             float xs[kDrainK][D], go[kDrainK][F];
             bool vld[kDrainK];
+            uint32_t ns[kDrainK];  // sample ids (the second-pair queue stores them)
 #pragma unroll
             for (int k = 0; k < kDrainK; ++k) {
                 uint32_t c = c0 + (uint32_t)k;
@@ -660,15 +859,24 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
                 const uint64_t wq = Wl[rank];
                 const uint32_t el = El[rank];
+#if EMER_SELECT_LUT
+                const uint32_t bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
+#else
                 const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
-                const uint32_t n = (uint32_t)(((wbase + wave_word0 + (int64_t)(el >> 16) * lane_word_step) << 6) + bit);
+#endif
+                const uint32_t n = (((uint32_t)wbase + (uint32_t)wave_word0 + ((el >> 16) << lane_word_shift)) << 6) + bit;  // (32-bit: n < 2^28)
                 vld[k] = in_range && (c0 + (uint32_t)k) < n_chunks;
-                load_x<D>(x, (int64_t)n, xs[k]);
-                if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
-                else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(dl + (int64_t)n * sn); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
+                ns[k] = n;
+                // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
+                // scalar-base + 32-bit-offset addressing mode instead of 64-bit multiply-adds per lane (sn == F)
+                const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (uint32_t)(n * (uint32_t)(D * 4)));
+                const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dl) + (uint32_t)(n * (uint32_t)(F * 4)));
+                load_x<D>(xp, 0, xs[k]);
+                if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(gp); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
+                else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(gp); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
                 else {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) go[k][f] = dl[(int64_t)n * sn + f];
+                    for (int f = 0; f < F; ++f) go[k][f] = gp[f];
                 }
             }
 #pragma unroll
@@ -688,6 +896,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #pragma unroll
                     for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
                     if (!valid) cell = 0xFFFFFFFFu;
+#if EMER_DPP_SCANS
+                    const uint32_t prev = wave_prev_u32(cell, ~cell);
+                    const bool head = cell != prev;  // (lane 0 compares with ~cell: always a head)
+                    const RunMasks rm = run_masks(head);
+                    const bool next_head = wave_next_u32(head ? 1u : 0u, 1u) != 0u;
+#else
                     const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
                     const bool head = lane == 0 || cell != prev;
                     int run_start = head ? lane : 0;
@@ -697,6 +911,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         if (lane >= off) run_start = run_start > t ? run_start : t;
                     }
                     const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
+#endif
                     const bool tail = valid && (lane == 63 || next_head);
 #pragma unroll
                     for (uint32_t m = 0; m < (1u << D); ++m) {
@@ -710,7 +925,11 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         float v[F];
 #pragma unroll
                         for (int f = 0; f < F; ++f) v[f] = wt * go[k][f];
+#if EMER_DPP_SCANS
+                        run_reduce_dpp<F>(v, rm);
+#else
                         run_reduce<F>(v, run_start, lane);
+#endif
                         const uint32_t idx = grid_index<D>(li, c);
                         if (tail && (idx >> shift) == slice) {
 #pragma unroll
@@ -723,50 +942,34 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                     // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
                     // (tcnn semantics) and may put the two x-corners in different slices: a wave holding such a hit
                     // takes the generic per-corner path below (wave-uniform test, never taken by EmerNeRF's own inputs).
-                    // Every lane first finds WHICH of its 2^(D-1) pairs live in this slice (usually one), then
-                    // the wave loops over "next matching pair of each lane": ~2 pair bodies per hit instead of 2^(D-1)
-                    // mostly-masked ones.
-                    const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+                    // A hit has ONE pair in this slice, now and then a second one (the 2^(D-1) pairs of a sample fall in
+                    // ~independent slices): every lane adds its first matching pair here on dense lanes; the rare further
+                    // pairs are queued (sample id + remaining pair mask) and drained a few at a time, again on dense
+                    // lanes, instead of running a second, 95 % masked, pair body after every chunk.
                     uint32_t hd[D][2];
-#pragma unroll
-                    for (int d = 1; d < D; ++d) { hd[d][0] = gi[d] * primes[d]; hd[d][1] = hd[d][0] + primes[d]; }
-                    uint32_t match = 0;
-#pragma unroll
-                    for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
-                        uint32_t h = 0;
-#pragma unroll
-                        for (int d = 1; d < D; ++d) h ^= hd[d][(m >> (d - 1)) & 1u];
-                        if ((((gi[0] ^ h) & (li.size - 1u)) >> shift) == slice) match |= 1u << m;
-                    }
-                    if (!valid) match = 0u;
-                    auto pair_body = [&]() {  // every lane: its next matching pair (if any)
-                        const bool has = match != 0u;
-                        const uint32_t m = has ? (uint32_t)__ffs((int)match) - 1u : 0u;
-                        match &= match - 1u;  // (0 stays 0)
-                        uint32_t h = 0;
-                        float wa = 1.0f - w[0], wb = w[0];  // same product order as the generic path: ((t0*t1)*t2)*t3
-#pragma unroll
-                        for (int d = 1; d < D; ++d) {
-                            const bool bit = (m >> (d - 1)) & 1u;
-                            h ^= bit ? hd[d][1] : hd[d][0];
-                            const float t = bit ? w[d] : 1.0f - w[d];
-                            wa *= t; wb *= t;
-                        }
-                        const uint32_t idx0 = (gi[0] ^ h) & (li.size - 1u);
-                        const uint32_t idx1 = ((gi[0] + 1u) ^ h) & (li.size - 1u);
-                        if (has) {
-#pragma unroll
-                            for (int f = 0; f < F; ++f) {
-                                atomicAdd(acc + (size_t)(idx0 - first) * F + f, (double)(wa * go[k][f]));  // ds_add_f64
-                                atomicAdd(acc + (size_t)(idx1 - first) * F + f, (double)(wb * go[k][f]));
+                    hash_terms<D>(gi, hd);
+                    uint32_t match = valid ? pair_matches<D>(hd, slice_want, slice_bits) : 0u;
+                    add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
+                    if (use_queue) {
+                        const bool more = match != 0u;
+                        const unsigned long long mb = __ballot(more);
+                        if (mb) {  // wave-uniform
+                            if (more) Qw[(q_head + q_len + (uint32_t)__popcll(mb & lt_mask)) % kPairQueue] = (ns[k] << 8) | match;
+                            q_len += (uint32_t)__popcll(mb);
+#ifdef EMER_QUEUE_DEBUG
+                            if (lane == 0) atomicAdd(g_queue_dbg + 1, (uint32_t)__popcll(mb));
+#endif
+                            if (q_len >= kPairQueueDrain) {  // (checked after every chunk: a chunk appends at most 64 entries)
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                const uint32_t done = q_len < 64u ? q_len : 64u;
+                                drain_pair_queue<D, F>(acc, li, x, dl, sn, Qw, q_head, done, slice_want, slice_bits, local_mask, lane);
+                                q_head = (q_head + done) % kPairQueue; q_len -= done;
                             }
                         }
-                    };
-                    // a hit has one matching pair, sometimes two: two straight-line rounds (no wave-level loop, so the
-                    // scheduler can overlap them and the neighbouring groups), then the rare rest
-                    pair_body();
-                    pair_body();
-                    while (__ballot(match != 0u)) pair_body();
+                    } else {
+                        add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
+                        while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
+                    }
                 } else {
 #pragma unroll
                     for (uint32_t m = 0; m < (1u << D); ++m) {
@@ -786,6 +989,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 }
             }
         }
+    }
+    while (q_len) {  // wave-uniform: second pairs still queued
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t done = q_len < 64u ? q_len : 64u;
+        drain_pair_queue<D, F>(acc, li, x, dl, sn, Qw, q_head, done, slice_want, slice_bits, local_mask, lane);
+        q_head = (q_head + done) % kPairQueue; q_len -= done;
     }
     __syncthreads();
     // write the slice.  One range: every entry is owned by exactly this workgroup -> plain coalesced stores.
@@ -1010,7 +1219,8 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
 extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
                                                int64_t sl, uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
-    EMER_REQUIRE(n >= 0 && n < (1ll << 31), "hashgrid_bwd_params_sliced: n out of range (sample ids are queued as 32-bit)");
+    EMER_REQUIRE(n >= 0 && n < (1ll << 28), "hashgrid_bwd_params_sliced: n out of range (byte offsets of the gathers are 32-bit: n < 2^28)");
+    EMER_REQUIRE(sn == (int64_t)g->n_features, "hashgrid_bwd_params_sliced: dout must be level-major with packed features (stride_n == n_features)");
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
     const SlicePlan plan = make_slice_plan(g);
@@ -1034,7 +1244,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
     uint32_t n_blocks = 256;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
-    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * kScanWords * sizeof(uint64_t);
+    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * (kScanWords * sizeof(uint64_t) + kPairQueue * sizeof(uint32_t)) + kSelectLutBytes;
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
@@ -1045,6 +1255,12 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     });
 }
 
+#ifdef EMER_QUEUE_DEBUG
+extern "C" int emer_debug_queue(int64_t n, uint32_t *out8, int reset) {
+    if (reset) { uint32_t z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_queue_dbg), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_queue_dbg_n), &n, sizeof(n)); return 0; }
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_queue_dbg), 8 * sizeof(uint32_t)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EMER_SLICED_TRACE
 extern "C" int emer_debug_sliced_trace(unsigned long long *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sliced_trace), &buf, sizeof(buf)) == hipSuccess ? EMER_OK : EMER_E_LAUNCH;

@@ -1,0 +1,144 @@
+// Per-ray epilogue of the volume renderer and the pixel losses for gfx950.
+//
+// Replaces the per-ray torch chains at the end of `rendering` (radiance_fields/render_utils.py:102-105: opacity clamp,
+// expected depth = sum(w t) / opacity; :217-226: rgb += rgb_sky * (1 - opacity)) and the two pixel losses every
+// EmerNeRF config trains with (loss/base.py:83-146 RealValueLoss "rgb" with L2, coefficient 1; :149-185 SkyLoss
+// "opacity_based" = binary cross entropy between opacity and 1 - sky_mask, coefficient 0.001 in
+// configs/default_config.yaml) together with their autograd graphs: about 25 elementwise launches per step on
+// [R, 1..3] tensors become two forward and two backward launches.  SURVEY.md section 8f row N4 (per-ray part).
+#include "common.h"
+
+namespace emer {
+
+// ---------------------------------------------------------------------------------------------- ray epilogue
+// stats [R,4] = (sum w, sum w*mid, median depth, -) from emer_render_weights_fwd.
+__global__ __launch_bounds__(256) void ray_epilogue_fwd_kernel(const float *__restrict__ stats, const float *__restrict__ acc_rgb,
+                                                               const float *__restrict__ rgb_sky, int64_t R,
+                                                               float *__restrict__ opacity, float *__restrict__ depth,
+                                                               float *__restrict__ median, float *__restrict__ rgb) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float4 st = *reinterpret_cast<const float4 *>(stats + r * 4);
+    const float o = fminf(fmaxf(st.x, 1e-6f), 1.0f);  // torch.clamp(1e-6, 1.0)
+    opacity[r] = o;
+    depth[r] = st.y / o;
+    if (median) median[r] = st.z;
+    if (rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc_rgb[r * 3 + c];
+            if (rgb_sky) v = v + rgb_sky[r * 3 + c] * (1.0f - o);
+            rgb[r * 3 + c] = v;
+        }
+    }
+}
+
+// d_stats [R,4] = gradient of ray_stats (columns 2, 3 zero); d_rgb_sky [R,3].  The gradient of acc_rgb is d_rgb itself.
+__global__ __launch_bounds__(256) void ray_epilogue_bwd_kernel(const float *__restrict__ stats, const float *__restrict__ rgb_sky,
+                                                               const float *__restrict__ d_opacity, const float *__restrict__ d_depth,
+                                                               const float *__restrict__ d_rgb, int64_t R, float *__restrict__ d_stats,
+                                                               float *__restrict__ d_rgb_sky) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float4 st = *reinterpret_cast<const float4 *>(stats + r * 4);
+    const float o = fminf(fmaxf(st.x, 1e-6f), 1.0f);
+    float go = d_opacity ? d_opacity[r] : 0.0f;
+    const float gd = d_depth ? d_depth[r] : 0.0f;
+    go -= gd * st.y / (o * o);
+    if (d_rgb && rgb_sky) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = d_rgb[r * 3 + c];
+            go -= g * rgb_sky[r * 3 + c];
+            if (d_rgb_sky) d_rgb_sky[r * 3 + c] = g * (1.0f - o);
+        }
+    }
+    // clamp passes the gradient where min <= x <= max (torch semantics, bounds included)
+    *reinterpret_cast<float4 *>(d_stats + r * 4) = make_float4((st.x >= 1e-6f && st.x <= 1.0f) ? go : 0.0f, gd / o, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ pixel losses
+// per-ray partial: w_rgb * sum_c (rgb - pix)^2 / (3 R) + w_sky * bce(opacity, 1 - sky) / R
+// bce(o, t) = -(t * max(log o, -100) + (1 - t) * max(log(1 - o), -100))   (torch.nn.functional.binary_cross_entropy)
+__global__ __launch_bounds__(256) void pixel_loss_fwd_kernel(const float *__restrict__ rgb, const float *__restrict__ pixels,
+                                                             const float *__restrict__ opacity, const float *__restrict__ sky_mask,
+                                                             int64_t R, float w_rgb, float w_sky, float *__restrict__ loss_rays) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float l = 0.0f;
+    if (rgb) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float d = rgb[r * 3 + c] - pixels[r * 3 + c]; s += d * d; }
+        l += w_rgb * s / (3.0f * (float)R);
+    }
+    if (opacity && sky_mask) {
+        const float o = opacity[r], t = 1.0f - sky_mask[r];
+        const float bce = -(t * fmaxf(logf(o), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - o), -100.0f));
+        l += w_sky * bce / (float)R;
+    }
+    loss_rays[r] = l;
+}
+
+// gradients times the upstream scalar g[0]: d_rgb = w_rgb * 2 (rgb - pix) / (3R), d_opacity = w_sky * (o - t) / max(o (1 - o), 1e-12) / R
+__global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float *__restrict__ rgb, const float *__restrict__ pixels,
+                                                             const float *__restrict__ opacity, const float *__restrict__ sky_mask,
+                                                             int64_t R, float w_rgb, float w_sky, const float *__restrict__ g,
+                                                             float *__restrict__ d_rgb, float *__restrict__ d_opacity) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float up = g ? g[0] : 1.0f;
+    if (d_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d_rgb[r * 3 + c] = up * w_rgb * 2.0f * (rgb[r * 3 + c] - pixels[r * 3 + c]) / (3.0f * (float)R);
+    }
+    if (d_opacity) {
+        const float o = opacity[r], t = 1.0f - sky_mask[r];
+        d_opacity[r] = up * w_sky * (o - t) / fmaxf(o * (1.0f - o), 1e-12f) / (float)R;
+    }
+}
+
+}  // namespace emer
+
+using namespace emer;
+
+extern "C" int emer_reduce_sum(const float *x, int64_t n, int accumulate, float *out, void *stream);
+
+extern "C" int emer_ray_epilogue_fwd(const float *ray_stats, const float *acc_rgb, const float *rgb_sky, int64_t n_rays, float *opacity,
+                                     float *depth, float *median_depth, float *rgb, void *stream) {
+    EMER_REQUIRE(n_rays >= 0, "ray_epilogue_fwd: negative n_rays");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(ray_stats && opacity && depth && (!rgb || acc_rgb), "ray_epilogue_fwd: null pointer");
+    hipLaunchKernelGGL(ray_epilogue_fwd_kernel, dim3((uint32_t)ceil_div(n_rays, 256)), dim3(256), 0, as_stream(stream), ray_stats, acc_rgb,
+                       rgb_sky, n_rays, opacity, depth, median_depth, rgb);
+    return check_launch("ray_epilogue_fwd");
+}
+
+extern "C" int emer_ray_epilogue_bwd(const float *ray_stats, const float *rgb_sky, const float *d_opacity, const float *d_depth,
+                                     const float *d_rgb, int64_t n_rays, float *d_ray_stats, float *d_rgb_sky, void *stream) {
+    EMER_REQUIRE(n_rays >= 0, "ray_epilogue_bwd: negative n_rays");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(ray_stats && d_ray_stats, "ray_epilogue_bwd: null pointer");
+    hipLaunchKernelGGL(ray_epilogue_bwd_kernel, dim3((uint32_t)ceil_div(n_rays, 256)), dim3(256), 0, as_stream(stream), ray_stats, rgb_sky,
+                       d_opacity, d_depth, d_rgb, n_rays, d_ray_stats, d_rgb_sky);
+    return check_launch("ray_epilogue_bwd");
+}
+
+extern "C" int emer_pixel_loss_fwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask, int64_t n_rays,
+                                   float w_rgb, float w_sky, float *loss_rays, float *loss_out, void *stream) {
+    EMER_REQUIRE(n_rays >= 1, "pixel_loss_fwd: needs at least one ray");
+    EMER_REQUIRE(loss_rays && loss_out && (!rgb || pixels) && (!opacity || sky_mask), "pixel_loss_fwd: null pointer");
+    hipLaunchKernelGGL(pixel_loss_fwd_kernel, dim3((uint32_t)ceil_div(n_rays, 256)), dim3(256), 0, as_stream(stream), rgb, pixels, opacity,
+                       sky_mask, n_rays, w_rgb, w_sky, loss_rays);
+    if (int rc = check_launch("pixel_loss_fwd")) return rc;
+    return emer_reduce_sum(loss_rays, n_rays, 0, loss_out, stream);
+}
+
+extern "C" int emer_pixel_loss_bwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask, int64_t n_rays,
+                                   float w_rgb, float w_sky, const float *upstream, float *d_rgb, float *d_opacity, void *stream) {
+    EMER_REQUIRE(n_rays >= 1, "pixel_loss_bwd: needs at least one ray");
+    EMER_REQUIRE((!d_rgb || (rgb && pixels)) && (!d_opacity || (opacity && sky_mask)), "pixel_loss_bwd: null pointer");
+    hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((uint32_t)ceil_div(n_rays, 256)), dim3(256), 0, as_stream(stream), rgb, pixels, opacity,
+                       sky_mask, n_rays, w_rgb, w_sky, upstream, d_rgb, d_opacity);
+    return check_launch("pixel_loss_bwd");
+}

@@ -138,7 +138,13 @@ class _HashGridFn(torch.autograd.Function):
 
 class _HashGridLMFn(torch.autograd.Function):
     """Same as _HashGridFn but exchanges the LEVEL-MAJOR [L, N, F] tensors the grid kernels use natively
-    (no transpose kernels): what the fused MLP chains read and write."""
+    (no transpose kernels): what the fused MLP chains read and write.
+
+    Gradient sink (``fused.grad_sinks()``, a trainer that owns its gradient buffers): the owner-computes backward writes
+    every table entry exactly once, so it can write STRAIGHT into the parameter's ``.grad`` -- no 49 MB temporary, no
+    AccumulateGrad add, and the trainer does not zero the table's gradient beforehand (``params._emer_grad_fresh`` is set
+    by the trainer's zero_grad: the first backward of a step overwrites, later ones of the same step -- the flow
+    configs evaluate an encoder three times -- add)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype):
@@ -150,6 +156,9 @@ class _HashGridLMFn(torch.autograd.Function):
         else:
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
         ctx.desc, ctx.grad_dtype = desc, grad_dtype
+        from . import fused
+        sink = fused._sink(params) if ctx.sliced else None
+        ctx.param = params if (sink is not None and sink.is_contiguous() and sink.numel() == pc.numel()) else None
         ctx.save_for_backward(xc, pc, masks)
         return lm
 
@@ -165,14 +174,22 @@ class _HashGridLMFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gdt = ctx.grad_dtype or torch.float32
                 if gdt == torch.float32 and masks is not None:
-                    grad = torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
+                    param = ctx.param
+                    direct = param is not None and getattr(param, "_emer_grad_fresh", False) and param.grad is not None
+                    grad = param.grad.view(-1) if direct else torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
                     _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
                               _ptr(grad), N, st)
+                    if direct:
+                        param._emer_grad_fresh = False
+                        grad = None
+                    elif param is not None and param.grad is not None:
+                        param.grad.view(-1).add_(grad)  # a further evaluation of the same encoder in this step
+                        grad = None
                 else:
                     grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)
-                dp = grad.to(pc.dtype) if grad.dtype != pc.dtype else grad
+                dp = None if grad is None else (grad.to(pc.dtype) if grad.dtype != pc.dtype else grad)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xc)
                 _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,
@@ -315,10 +332,11 @@ def prop_level_loss(s_final: Tensor, trans: Tensor, s_prop: Tensor, cdf_prop: Te
 
 # ------------------------------------------------------------------------------- compositing
 class _RenderWeightsFn(torch.autograd.Function):
-    """(weights, trans, alphas, cdfs, ray_stats) from density; grads flow to sigma only (from every output)."""
+    """(weights, trans, alphas, cdfs, ray_stats[, t_mid, t_dist]) from density; grads flow to sigma only (from every
+    differentiable output)."""
 
     @staticmethod
-    def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigma: Tensor):
+    def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigma: Tensor, want_t: bool):
         ctx.set_materialize_grads(False)
         ts, te, sg = _f32c(t_starts), _f32c(t_ends), _f32c(sigma)
         R, S = sg.shape
@@ -326,13 +344,17 @@ class _RenderWeightsFn(torch.autograd.Function):
             w, T, a = (torch.empty_like(sg) for _ in range(3))
             cdfs = torch.empty((R, S + 1), device=sg.device, dtype=torch.float32)
             stats = torch.empty((R, 4), device=sg.device, dtype=torch.float32)
+            tm, td = (torch.empty_like(sg), torch.empty_like(sg)) if want_t else (None, None)
             _lib.call("emer_render_weights_fwd", _ptr(ts), _ptr(te), _ptr(sg), R, S, _ptr(w), _ptr(T), _ptr(a), _ptr(cdfs),
-                      _ptr(stats), _stream(sg))
+                      _ptr(stats), _ptr(tm), _ptr(td), _stream(sg))
         ctx.save_for_backward(ts, te, sg)
+        if want_t:
+            ctx.mark_non_differentiable(tm, td)
+            return w, T, a, cdfs, stats, tm, td
         return w, T, a, cdfs, stats
 
     @staticmethod
-    def backward(ctx, dw, dT, da, dcdfs, dstats):
+    def backward(ctx, dw, dT, da, dcdfs, dstats, *_unused):
         ts, te, sg = ctx.saved_tensors
         R, S = sg.shape
         gT = None
@@ -343,20 +365,21 @@ class _RenderWeightsFn(torch.autograd.Function):
             gT = g.contiguous() if gT is None else gT + g
         gw = None if dw is None else _f32c(dw)
         ga = None if da is None else _f32c(da)
-        gs = None if dstats is None else _f32c(dstats)[:, :2].contiguous()
+        gs = None if dstats is None else _f32c(dstats)  # [R,4]; the kernel reads columns 0, 1
         if gw is None and gT is None and gs is None and ga is None:
-            return None, None, None
+            return None, None, None, None
         with torch.cuda.device(sg.device):
             dsig = torch.empty_like(sg)
             _lib.call("emer_render_weights_bwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(gw), _ptr(gT), _ptr(ga), _ptr(gs), R, S, _ptr(dsig),
                       _stream(sg))
-        return None, None, dsig
+        return None, None, dsig, None
 
 
-def render_weights(t_starts: Tensor, t_ends: Tensor, sigma: Tensor):
-    """Returns (weights, trans, alphas, cdfs [R,S+1], ray_stats [R,4] = (sum w, sum w*mid, median_depth, 0))."""
+def render_weights(t_starts: Tensor, t_ends: Tensor, sigma: Tensor, want_t: bool = False):
+    """Returns (weights, trans, alphas, cdfs [R,S+1], ray_stats [R,4] = (sum w, sum w*mid, median_depth, 0)) and, with
+    ``want_t``, also (t_mid, t_dist) = ((t_starts + t_ends) / 2, t_ends - t_starts) from the same launch."""
     _check_cuda(t_starts, t_ends, sigma)
-    return _RenderWeightsFn.apply(t_starts, t_ends, sigma)
+    return _RenderWeightsFn.apply(t_starts, t_ends, sigma, want_t)
 
 
 class _AccumulateFn(torch.autograd.Function):
@@ -391,6 +414,88 @@ def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None) -> T
     """nerfacc.accumulate_along_rays on dense (R,S)/(R,S,C) tensors -> (R,C)."""
     _check_cuda(weights, values)
     return _AccumulateFn.apply(weights, values)
+
+
+class _RayEpilogueFn(torch.autograd.Function):
+    """(opacity [R,1], depth [R,1], median_depth [R,1], rgb [R,3] | None) from the scan kernel's per-ray sums
+    (render_utils.py:102-122,217-226)."""
+
+    @staticmethod
+    def forward(ctx, stats: Tensor, acc_rgb: Optional[Tensor], rgb_sky: Optional[Tensor]):
+        ctx.set_materialize_grads(False)
+        st = _f32c(stats)
+        R = st.shape[0]
+        ar = None if acc_rgb is None else _f32c(acc_rgb)
+        sk = None if rgb_sky is None else _f32c(rgb_sky)
+        with torch.cuda.device(st.device):
+            opa, dep, med = (torch.empty((R, 1), device=st.device, dtype=torch.float32) for _ in range(3))
+            rgb = torch.empty((R, 3), device=st.device, dtype=torch.float32) if ar is not None else None
+            _lib.call("emer_ray_epilogue_fwd", _ptr(st), _ptr(ar), _ptr(sk), R, _ptr(opa), _ptr(dep), _ptr(med), _ptr(rgb), _stream(st))
+        ctx.save_for_backward(st, sk)
+        ctx.has_rgb = ar is not None
+        ctx.mark_non_differentiable(med)
+        return opa, dep, med, rgb
+
+    @staticmethod
+    def backward(ctx, do, dd, dm, drgb):
+        st, sk = ctx.saved_tensors
+        R = st.shape[0]
+        if do is None and dd is None and drgb is None:
+            return None, None, None
+        go = None if do is None else _f32c(do)
+        gd = None if dd is None else _f32c(dd)
+        gr = None if drgb is None else _f32c(drgb)
+        with torch.cuda.device(st.device):
+            dst = torch.empty((R, 4), device=st.device, dtype=torch.float32)
+            dsk = torch.empty((R, 3), device=st.device, dtype=torch.float32) if (sk is not None and gr is not None) else None
+            _lib.call("emer_ray_epilogue_bwd", _ptr(st), _ptr(sk), _ptr(go), _ptr(gd), _ptr(gr), R, _ptr(dst), _ptr(dsk), _stream(st))
+        return dst, (gr if ctx.has_rgb else None), dsk
+
+
+def ray_epilogue(stats: Tensor, acc_rgb: Optional[Tensor] = None, rgb_sky: Optional[Tensor] = None):
+    """Per-ray tail of `rendering`: opacity = clamp(sum w, 1e-6, 1), depth = sum(w t) / opacity, median depth, and
+    rgb = acc_rgb + rgb_sky * (1 - opacity).  Returns (opacity, depth, median_depth, rgb)."""
+    _check_cuda(stats, acc_rgb, rgb_sky)
+    return _RayEpilogueFn.apply(stats, acc_rgb, rgb_sky)
+
+
+class _PixelLossFn(torch.autograd.Function):
+    """w_rgb * mse(rgb, pixels) + w_sky * bce(opacity, 1 - sky_mask) (loss/base.py:83-185), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask: Optional[Tensor], w_rgb: float, w_sky: float):
+        r, px = _f32c(rgb).view(-1, 3), _f32c(pixels).view(-1, 3)
+        R = r.shape[0]
+        op = None if opacity is None else _f32c(opacity).view(-1)
+        sm = None if sky_mask is None else _f32c(sky_mask).view(-1)
+        with torch.cuda.device(r.device):
+            rays = torch.empty((R,), device=r.device, dtype=torch.float32)
+            loss = torch.empty((), device=r.device, dtype=torch.float32)
+            _lib.call("emer_pixel_loss_fwd", _ptr(r), _ptr(px), _ptr(op), _ptr(sm), R, float(w_rgb), float(w_sky), _ptr(rays), _ptr(loss),
+                      _stream(r))
+        ctx.save_for_backward(r, px, op, sm)
+        ctx.w, ctx.shapes = (float(w_rgb), float(w_sky)), (rgb.shape, None if opacity is None else opacity.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        r, px, op, sm = ctx.saved_tensors
+        R = r.shape[0]
+        need_o = op is not None and ctx.needs_input_grad[1]
+        gc = _f32c(g).reshape(1)
+        with torch.cuda.device(r.device):
+            dr = torch.empty_like(r) if ctx.needs_input_grad[0] else None
+            do = torch.empty_like(op) if need_o else None
+            _lib.call("emer_pixel_loss_bwd", _ptr(r), _ptr(px), _ptr(op), _ptr(sm), R, ctx.w[0], ctx.w[1], _ptr(gc), _ptr(dr), _ptr(do),
+                      _stream(r))
+        return (None if dr is None else dr.view(ctx.shapes[0])), (None if do is None else do.view(ctx.shapes[1])), None, None, None, None
+
+
+def pixel_loss(rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask: Optional[Tensor], w_rgb: float = 1.0,
+               w_sky: float = 0.001) -> Tensor:
+    """rgb L2 + opacity-based sky BCE of a pixel-ray batch as one scalar (0-dim tensor)."""
+    _check_cuda(rgb, opacity, pixels, sky_mask)
+    return _PixelLossFn.apply(rgb, opacity, pixels, sky_mask, w_rgb, w_sky)
 
 
 # ---------------------------------------------------------------------------------- MLP heads

@@ -53,7 +53,7 @@ class PropNetEstimator(AbstractEstimator):
         dev = self.device
         planes = (float(near_plane), float(far_plane), sampling_type)
         # level 0 resamples the trivial histogram on [0, 1]
-        edges = cdfs = torch.tensor([0.0, 1.0], device=dev).expand(n_rays, 2).contiguous()
+        edges = cdfs = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()  # (device-side: graph-capturable)
         for level, (sigma_fn, n_level) in enumerate(zip(prop_sigma_fns, prop_samples)):
             u = self.jitter_fn(n_rays, dev) if stratified else None
             edges, t0, t1 = ops.importance_sample(edges, cdfs, n_level, u, stot=planes, intervals=True)
@@ -82,6 +82,7 @@ class PropNetEstimator(AbstractEstimator):
         s_final = final.vals
         R, n = trans.shape
         anti = bool(self.enable_anti_aliasing_loss)
+        trans_ng = trans.detach()  # the final histogram is a target, not a variable (:186-187)
         total = None
         while self.prop_cache:
             level_edges, level_cdfs, level = self.prop_cache.pop()
@@ -89,7 +90,7 @@ class PropNetEstimator(AbstractEstimator):
             # mean over (R, m) proposal intervals (anti-aliased, :226) or over (R, n) final intervals (_pdf_loss, :230)
             count = R * (m if anti else n)
             pulse = float(self.pulse_width[level]) if anti else 0.0
-            term = ops.prop_level_loss(s_final, trans, level_edges.vals, level_cdfs, pulse, anti, float(loss_scaler) / count)
+            term = ops.prop_level_loss(s_final, trans_ng, level_edges.vals, level_cdfs, pulse, anti, float(loss_scaler) / count)
             total = term if total is None else total + term
         return total if total is not None else torch.zeros((), device=self.device)
 

@@ -446,9 +446,13 @@ class RadianceField(nn.Module):
     # ------------------------------------------------------------------ forward (:391-551)
     def forward(self, positions: Tensor, directions: Tensor = None, data_dict: Dict[str, Tensor] = {},
                 return_density_only: bool = False, combine_static_dynamic: bool = False,
-                query_feature_head: bool = True, query_pe_head: bool = True) -> Dict[str, Tensor]:
+                query_feature_head: bool = True, query_pe_head: bool = True,
+                normed_positions: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """``normed_positions`` (extension): the contracted positions when the caller already has them (render_rays
+        gets them from the ray-point kernel); ``positions`` may then be None unless the flow branch is on."""
         results_dict = {}
-        normed_positions = self.contract_points(positions)
+        if normed_positions is None:
+            normed_positions = self.contract_points(positions)
         geo_feats, semantic_feats, static_density = self._static_split(normed_positions)
 
         has_timestamps = "normed_timestamps" in data_dict or "lidar_normed_timestamps" in data_dict

@@ -28,8 +28,7 @@ from .radiance_field import DensityField, RadianceField
 def render_weights_opacity_depth_from_density(t_starts: Tensor, t_ends: Tensor, density: Tensor):
     """render_utils.py:19-45."""
     weights, _, _, _, stats = ops.render_weights(t_starts, t_ends, density)
-    opacities = stats[:, 0:1].clamp(1e-6, 1.0)
-    depths = stats[:, 1:2] / opacities
+    opacities, depths, _, _ = ops.ray_epilogue(stats)
     return weights, opacities, depths
 
 
@@ -38,17 +37,14 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
     """render_utils.py:48-287."""
     results = query_fn(t_starts, t_ends)
     density = results["density"].squeeze(-1)
-    weights, trans, _, _, stats = ops.render_weights(t_starts, t_ends, density)
-    extras = {"weights": weights, "trans": trans, "t_vals": (t_starts + t_ends) / 2.0, "t_dist": (t_ends - t_starts)}
+    # one scan kernel: weights, transmittance, the per-ray sums behind opacity / depth / median depth (:102-122) and the
+    # t_vals / t_dist extras (:84-85)
+    weights, trans, _, _, stats, t_vals, t_dist = ops.render_weights(t_starts, t_ends, density, want_t=True)
+    extras = {"weights": weights, "trans": trans, "t_vals": t_vals, "t_dist": t_dist}
     for k in ["forward_flow", "backward_flow", "forward_pred_backward_flow", "backward_pred_forward_flow"]:
         if k in results:
             extras[k] = results[k]
-
-    # geometry (:102-122): opacity, expected depth and median depth come out of the same scan kernel
-    opacities = stats[:, 0:1].clamp(1e-6, 1.0)
-    depths = stats[:, 1:2] / opacities
-    median_depth = stats[:, 2:3].detach()
-    results_dict = {"density": density, "depth": depths, "opacity": opacities, "median_depth": median_depth}
+    results_dict = {"density": density}
 
     if "static_density" in results and "dynamic_density" in results:  # :125-155
         extras["static_density"] = results["static_density"]
@@ -63,8 +59,9 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
                 t_starts, t_ends, results["dynamic_density"])
             results_dict["dynamic_opacity"], results_dict["dynamic_depth"] = dynamic_opacities, dynamic_depths
 
+    acc_rgb = None
     if "rgb" in results:  # :158-159
-        results_dict["rgb"] = accumulate_along_rays(weights, values=results["rgb"])
+        acc_rgb = accumulate_along_rays(weights, values=results["rgb"])
     elif "static_rgb" in results and "dynamic_rgb" in results:  # :160-214
         shadow_ratio = 0.0
         if "shadow_ratio" in results:
@@ -72,7 +69,7 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
             results_dict["shadow_ratio"] = accumulate_along_rays(weights, values=shadow_ratio.square())
         rgb = static_ratio[..., None] * results["static_rgb"] * (1 - shadow_ratio) \
             + dynamic_ratio[..., None] * results["dynamic_rgb"]
-        results_dict["rgb"] = accumulate_along_rays(weights, values=rgb)
+        acc_rgb = accumulate_along_rays(weights, values=rgb)
         if return_decomposition:
             results_dict["static_rgb"] = accumulate_along_rays(static_weights, values=results["static_rgb"])
             if "shadow_ratio" in results:
@@ -87,10 +84,14 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
                 results_dict["forward_flow"] = accumulate_along_rays(dynamic_weights, values=results["forward_flow"])
                 results_dict["backward_flow"] = accumulate_along_rays(dynamic_weights, values=results["backward_flow"])
 
-    if "rgb_sky" in results:  # :217-226
-        results_dict["rgb"] = results_dict["rgb"] + results["rgb_sky"] * (1.0 - results_dict["opacity"])
-        if "static_rgb" in results_dict:
-            results_dict["static_rgb"] = results_dict["static_rgb"] + results["rgb_sky"] * (1.0 - results_dict["static_opacity"])
+    # geometry (:102-122) and the sky composite (:217-220) in one per-ray kernel:
+    # opacity = clamp(sum w, 1e-6, 1), depth = sum(w t) / opacity, rgb = acc_rgb + rgb_sky * (1 - opacity)
+    opacities, depths, median_depth, rgb_out = ops.ray_epilogue(stats, acc_rgb, results.get("rgb_sky") if acc_rgb is not None else None)
+    results_dict.update({"depth": depths, "opacity": opacities, "median_depth": median_depth})
+    if rgb_out is not None:
+        results_dict["rgb"] = rgb_out
+    if "rgb_sky" in results and "static_rgb" in results_dict:  # :221-226
+        results_dict["static_rgb"] = results_dict["static_rgb"] + results["rgb_sky"] * (1.0 - results_dict["static_opacity"])
 
     def _finish_dino():
         if "dino_sky_feat" in results:
@@ -143,15 +144,19 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
 
     def query_fn(t_starts, t_ends):
         S = t_starts.shape[-1]
-        t_origins = chunk[prefix + "origins"][..., None, :]
         t_dirs = chunk[prefix + "viewdirs"][..., None, :].expand(-1, S, -1)
         sub_dict = _per_sample(chunk, S, [k for k in chunk if k not in (prefix + "viewdirs", prefix + "origins", "pixel_coords")
                                           and chunk[k].dim() == 1])
         sub_dict["t_starts"], sub_dict["t_ends"] = t_starts, t_ends
         if "pixel_coords" in chunk:
             sub_dict["pixel_coords"] = chunk["pixel_coords"]
-        positions = t_origins + t_dirs * (t_starts + t_ends)[..., None] / 2.0
-        results_dict = radiance_field(positions, t_dirs, sub_dict, return_density_only=(prefix == "lidar_"))
+        # o + d (t0 + t1) / 2 and the contraction in one kernel (sample positions never carry a gradient,
+        # nerfacc_prop_net.py:89); the un-contracted positions are only needed by the flow warp (:553-620)
+        want_pos = radiance_field.flow_xyz_encoder is not None
+        normed, positions = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
+                                           radiance_field.aabb, radiance_field.unbounded, want_positions=want_pos)
+        results_dict = radiance_field(positions, t_dirs, sub_dict, return_density_only=(prefix == "lidar_"),
+                                      normed_positions=normed)
         results_dict["density"] = results_dict["density"].squeeze(-1)
         return results_dict
 
@@ -178,7 +183,8 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         chunk_results = rendering(t_starts, t_ends, query_fn=query_fn, return_decomposition=return_decomposition)
         extras = chunk_results.pop("extras")
         results.append(chunk_results)
-    render_results = {k: torch.cat([r[k] for r in results], 0) for k in results[0]}
+    # (a training batch is one chunk: no concatenation copies of [R,S] tensors)
+    render_results = dict(results[0]) if len(results) == 1 else {k: torch.cat([r[k] for r in results], 0) for k in results[0]}
     extras["density"] = render_results.pop("density")
     for k, v in render_results.items():
         render_results[k] = v.reshape(list(rays_shape[:-1]) + list(v.shape[1:]))

@@ -114,12 +114,58 @@ class FlatParams:
             p.data = self.params[o:o + n].view(p.shape)
             p.grad = self.grads[o:o + n].view(p.shape)
         self._plist = plist
+        # hash tables (large 1-D parameters named "...tcnn_encoding.params") vs everything else, merged into few ranges
+        names = {id(p): n for m in [m for mods in groups.values() for m in mods] for n, p in m.named_parameters()}
+        self._table_offsets = [(p, o) for p, o in plist if names.get(id(p), "").endswith("tcnn_encoding.params")]
+        self._tables = [p for p, _ in self._table_offsets]
+        table_ids = {id(p) for p in self._tables}
+        self._dense_ranges = []
+        for p, o in plist:
+            if id(p) in table_ids:
+                continue
+            if self._dense_ranges and self._dense_ranges[-1][1] == o:
+                self._dense_ranges[-1][1] = o + p.numel()
+            else:
+                self._dense_ranges.append([o, o + p.numel()])
 
     def zero_grad(self):
-        self.grads.zero_()
+        """Zero what is ACCUMULATED into (MLP weights, embeddings: a few hundred KB) and only mark the hash tables:
+        their gradient is overwritten by the owner-computes grid backward (``ops._HashGridLMFn``), which writes every
+        entry exactly once, so zeroing 90 MB per step would be wasted HBM traffic.  A table whose backward did not run
+        this step is zeroed lazily by ``finish_grads`` before anything reads it."""
+        for a, b in self._dense_ranges:
+            self.grads[a:b].zero_()
         for p, o in self._plist:  # autograd may have replaced .grad; re-pin the views
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)
+        for p in self._tables:
+            p._emer_grad_fresh = True
+
+    def finish_grads(self, group: str) -> None:
+        """Tables of ``group`` that no backward wrote this step get their zero gradient now."""
+        a, b = self.ranges[group]
+        for p, o in self._table_offsets:
+            if a <= o < b and getattr(p, "_emer_grad_fresh", False):
+                self.grads[o:o + p.numel()].zero_()
+                p._emer_grad_fresh = False
+
+
+def capture_main_grid_positions(trainer: "Trainer", data: Dict[str, Tensor]) -> Tensor:
+    """Contracted positions [R*S, 3] the MAIN grid is evaluated at during one training step on ``data`` (the
+    proposal-resampled "training distribution" of the grid kernels): tests and profiling tools feed the grid kernels
+    with it.  Runs one optimizer step."""
+    enc = trainer.model.xyz_encoder.tcnn_encoding
+    orig, cap = enc.forward_level_major, {}
+
+    def hook(x):
+        cap["x"] = x.detach().reshape(-1, enc.n_input_dims).contiguous()
+        return orig(x)
+    enc.forward_level_major = hook
+    try:
+        trainer.train_step(data)
+    finally:
+        enc.forward_level_major = orig
+    return cap["x"]
 
 
 def lr_factor(step: int, num_iters: int) -> float:
@@ -183,8 +229,7 @@ class Trainer:
 
     def losses(self, results, data) -> Tensor:
         """rgb L2 (loss/base.py:83-146, coef 1) + opacity-based sky BCE (loss/base.py:149-185, coef 0.001)."""
-        loss = F.mse_loss(results["rgb"].squeeze(), data["pixels"].squeeze())
-        loss = loss + 0.001 * F.binary_cross_entropy(results["opacity"].squeeze(), 1 - data["sky_masks"].float().squeeze())
+        loss = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001)  # one launch
         if "dynamic_density" in results["extras"]:
             loss = loss + 0.01 * results["extras"]["dynamic_density"].mean()
         if "shadow_ratio" in results:
@@ -255,6 +300,9 @@ class Trainer:
                 loss = self._forward_backward(data, prop_grad)
         else:
             loss = self._forward_backward(data, prop_grad)
+        self.flat.finish_grads("main")
+        if prop_grad:
+            self.flat.finish_grads("prop")
         if self.world_size > 1:
             # the single RCCL collective of the step (sum; 1/W folded into Adam).  Proposal-net gradients exist only on
             # the steps that train them (same schedule on every rank), so the other steps exchange the main range only

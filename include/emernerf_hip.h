@@ -97,7 +97,8 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
 /* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
  * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice (accumulated in double) and
  * streams its 1-bit-per-sample slice bitmap ("owner computes"; see csrc/hashgrid.hip).  The training path.
- * slice_masks [L][64][ceil(N/64)] (+ EMER_SLICE_MASK_SCRATCH words the call overwrites): from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x. */
+ * slice_masks [L][64][ceil(N/64)] (+ EMER_SLICE_MASK_SCRATCH words the call overwrites): from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x.
+ * dout is level-major: dout_stride_n == n_features (dout_stride_l free); n < 2^28. */
 int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
                                     const float *dout, int64_t dout_stride_n,
                                     int64_t dout_stride_l, uint64_t *slice_masks,
@@ -186,17 +187,39 @@ int emer_scale(const float *x, const float *dev_scalar, float host_scale, float 
  * w = T*alpha.  Any of weights/trans/alphas/cdfs/ray_stats may be NULL.
  *   cdfs [R,S+1]  = 1 - [T, 0]                        (nerfacc_prop_net.py:166-168)
  *   ray_stats [R,4] = (sum w, sum w*mid, median_depth, reserved), mid = (t_start+t_end)/2;
- *   median_depth follows render_utils.py:107-115 (first s with cumsum(w) >= 0.5, clamped). */
+ *   median_depth follows render_utils.py:107-115 (first s with cumsum(w) >= 0.5, clamped);
+ *   t_mid / t_dist [R,S] (may be NULL) = (t_start+t_end)/2, t_end-t_start: extras["t_vals"], ["t_dist"] (:84-85). */
 int emer_render_weights_fwd(const float *t_starts, const float *t_ends, const float *sigma,
                             int64_t n_rays, int32_t n_samples, float *weights, float *trans,
-                            float *alphas, float *cdfs, float *ray_stats, void *stream);
+                            float *alphas, float *cdfs, float *ray_stats, float *t_mid, float *t_dist,
+                            void *stream);
 /* Given dL/dweights, dL/dtrans, dL/dalphas (any may be NULL) and dL/d(sum w), dL/d(sum w*mid) per ray
- * (d_ray_stats [R,2], may be NULL) produce dL/dsigma.  alphas is a differentiable output because the
+ * (columns 0, 1 of d_ray_stats [R,4], may be NULL) produce dL/dsigma.  alphas is a differentiable output because the
  * reference forms weights = trans * alphas itself (render_utils.py:73-77). */
 int emer_render_weights_bwd(const float *t_starts, const float *t_ends, const float *sigma,
                             const float *d_weights, const float *d_trans, const float *d_alphas,
                             const float *d_ray_stats, int64_t n_rays, int32_t n_samples, float *d_sigma,
                             void *stream);
+/* Per-ray epilogue of `rendering` (radiance_fields/render_utils.py:102-105,217-226):
+ *   opacity = clamp(sum w, 1e-6, 1); depth = (sum w*mid) / opacity; median_depth = ray_stats[:,2];
+ *   rgb = acc_rgb + rgb_sky * (1 - opacity)   (rgb_sky NULL: rgb = acc_rgb; rgb NULL: geometry only, lidar rays).
+ * ray_stats [R,4] from emer_render_weights_fwd; acc_rgb / rgb_sky / rgb [R,3]; opacity / depth / median_depth [R]. */
+int emer_ray_epilogue_fwd(const float *ray_stats, const float *acc_rgb, const float *rgb_sky, int64_t n_rays,
+                          float *opacity, float *depth, float *median_depth, float *rgb, void *stream);
+/* d_ray_stats [R,4] = gradient of ray_stats for emer_render_weights_bwd (columns 2, 3 zero); d_rgb_sky [R,3] (may be NULL).
+ * The gradient of acc_rgb is d_rgb itself.  Any of d_opacity / d_depth / d_rgb may be NULL (zero). */
+int emer_ray_epilogue_bwd(const float *ray_stats, const float *rgb_sky, const float *d_opacity, const float *d_depth,
+                          const float *d_rgb, int64_t n_rays, float *d_ray_stats, float *d_rgb_sky, void *stream);
+/* Pixel losses of a training step (loss/base.py:83-146 rgb L2, :149-185 opacity-based sky loss):
+ *   loss = w_rgb * mean((rgb - pixels)^2) + w_sky * mean(binary_cross_entropy(opacity, 1 - sky_mask))
+ * with torch's clamping of the logs at -100.  rgb/pixels [R,3] (NULL: no rgb term), opacity/sky_mask [R] (NULL: no
+ * sky term).  loss_rays [R] scratch, loss_out [1] (fixed summation order). */
+int emer_pixel_loss_fwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask,
+                        int64_t n_rays, float w_rgb, float w_sky, float *loss_rays, float *loss_out, void *stream);
+/* d_rgb [R,3], d_opacity [R] (either may be NULL), multiplied by the device scalar upstream[0] (NULL: 1). */
+int emer_pixel_loss_bwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask,
+                        int64_t n_rays, float w_rgb, float w_sky, const float *upstream, float *d_rgb,
+                        float *d_opacity, void *stream);
 /* out[r,c] = sum_s w[r,s] * values[r,s,c]   (values == NULL: C = 1, out[r] = sum_s w). */
 int emer_accumulate_fwd(const float *weights, const float *values, int64_t n_rays,
                         int32_t n_samples, int32_t n_channels, float *out, void *stream);
@@ -344,6 +367,38 @@ int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_st
  * dirs [n,3] -> out [n, 3*(1+2*(max_deg+1))].  remap != 0 applies the (d+1)/2 step first. */
 int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, int remap,
                     void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-ray generation (replaces datasets/base/pixel_source.py:39-76 get_rays and
+ * :564-731 sample_uniform_rays / sample_important_rays / the gathers of get_train_rays) on device-resident
+ * dataset tensors.  Random numbers: splitmix64(seed_word[0] ^ salt, counter) -- seed_word lives in device memory so a
+ * captured hipGraph draws new rays by bumping it.
+ * ---------------------------------------------------------------------------------------------- */
+/* n uniform pixels: image = candidates[randint(n_candidates)] (candidates NULL: 0..n_candidates-1), x = randint(width),
+ * y = randint(height)  (pixel_source.py:622-668). */
+int emer_sample_uniform(const uint64_t *seed_word, uint64_t salt, int64_t n, const int64_t *candidates,
+                        int32_t n_candidates, int32_t height, int32_t width, int64_t *img_idx, int64_t *y,
+                        int64_t *x, void *stream);
+/* k DISTINCT indices into weights[0..n_weights) with probability proportional to the weights, without replacement
+ * (torch.multinomial(w, k, replacement=False), pixel_source.py:588-592): Efraimidis-Spirakis keys -log(u)/w, the k
+ * smallest found by a 3-pass radix select.  workspace: 4 + 2048 uint32 words.  Order of flat_out is unspecified. */
+int emer_sample_importance(const float *weights, int64_t n_weights, const uint64_t *seed_word, uint64_t salt,
+                           int64_t k, uint32_t *workspace, int64_t *flat_out, void *stream);
+/* flat index into the [n_candidates][buffer_height][buffer_width] error buffer -> (image, y, x) at full resolution with
+ * a random offset inside the downscaled cell, clamped to the image (pixel_source.py:593-620). */
+int emer_buffer_to_pixels(const int64_t *flat, int64_t n, int32_t buffer_height, int32_t buffer_width,
+                          int32_t downscale, const int64_t *candidates, int32_t height, int32_t width,
+                          const uint64_t *seed_word, uint64_t salt, int64_t *img_idx, int64_t *y, int64_t *x,
+                          void *stream);
+/* (img, y, x) -> ray through pixel centre (x + 0.5, y + 0.5): origins / viewdirs [n,3], direction_norms [n]
+ * (get_rays), pixel_coords [n,2] = (y/H, x/W), and the gathers pixels = images[img,y,x,:] [n,3], sky = sky_masks[img,y,x],
+ * ray_timestamps = timestamps[img], ray_cam_ids = cam_ids[img] (each dataset tensor may be NULL; then its output is
+ * not written).  cam_to_worlds [n_imgs,4,4], intrinsics [n_imgs,3,3] row-major. */
+int emer_gen_rays(const int64_t *img_idx, const int64_t *y, const int64_t *x, const float *cam_to_worlds,
+                  const float *intrinsics, const float *images, const float *sky_masks, const float *timestamps,
+                  const int64_t *cam_ids, int64_t n, int32_t height, int32_t width, float *origins,
+                  float *viewdirs, float *direction_norms, float *pixel_coords, float *pixels, float *sky,
+                  float *ray_timestamps, int64_t *ray_cam_ids, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam as configured in builders.py:50-60,114-120: eps 1e-15,

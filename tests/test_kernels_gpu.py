@@ -201,7 +201,7 @@ def test_render_weights(hip_lib, oracle, R, S):
     w, T, a, cdfs, stats = ops.render_weights(ts.to(dev), te.to(dev), sgd)
     np.testing.assert_allclose(w.detach().cpu().numpy(), w_ref, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(T.detach().cpu().numpy(), T_ref, rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(a.cpu().numpy(), a_ref, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), a_ref, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(cdfs.detach().cpu().numpy()[:, :S], 1 - T_ref, rtol=0, atol=2e-6)
     assert (cdfs.detach().cpu().numpy()[:, S] == 1.0).all()
     mid = ((ts + te) / 2).numpy()
@@ -216,13 +216,15 @@ def test_render_weights(hip_lib, oracle, R, S):
     # backward through weights, trans, cdfs and the per-ray sums vs torch autograd (fp64 on CPU)
     gw, gT, gc = (torch.randn(R, S, generator=g), torch.randn(R, S, generator=g), torch.randn(R, S + 1, generator=g))
     gs = torch.randn(R, 2, generator=g)
-    loss = (w * gw.to(dev)).sum() + (T * gT.to(dev)).sum() + (cdfs * gc.to(dev)).sum() + (stats[:, :2] * gs.to(dev)).sum()
+    ga = torch.randn(R, S, generator=g)  # alphas is a differentiable output too (the reference forms trans * alphas itself)
+    loss = (w * gw.to(dev)).sum() + (T * gT.to(dev)).sum() + (cdfs * gc.to(dev)).sum() + (stats[:, :2] * gs.to(dev)).sum() \
+        + (a * ga.to(dev)).sum()
     loss.backward()
     s64 = sg.double().requires_grad_(True)
-    w2, T2, _ = _torch_render(ts.double(), te.double(), s64)
+    w2, T2, a2 = _torch_render(ts.double(), te.double(), s64)
     c2 = 1 - torch.cat([T2, torch.zeros(R, 1, dtype=torch.double)], -1)
     st2 = torch.stack([w2.sum(-1), (w2 * (ts + te).double() / 2).sum(-1)], -1)
-    ((w2 * gw).sum() + (T2 * gT).sum() + (c2 * gc).sum() + (st2 * gs).sum()).backward()
+    ((w2 * gw).sum() + (T2 * gT).sum() + (c2 * gc).sum() + (st2 * gs).sum() + (a2 * ga).sum()).backward()
     ref_g = s64.grad.numpy()
     np.testing.assert_allclose(sgd.grad.cpu().numpy(), ref_g, rtol=1e-4, atol=1e-5 * np.abs(ref_g).max())
 
@@ -379,8 +381,9 @@ def test_cpu_tensor_is_rejected(hip_lib):
 def _prop_inputs(R, n, m, seed):
     """Final-level edges / transmittance and one proposal level (edges, cdf) shaped like a training step's cache."""
     g = torch.Generator().manual_seed(seed)
-    s_fin = torch.sort(torch.rand(R, n + 1, generator=g), -1).values
-    s_fin[:, 0], s_fin[:, -1] = 0.0, 1.0
+    gaps = torch.rand(R, n, generator=g) ** 2 + 1e-4  # strictly increasing edges (a repeated edge is 0/0 in the reference)
+    s_fin = torch.cat([torch.zeros(R, 1), torch.cumsum(gaps, -1)], -1)
+    s_fin = s_fin / s_fin[:, -1:]
     dens = torch.rand(R, n, generator=g) ** 3 * 40
     dt = s_fin[:, 1:] - s_fin[:, :-1]
     cum = torch.cumsum(dens * dt, -1)
@@ -449,3 +452,157 @@ def test_pdf_loss_matches_torch_form(hip_lib, R, n, m):
     assert abs(float(got) - float(want)) <= 1e-4 * abs(float(want)) + 1e-12
     sc = float(cp.grad.abs().max())
     assert float((cd.grad.cpu() - cp.grad).abs().max()) <= 2e-4 * sc + 1e-12
+
+
+# ----------------------------------------------------------------------------- per-ray epilogue and pixel losses
+@pytest.mark.parametrize("R,with_sky", [(1, True), (1000, True), (8192, False)])
+def test_ray_epilogue_matches_torch(hip_lib, R, with_sky):
+    """emer_ray_epilogue_* vs the reference's per-ray torch chain (render_utils.py:102-105,217-220) in fp64, values and
+    gradients, including rays whose sum of weights sits outside the clamp range."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R)
+    stats = torch.rand(R, 4, generator=g)
+    stats[:, 1] *= 30
+    if R > 10:
+        stats[1, 0] = 1.0 + 3e-7   # above the clamp: gradient of the sum is cut
+        stats[2, 0] = 1e-8         # below
+        stats[3, 0] = 1.0          # on the bound: passes (torch convention)
+    acc = torch.rand(R, 3, generator=g)
+    sky = torch.rand(R, 3, generator=g) if with_sky else None
+    sd, ad = stats.to(dev).requires_grad_(True), acc.to(dev).requires_grad_(True)
+    kd = None if sky is None else sky.to(dev).requires_grad_(True)
+    opa, dep, med, rgb = ops.ray_epilogue(sd, ad, kd)
+    go, gd, gr = torch.randn(R, 1, generator=g), torch.randn(R, 1, generator=g), torch.randn(R, 3, generator=g)
+    ((opa * go.to(dev)).sum() + (dep * gd.to(dev)).sum() + (rgb * gr.to(dev)).sum()).backward()
+    s64, a64 = stats.double().requires_grad_(True), acc.double().requires_grad_(True)
+    k64 = None if sky is None else sky.double().requires_grad_(True)
+    o = s64[:, 0:1].clamp(float(np.float32(1e-6)), 1.0)
+    d = s64[:, 1:2] / o
+    c = a64 if k64 is None else a64 + k64 * (1.0 - o)
+    ((o * go.double()).sum() + (d * gd.double()).sum() + (c * gr.double()).sum()).backward()
+    np.testing.assert_allclose(opa.detach().cpu().numpy(), o.detach().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(dep.detach().cpu().numpy(), d.detach().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), c.detach().numpy(), rtol=2e-6, atol=1e-7)
+    assert torch.equal(med.cpu()[:, 0], stats[:, 2])
+    gs = sd.grad.cpu().double()
+    assert float(gs[:, 2:].abs().max()) == 0.0
+    np.testing.assert_allclose(gs[:, :2].numpy(), s64.grad[:, :2].numpy(), rtol=1e-4, atol=1e-5 * float(s64.grad.abs().max()))
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), a64.grad.numpy(), rtol=1e-6)
+    if sky is not None:
+        np.testing.assert_allclose(kd.grad.cpu().numpy(), k64.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("R", [1, 777, 8192])
+def test_pixel_loss_matches_torch(hip_lib, R):
+    """emer_pixel_loss_* vs F.mse_loss + 0.001 * F.binary_cross_entropy (loss/base.py:83-185 as the trainer applies
+    them), incl. opacities of exactly 1 and 1e-6 (torch clamps the logs at -100)."""
+    import torch.nn.functional as Fn
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + 5)
+    rgb, pix = torch.rand(R, 3, generator=g), torch.rand(R, 3, generator=g)
+    opa = torch.rand(R, 1, generator=g).clamp(1e-6, 1.0)
+    sky = (torch.rand(R, generator=g) < 0.3).float()
+    if R > 4:
+        opa[0], opa[1], opa[2], opa[3] = 1.0, 1.0, 1e-6, 1e-6
+        sky[0], sky[1], sky[2], sky[3] = 1.0, 0.0, 1.0, 0.0
+    rd, od = rgb.to(dev).requires_grad_(True), opa.to(dev).requires_grad_(True)
+    loss = ops.pixel_loss(rd, od, pix.to(dev), sky.to(dev), 1.0, 0.001)
+    (loss * 1024.0).backward()
+    r2, o2 = rgb.clone().requires_grad_(True), opa.clone().requires_grad_(True)
+    want = Fn.mse_loss(r2.squeeze(), pix.squeeze()) + 0.001 * Fn.binary_cross_entropy(o2.squeeze(-1), 1 - sky)
+    (want * 1024.0).backward()
+    np.testing.assert_allclose(float(loss), float(want), rtol=2e-6)
+    np.testing.assert_allclose(rd.grad.cpu().numpy(), r2.grad.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(od.grad.cpu().numpy(), o2.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------ training-ray generation
+def _ref_get_rays(x, y, c2w, K):
+    """datasets/base/pixel_source.py:39-76 restated (the reference module cannot travel to the GPU box)."""
+    cam = torch.nn.functional.pad(torch.stack([(x - K[:, 0, 2] + 0.5) / K[:, 0, 0], (y - K[:, 1, 2] + 0.5) / K[:, 1, 1]], -1), (0, 1), value=1.0)
+    d = (cam[:, None, :] * c2w[:, :3, :3]).sum(-1)
+    o = torch.broadcast_to(c2w[:, :3, -1], d.shape)
+    n = torch.linalg.norm(d, dim=-1, keepdims=True)
+    return o, d / (n + 1e-8), n
+
+
+def test_gen_rays_and_train_batch(hip_lib):
+    """emer_gen_rays vs get_rays + the index gathers of get_train_rays (pixel_source.py:670-731); uniform sampling ranges."""
+    from emernerf_amd.pixel_source import PixelSource, get_rays
+    dev = _dev()
+    src = PixelSource.synthetic(dev, num_imgs=12, height=48, width=64, num_cams=3, seed=4)
+    batch = src.get_train_rays(5000, candidate_indices=[1, 4, 7, 10])
+    img, pc = batch["img_idx"].cpu(), batch["pixel_coords"].cpu()
+    assert set(img.tolist()) <= {1, 4, 7, 10} and len(set(img.tolist())) == 4
+    y, x = (pc[:, 0] * 48).round().long(), (pc[:, 1] * 64).round().long()
+    assert int(y.min()) == 0 and int(y.max()) == 47 and int(x.min()) == 0 and int(x.max()) == 63
+    o, d, n = _ref_get_rays(x.float(), y.float(), src.cam_to_worlds.cpu()[img], src.intrinsics.cpu()[img])
+    np.testing.assert_allclose(batch["origins"].cpu().numpy(), o.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(batch["viewdirs"].cpu().numpy(), d.numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(batch["direction_norms"].cpu().numpy(), n.numpy(), rtol=2e-7)
+    assert torch.equal(batch["pixels"].cpu(), src.images.cpu()[img, y, x])
+    assert torch.equal(batch["sky_masks"].cpu(), src.sky_masks.cpu()[img, y, x])
+    assert torch.equal(batch["normed_timestamps"].cpu(), src.normalized_timestamps.cpu()[img])
+    assert torch.equal(batch["cam_idx"].cpu(), src.cam_ids.cpu()[img])
+    # a new batch differs (the seed word advances on the device), and the stand-alone get_rays agrees
+    b2 = src.get_train_rays(5000, candidate_indices=[1, 4, 7, 10])
+    assert not torch.equal(b2["pixel_coords"], batch["pixel_coords"])
+    o2, d2, n2 = get_rays(x.to(dev), y.to(dev), src.cam_to_worlds[img.to(dev)], src.intrinsics[img.to(dev)])
+    assert torch.equal(o2, batch["origins"]) and torch.equal(d2, batch["viewdirs"])
+    # render rays: every pixel of image 5, image-shaped
+    rr = src.get_render_rays(5)
+    assert rr["origins"].shape == (48, 64, 3) and rr["pixels"].shape == (48, 64, 3) and rr["sky_masks"].shape == (48, 64)
+    assert torch.equal(rr["pixels"], src.images[5])
+
+
+def test_importance_sampling_without_replacement(hip_lib):
+    """emer_sample_importance == torch.multinomial(w, k, replacement=False) in distribution: k distinct indices, never a
+    zero-weight one, inclusion frequencies within 5 sigma of torch's own over 3000 draws; and a million-entry buffer."""
+    import ctypes
+    from emernerf_amd import _lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    n, k, draws = 64, 8, 3000
+    w = torch.rand(n, generator=g) ** 3
+    w[5], w[17] = 0.0, 0.0
+    wd = w.to(dev)
+    ws = torch.empty(4 + 2048, dtype=torch.int32, device=dev)
+    out = torch.empty(k, dtype=torch.int64, device=dev)
+    counts = torch.zeros(n)
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    for t in range(draws):
+        seed.fill_(t * 7919 + 1)
+        _lib.call("emer_sample_importance", ops._ptr(wd), n, ops._ptr(seed), 0, k, ops._ptr(ws), ops._ptr(out), ops._stream(wd))
+        o = out.cpu()
+        assert len(set(o.tolist())) == k and int(o.min()) >= 0 and int(o.max()) < n
+        counts[o] += 1
+    assert counts[5] == 0 and counts[17] == 0
+    ref = torch.zeros(n)
+    gg = torch.Generator().manual_seed(1)
+    for _ in range(draws):
+        ref[torch.multinomial(w, k, replacement=False, generator=gg)] += 1
+    p = ref / draws
+    sigma = torch.sqrt(p * (1 - p) / draws).clamp_min(1e-3) * (2 ** 0.5)
+    assert float(((counts / draws - p).abs() / sigma).max()) < 5.0
+    # error-buffer scale: 200 images at 160 x 240 -> 7.68 M weights, 2048 winners
+    big = torch.rand(200 * 160 * 240, generator=g).to(dev)
+    big[::3] = 0.0
+    o = torch.empty(2048, dtype=torch.int64, device=dev)
+    _lib.call("emer_sample_importance", ops._ptr(big), big.numel(), ops._ptr(seed), 5, 2048, ops._ptr(ws), ops._ptr(o), ops._stream(big))
+    oc = o.cpu()
+    assert len(set(oc.tolist())) == 2048 and float(big[o].min()) > 0.0
+    assert float(big[o].mean()) > 0.6  # weights ~U(0,1): winners are biased to heavy entries (E[w | picked] = 2/3)
+    # through the PixelSource API
+    from emernerf_amd.pixel_source import PixelSource
+    src = PixelSource.synthetic(dev, num_imgs=6, height=32, width=48, seed=2, buffer_ratio=0.2)
+    src.build_pixel_error_buffer()
+    err = torch.zeros(6, 8, 12)
+    err[2, 3, 4] = 1.0
+    err[4] = 0.5
+    src.update_pixel_error_maps(torch.zeros(6, 8, 12, 3), err[..., None].expand(-1, -1, -1, 3))
+    b = src.get_train_rays(400)
+    assert b["origins"].shape == (400, 3)
+    roi = b["img_idx"].cpu()[320:]  # the last fifth (80 rays) comes from the buffer: only images 2 and 4 (97 cells) carry error
+    assert set(roi.tolist()) <= {2, 4}

@@ -4,6 +4,9 @@ passes) and a quick A/B timer.  argv: [--uniform] [--iters K] [--grid D,L,base,m
 import argparse, ctypes, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import emernerf_amd._lib as _L0
+if "--lib" in sys.argv:  # A/B: emernerf_amd/lib/libemernerf_<tag>.so built by tools/build_variant.sh
+    _L0.LIB_PATH = os.path.join(os.path.dirname(_L0.LIB_PATH), f"libemernerf_{sys.argv[sys.argv.index('--lib') + 1]}.so")
 from emernerf_amd import _lib, ops
 from emernerf_amd.trainer import Trainer, synthetic_rays
 import numpy as np
@@ -13,6 +16,7 @@ ap.add_argument("--uniform", action="store_true")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--grid", default="3,16,16,2048,19,2")
 ap.add_argument("--table-init", type=float, default=None)
+ap.add_argument("--lib", default=None)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 D, L, base, mx, T, F = (int(v) for v in args.grid.split(","))
@@ -24,13 +28,10 @@ if args.uniform:
 else:
     tr = Trainer(kind="static", device=dev, table_init=args.table_init)
     data = synthetic_rays(8192, dev, seed=1000)
-    cap = {}
-    orig = tr.model.contract_points
-    def hook(p):
-        out = orig(p); cap["x"] = out.detach().reshape(-1, 3).contiguous(); return out
-    tr.model.contract_points = hook
-    for _ in range(3):
+    from emernerf_amd.trainer import capture_main_grid_positions
+    for _ in range(2):
         tr.train_step(data)
+    cap = {"x": capture_main_grid_positions(tr, data)}
     x = cap["x"]
     if D == 4:
         x = torch.cat([x, data["normed_timestamps"][:, None].expand(-1, 128).reshape(-1, 1)], -1).contiguous()
@@ -53,7 +54,8 @@ def timeit(fn, iters):
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
     return ts[len(ts) // 2]
 f_us, b_us = timeit(fwd, args.iters), timeit(bwd, args.iters)
+f0_us = timeit(lambda: ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=False), args.iters)
 fb = 4 * D + (2 ** D) * L * F * 4 + L * F * 4
 bb = 4 * D + L * F * 4 + 2 * (2 ** D) * L * F * 4
-print(json.dumps({"grid": args.grid, "dist": "uniform" if args.uniform else "training", "fwd_us": round(f_us, 1), "bwd_us": round(b_us, 1),
+print(json.dumps({"lib": args.lib or "base", "grid": args.grid, "dist": "uniform" if args.uniform else "training", "fwd_us": round(f_us, 1), "fwd_nomask_us": round(f0_us, 1), "bwd_us": round(b_us, 1),
                   "pair_frac_of_8TBps": round((fb + bb) * N / ((f_us + b_us) * 1e-6) / 8e12, 4)}))

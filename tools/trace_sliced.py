@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import emernerf_amd._build as B
 B.build()
-subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "trace", "hashgrid.hip", "1s|^|#define EMER_SLICED_TRACE 1\\n|"])
+extra = "".join(f"#define {d.replace('=', ' ')}\\n" for d in os.environ.get("EMER_TRACE_DEFS", "").split())  # e.g. "EMER_DENSE_ITEMS=1024"
+subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "trace", "hashgrid.hip", f"1s|^|#define EMER_SLICED_TRACE 1\\n{extra}|"])
 import emernerf_amd._lib as L
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libemernerf_trace.so")
 import numpy as np
@@ -26,13 +27,10 @@ if "--uniform" in sys.argv:
 else:
     tr = Trainer(kind="static", device=dev, table_init=0.3 if "--clustered" in sys.argv else None)
     data = synthetic_rays(8192, dev, seed=1000)
-    cap = {}
-    orig = tr.model.contract_points
-    def hook(p):
-        out = orig(p); cap["x"] = out.detach().reshape(-1, 3).contiguous(); return out
-    tr.model.contract_points = hook
-    for _ in range(3):
+    from emernerf_amd.trainer import capture_main_grid_positions
+    for _ in range(2):
         tr.train_step(data)
+    cap = {"x": capture_main_grid_positions(tr, data)}
     x = cap["x"]
     del tr
 p = torch.rand(desc.n_entries * F, device=dev) - 0.5
