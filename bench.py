@@ -117,6 +117,22 @@ def pmc_traffic(dominant: str, D: int, F: int, args):
         return None, None
 
 
+def rccl_summary(path, world):
+    """The lines of RCCL's INFO log (rank 0) that show how many ranks the communicator has and what it built."""
+    keep, n = [], 0
+    try:
+        with open(path, errors="replace") as f:
+            for line in f:
+                n += 1
+                if any(t in line for t in ("nranks", "nRanks", "Init COMPLETE", "Connected all", "Channel 00", "Trees", "Ring 00",
+                                           "comm 0x", "via P2P", "XGMI", "xgmi", "Algo", "algo")):
+                    if len(keep) < 12:
+                        keep.append(line.strip()[:240])
+    except OSError as e:
+        return {"world_size": world, "log": f"unavailable: {e!r}"}
+    return {"world_size": world, "backend": "nccl (RCCL)", "log_lines_total": n, "log_excerpt": keep}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +162,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    rccl_log = None
     if world > 1:
+        # RCCL's own account of the communicator (ranks, rings / trees, transport) goes to a per-rank file, not to stdout
+        # (the JSON line must stay alone there); rank 0 quotes the relevant lines in the result
+        rccl_log = f"/tmp/emer_rccl_rank{rank}_{os.getpid()}.log"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from emernerf_amd import _build, _lib
@@ -325,6 +348,8 @@ def main():
             "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "
                             "timed region; the roofline kernels are timed with HIP events inside the timed region itself",
         }
+        if world > 1:
+            out["rccl"] = rccl_summary(os.environ.get("NCCL_DEBUG_FILE", rccl_log), world)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(trainer, args.cpu_rays, args.samples)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "emer_ray_epilogue_bwd": [_P, _P, _P, _P, _P, c_int64, _P, _P, _P],
     "emer_pixel_loss_fwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],
     "emer_pixel_loss_bwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P, _P],
+    "emer_lidar_loss": [_P, _P, _P, _P, c_int64, c_int32, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
     "emer_linear_fwd": [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, c_int, _P, _P],

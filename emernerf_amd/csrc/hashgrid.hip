@@ -292,27 +292,68 @@ __device__ __forceinline__ uint32_t bitmap_rows(const SlicePlan &p, uint32_t lev
 
 
 // 64x64 bit-matrix transpose across the 64 lanes of a wave (lane r holds row r; afterwards lane c holds
-// column c): six butterfly stages, each swapping the off-diagonal blocks with lane ^ j.
-__device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x, int lane) {
-    const uint64_t lowmask[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
-                                 0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-#pragma unroll
-    for (int st = 0; st < 6; ++st) {
-        const int j = 32 >> st;
-        const uint64_t lm = lowmask[st];
-        const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)x, j, kWave);
-        x = (lane & j) ? (((y & ~lm) >> j) | (x & ~lm)) : ((x & lm) | ((y & lm) << j));
+// column c): six butterfly stages, each swapping the off-diagonal blocks with lane ^ j -- all on VALU data-parallel
+// primitives (DPP, v_permlane16/32_swap_b32 of gfx950), no ds_bpermute round trips through the LDS crossbar.
+// value of lane ^ J for J in {1, 2, 4, 8, 16}, without touching the LDS crossbar: quad permutes (1, 2), row shifts
+// selected by the lane's bit (4), a row rotation by 8, and the gfx950 row-pair swap v_permlane16_swap_b32 (16)
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);        // quad_perm [2,3,0,1]
+    if (J == 4) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, false);  // row_shl:4  <- lane + 4
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4  <- lane - 4
+        return (lane & 4) ? dn : up;
     }
+    if (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);       // row_ror:8
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0]: odd rows <- lane - 16; r[1]: even rows <- lane + 16
+    return (lane & 16) ? r[0] : r[1];
+}
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v, int lane) {
+    return ((uint64_t)lane_xor_u32<J>((uint32_t)(v >> 32), lane) << 32) | lane_xor_u32<J>((uint32_t)v, lane);
+}
+template <int J>
+__device__ __forceinline__ uint64_t transpose_stage(uint64_t x, uint64_t lm, int lane) {
+    const uint64_t y = lane_xor_u64<J>(x, lane);
+    return (lane & J) ? (((y & ~lm) >> J) | (x & ~lm)) : ((x & lm) | ((y & lm) << J));
+}
+__device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x, int lane) {
+    {   // j = 32: whole dwords change halves of the wave
+        const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)(x >> 32), false, false);
+        x = ((uint64_t)r[1] << 32) | r[0];
+    }
+    x = transpose_stage<16>(x, 0x0000FFFF0000FFFFull, lane);
+    x = transpose_stage<8>(x, 0x00FF00FF00FF00FFull, lane);
+    x = transpose_stage<4>(x, 0x0F0F0F0F0F0F0F0Full, lane);
+    x = transpose_stage<2>(x, 0x3333333333333333ull, lane);
+    x = transpose_stage<1>(x, 0x5555555555555555ull, lane);
     return x;
 }
 
-// The owner-computes backward reads ONE bit per sample for each (level, slice).  A wave holding the 64-bit
-// slice masks of 64 consecutive samples transposes them, so lane s holds the membership bits of slice s,
-// and writes word (n0 / 64) of that slice's bitmap.  Layout: bitmaps[(level * 64 + s) * n_words + word].
+// The owner-computes backward reads ONE bit per sample for each (level, slice).  A wave holding the 64-bit slice masks
+// of 64 consecutive samples transposes them, so lane s holds the membership bits of slice s; the four waves of a
+// workgroup (256 consecutive samples) stage their columns in LDS and wave 0 writes 32 contiguous bytes per bitmap row
+// (one store instruction touches 64 lines instead of four doing so).  Layout: bitmaps[(level * 64 + s) * n_words + word].
+// Must be called by ALL 256 threads of the workgroup (it synchronises).
 __device__ __forceinline__ void store_slice_bitmaps(uint64_t *__restrict__ bitmaps, uint64_t mask, uint32_t level, uint32_t n_slices,
-                                                    int64_t n0_wave, int64_t n_words, int lane) {
-    const uint64_t col = wave_bit_transpose(mask, lane);
-    if ((uint32_t)lane < n_slices && (n0_wave >> 6) < n_words) bitmaps[((int64_t)level * 64 + lane) * n_words + (n0_wave >> 6)] = col;
+                                                    int64_t n0_block, int64_t n_words, int tid) {
+    __shared__ uint64_t tile[4][64];  // [wave][row]: conflict-free writes and reads
+    const int lane = tid & 63, wave = tid >> 6;
+    tile[wave][lane] = wave_bit_transpose(mask, lane);
+    __syncthreads();
+    if (wave == 0 && (uint32_t)lane < n_slices) {
+        const int64_t w0 = n0_block >> 6;  // first word of this workgroup (a multiple of 4)
+        uint64_t *dst = bitmaps + ((int64_t)level * 64 + lane) * n_words + w0;
+        if ((n_words & 3) == 0 && w0 + 4 <= n_words) {
+            reinterpret_cast<ulonglong2 *>(dst)[0] = make_ulonglong2(tile[0][lane], tile[1][lane]);
+            reinterpret_cast<ulonglong2 *>(dst)[1] = make_ulonglong2(tile[2][lane], tile[3][lane]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (w0 + q < n_words) dst[q] = tile[q][lane];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -351,6 +392,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
             const uint32_t maskv = li.size - 1u;
             const bool x_even = (gi[0] & 1u) == 0u;
+            // inside the grid (gi[0] + 1 <= res) the two x-neighbours differ only in index bits below the slice bits when
+            // the resolution is below the slice width: one membership bit covers both
+            const bool x_pair_one_slice = li.res < (1u << plan.shift[level]) && !__ballot(gi[0] >= li.res);
 #pragma unroll
             for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
                 uint32_t h = 0;
@@ -379,7 +423,10 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
                 for (int f = 0; f < F; ++f) acc[f] += wa * v0[f];
 #pragma unroll
                 for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
-                if (masks) mask |= (1ull << slice_of(plan, level, idx0)) | (1ull << slice_of(plan, level, idx1));
+                if (masks) {
+                    mask |= 1ull << slice_of(plan, level, idx0);
+                    if (!x_pair_one_slice) mask |= 1ull << slice_of(plan, level, idx1);  // (level-uniform)
+                }
             }
         }
         }
@@ -409,10 +456,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             for (int f = 0; f < F; ++f) o[f] = acc[f];
         }
     }
-    if (masks) {  // the whole wave takes part in the transpose (tail lanes carry an empty mask)
-        const int lane = threadIdx.x & 63;
-        store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), n - lane, (N + 63) >> 6, lane);
-    }
+    if (masks)  // the whole workgroup takes part (tail lanes carry an empty mask)
+        store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------ backward (params)
@@ -869,7 +914,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 ns[k] = n;
                 // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
                 // scalar-base + 32-bit-offset addressing mode instead of 64-bit multiply-adds per lane (sn == F)
-                const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (uint32_t)(n * (uint32_t)(D * 4)));
+                // (n * 12 as shifts: v_mul_lo_u32 is a quarter-rate instruction)
+                const uint32_t xoff = (D == 3) ? ((n << 3) + (n << 2)) : (n * (uint32_t)(D * 4));
+                const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + xoff);
                 const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dl) + (uint32_t)(n * (uint32_t)(F * 4)));
                 load_x<D>(xp, 0, xs[k]);
                 if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(gp); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
@@ -1054,8 +1101,7 @@ __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_gr
             mask |= 1ull << slice_of(plan, level, grid_index<D>(li, c));
         }
     }
-    const int lane = threadIdx.x & 63;
-    store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), n - lane, (N + 63) >> 6, lane);
+    store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------- backward (input)

@@ -98,6 +98,81 @@ __global__ __launch_bounds__(256) void pixel_loss_bwd_kernel(const float *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ lidar losses
+// Depth + line-of-sight supervision of a lidar-ray batch (loss/base.py:188-271 DepthLoss "l2", :295-345 LineOfSightLoss,
+// :430-464 compute_line_of_sight_loss; called at train_emernerf.py:770-808).  With gt = lidar range, t = sample
+// midpoints, w = rendering weights:
+//   depth:  mean over VALID rays (0.01 < gt < max_depth) of (clamp(pred / max, 0, 1) - clamp(gt / max, 0, 1))^2
+//   sight:  [ mean_r sum_s w^2 [t < gt - eps]  +  mean_r sum_s (w - N(t - gt; sigma = eps / 3))^2 [|t - gt| < eps] ]
+//           * mean_r [gt > 0]
+// (the reference multiplies the SCALAR sum of the two ray-means by the per-ray mask gt > 0 and then averages: the
+// product of two means, reproduced as is).  counts = (#rays with gt > 0, #valid rays) from lidar_counts_kernel.
+__global__ __launch_bounds__(1024) void lidar_counts_kernel(const float *__restrict__ gt, int64_t R, float max_depth, float *__restrict__ counts) {
+    __shared__ float part[2][16];
+    float a = 0.0f, b = 0.0f;
+    for (int64_t i = threadIdx.x; i < R; i += 1024) {
+        const float g = gt[i];
+        a += g > 0.0f ? 1.0f : 0.0f;
+        b += (g > 0.01f && g < max_depth) ? 1.0f : 0.0f;
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.0f, sb = 0.0f;
+        for (int i = 0; i < 16; ++i) { sa += part[0][i]; sb += part[1][i]; }
+        counts[0] = sa; counts[1] = sb;
+    }
+}
+
+// one wave per ray; loss_rays [R] = this ray's share of the total; d_depth [R], d_weights [R,S] times upstream g[0]
+__global__ __launch_bounds__(256) void lidar_loss_kernel(const float *__restrict__ depth, const float *__restrict__ gt,
+                                                         const float *__restrict__ weights, const float *__restrict__ t_vals,
+                                                         int64_t R, int32_t S, float eps, float max_depth, float w_depth, float w_sight,
+                                                         const float *__restrict__ counts, const float *__restrict__ g,
+                                                         float *__restrict__ loss_rays, float *__restrict__ d_depth,
+                                                         float *__restrict__ d_weights) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const float up = g ? g[0] : 1.0f;
+    const float n_pos = counts[0], n_valid = counts[1];
+    const float gd = gt[r];
+    // ---- depth term (per valid ray)
+    float l = 0.0f;
+    const bool valid = gd > 0.01f && gd < max_depth;
+    if (valid && w_depth != 0.0f) {
+        const float pn = depth[r] / max_depth, gn = fminf(fmaxf(gd / max_depth, 0.0f), 1.0f);
+        const float pc = fminf(fmaxf(pn, 0.0f), 1.0f);
+        const float d = pc - gn;
+        l += w_depth * d * d / n_valid;
+        if (d_depth && lane == 0) d_depth[r] = (pn >= 0.0f && pn <= 1.0f) ? up * w_depth * 2.0f * d / (max_depth * n_valid) : 0.0f;
+    } else if (d_depth && lane == 0) {
+        d_depth[r] = 0.0f;
+    }
+    // ---- line of sight: scale = w_sight * mean[gt > 0] / R
+    const float scale = w_sight * (n_pos / (float)R) / (float)R;
+    const float sigma = eps / 3.0f;
+    const float norm = 1.0f / sqrtf(2.0f * 3.14159265358979323846f * sigma * sigma), inv2s2 = 1.0f / (2.0f * sigma * sigma);
+    float acc = 0.0f;
+    for (int32_t s = lane; s < S; s += kWave) {
+        const int64_t i = r * S + s;
+        const float w = weights[i], t = t_vals[i];
+        float term = 0.0f, dw = 0.0f;
+        if (t < gd - eps) { term = w * w; dw = 2.0f * w; }
+        else if (t > gd - eps && t < gd + eps) {
+            const float x = t - gd;
+            const float e = w - norm * expf(-(x * x) * inv2s2);
+            term = e * e; dw = 2.0f * e;
+        }
+        acc += term;
+        if (d_weights) d_weights[i] = up * scale * dw;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) loss_rays[r] = l + scale * acc;
+}
+
 }  // namespace emer
 
 using namespace emer;
@@ -141,4 +216,20 @@ extern "C" int emer_pixel_loss_bwd(const float *rgb, const float *pixels, const 
     hipLaunchKernelGGL(pixel_loss_bwd_kernel, dim3((uint32_t)ceil_div(n_rays, 256)), dim3(256), 0, as_stream(stream), rgb, pixels, opacity,
                        sky_mask, n_rays, w_rgb, w_sky, upstream, d_rgb, d_opacity);
     return check_launch("pixel_loss_bwd");
+}
+
+// workspace: n_rays + 2 floats (per-ray partials + the two counts)
+extern "C" int emer_lidar_loss(const float *depth, const float *lidar_ranges, const float *weights, const float *t_vals, int64_t n_rays,
+                               int32_t n_samples, float epsilon, float max_depth, float w_depth, float w_sight, const float *upstream,
+                               float *workspace, float *loss_out, float *d_depth, float *d_weights, void *stream) {
+    EMER_REQUIRE(n_rays >= 1 && n_samples >= 1 && epsilon > 0.0f && max_depth > 0.0f, "lidar_loss: bad arguments");
+    EMER_REQUIRE(depth && lidar_ranges && weights && t_vals && workspace, "lidar_loss: null pointer");
+    hipStream_t st = as_stream(stream);
+    float *counts = workspace + n_rays;
+    hipLaunchKernelGGL(lidar_counts_kernel, dim3(1), dim3(1024), 0, st, lidar_ranges, n_rays, max_depth, counts);
+    hipLaunchKernelGGL(lidar_loss_kernel, dim3((uint32_t)ceil_div(n_rays, 4)), dim3(256), 0, st, depth, lidar_ranges, weights, t_vals, n_rays,
+                       n_samples, epsilon, max_depth, w_depth, w_sight, counts, upstream, workspace, d_depth, d_weights);
+    if (int rc = check_launch("lidar_loss")) return rc;
+    if (loss_out) return emer_reduce_sum(workspace, n_rays, 0, loss_out, stream);
+    return EMER_OK;
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void race_emit_kernel(const float *__restrict_
         const uint32_t k = race_key(seed, i, w[i]);
         if (k < thr) {
             const uint32_t p = atomicAdd(state + 2, 1u);
-            out[p] = i;
+            if (p < n_lt) out[p] = i;  // (always true when the histograms are consistent; never write out of bounds)
         } else if (k == thr) {
             const uint32_t p = atomicAdd(state + 3, 1u);
             if (p < n_eq) out[n_lt + p] = i;

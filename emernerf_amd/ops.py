@@ -159,6 +159,7 @@ class _HashGridLMFn(torch.autograd.Function):
         from . import fused
         sink = fused._sink(params) if ctx.sliced else None
         ctx.param = params if (sink is not None and sink.is_contiguous() and sink.numel() == pc.numel()) else None
+        ctx.param_obj = params
         ctx.save_for_backward(xc, pc, masks)
         return lm
 
@@ -168,6 +169,9 @@ class _HashGridLMFn(torch.autograd.Function):
         desc = ctx.desc
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         dx = dp = None
+        cb = getattr(ctx.param_obj, "_emer_before_table_grad", None)
+        if cb is not None:  # data-parallel trainer: everything upstream of this table has its gradient enqueued by now
+            cb()
         with torch.cuda.device(xc.device):
             dlm = _f32c(dlm)
             st = _stream(xc)
@@ -496,6 +500,46 @@ def pixel_loss(rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask:
     """rgb L2 + opacity-based sky BCE of a pixel-ray batch as one scalar (0-dim tensor)."""
     _check_cuda(rgb, opacity, pixels, sky_mask)
     return _PixelLossFn.apply(rgb, opacity, pixels, sky_mask, w_rgb, w_sky)
+
+
+class _LidarLossFn(torch.autograd.Function):
+    """w_depth * depth loss + w_sight * line-of-sight loss of a lidar-ray batch (train_emernerf.py:770-808)."""
+
+    @staticmethod
+    def forward(ctx, depth: Tensor, weights: Tensor, ranges: Tensor, t_vals: Tensor, epsilon: float, max_depth: float,
+                w_depth: float, w_sight: float):
+        dp, w, rg, tv = _f32c(depth).view(-1), _f32c(weights), _f32c(ranges).view(-1), _f32c(t_vals)
+        R, S = w.shape
+        with torch.cuda.device(w.device):
+            ws = torch.empty((R + 2,), device=w.device, dtype=torch.float32)
+            loss = torch.empty((), device=w.device, dtype=torch.float32)
+            _lib.call("emer_lidar_loss", _ptr(dp), _ptr(rg), _ptr(w), _ptr(tv), R, S, float(epsilon), float(max_depth), float(w_depth),
+                      float(w_sight), None, _ptr(ws), _ptr(loss), None, None, _stream(w))
+        ctx.save_for_backward(dp, w, rg, tv)
+        ctx.cfg, ctx.dshape = (float(epsilon), float(max_depth), float(w_depth), float(w_sight)), depth.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        dp, w, rg, tv = ctx.saved_tensors
+        R, S = w.shape
+        eps, md, wd, wsg = ctx.cfg
+        gc = _f32c(g).reshape(1)
+        with torch.cuda.device(w.device):
+            ws = torch.empty((R + 2,), device=w.device, dtype=torch.float32)
+            dd = torch.empty((R,), device=w.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+            dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+            _lib.call("emer_lidar_loss", _ptr(dp), _ptr(rg), _ptr(w), _ptr(tv), R, S, eps, md, wd, wsg, _ptr(gc), _ptr(ws), None, _ptr(dd),
+                      _ptr(dw), _stream(w))
+        return (None if dd is None else dd.view(ctx.dshape)), dw, None, None, None, None, None, None
+
+
+def lidar_loss(depth: Tensor, weights: Tensor, lidar_ranges: Tensor, t_vals: Tensor, epsilon: float, max_depth: float = 80.0,
+               w_depth: float = 1.0, w_sight: float = 0.1) -> Tensor:
+    """Depth (loss/base.py:188-271, l2) + line-of-sight (loss/base.py:430-464) supervision as one scalar; gradients flow
+    to the rendered depth [R,1] and the rendering weights [R,S]."""
+    _check_cuda(depth, weights, lidar_ranges, t_vals)
+    return _LidarLossFn.apply(depth, weights, lidar_ranges, t_vals, epsilon, max_depth, w_depth, w_sight)
 
 
 # ---------------------------------------------------------------------------------- MLP heads

@@ -220,6 +220,16 @@ int emer_pixel_loss_fwd(const float *rgb, const float *pixels, const float *opac
 int emer_pixel_loss_bwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask,
                         int64_t n_rays, float w_rgb, float w_sky, const float *upstream, float *d_rgb,
                         float *d_opacity, void *stream);
+/* Lidar-ray supervision (train_emernerf.py:770-808): depth loss (loss/base.py:188-271, "l2", normalised by max_depth,
+ * mean over rays with 0.01 < range < max_depth) + line-of-sight loss (loss/base.py:430-464: empty-space and near-surface
+ * terms with margin epsilon, times the fraction of rays with range > 0).
+ *   loss = w_depth * depth_loss + w_sight * sight_loss   (w_sight = loss_coef * coef_decay)
+ * depth / lidar_ranges [R], weights / t_vals [R,S].  workspace: R + 2 floats.  loss_out [1] (may be NULL);
+ * d_depth [R] / d_weights [R,S] (may be NULL) are multiplied by the device scalar upstream[0] (NULL: 1). */
+int emer_lidar_loss(const float *depth, const float *lidar_ranges, const float *weights, const float *t_vals,
+                    int64_t n_rays, int32_t n_samples, float epsilon, float max_depth, float w_depth, float w_sight,
+                    const float *upstream, float *workspace, float *loss_out, float *d_depth, float *d_weights,
+                    void *stream);
 /* out[r,c] = sum_s w[r,s] * values[r,s,c]   (values == NULL: C = 1, out[r] = sum_s w). */
 int emer_accumulate_fwd(const float *weights, const float *values, int64_t n_rays,
                         int32_t n_samples, int32_t n_channels, float *out, void *stream);

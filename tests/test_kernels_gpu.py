@@ -606,3 +606,41 @@ def test_importance_sampling_without_replacement(hip_lib):
     assert b["origins"].shape == (400, 3)
     roi = b["img_idx"].cpu()[320:]  # the last fifth (80 rays) comes from the buffer: only images 2 and 4 (97 cells) carry error
     assert set(roi.tolist()) <= {2, 4}
+
+
+# ---------------------------------------------------------------------------------------------- lidar losses
+@pytest.mark.parametrize("R,S", [(1, 16), (300, 64), (4096, 128)])
+def test_lidar_loss_matches_reference_form(hip_lib, R, S):
+    """emer_lidar_loss vs the reference's DepthLoss("l2") + compute_line_of_sight_loss (loss/base.py:188-271,430-464)
+    restated literally in torch fp64 (including the scalar-mean x per-ray-mask product), values and gradients."""
+    import math
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + S)
+    t = torch.sort(torch.rand(R, S, generator=g) * 90, -1).values
+    w = torch.rand(R, S, generator=g) ** 2 * 0.1
+    gt = torch.rand(R, 1, generator=g) * 100 - 5  # some <= 0, some beyond 80 m
+    depth = torch.rand(R, 1, generator=g) * 100 - 5
+    eps, coef = 3.7, 0.05
+    dd, wd = depth.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    loss = ops.lidar_loss(dd, wd, gt.to(dev), t.to(dev), eps, 80.0, 1.0, coef)
+    (loss * 3.0).backward()
+
+    d64, w64 = depth.double().requires_grad_(True), w.double().requires_grad_(True)
+    g64, t64 = gt.double().squeeze(-1), t.double()
+    valid = (g64 > 0.01) & (g64 < 80.0)
+    norm = lambda v: torch.clamp(v / 80.0, 0.0, 1.0)  # noqa: E731
+    depth_loss = ((norm(d64.squeeze(-1)[valid]) - norm(g64[valid])) ** 2).mean() if bool(valid.any()) else torch.zeros((), dtype=torch.float64)
+    gd = g64.unsqueeze(-1)
+    empty = t64 < gd - eps
+    near = (t64 > gd - eps) & (t64 < gd + eps)
+    sigma = eps / 3
+    delta = (1 / math.sqrt(2 * math.pi * sigma ** 2)) * torch.exp(-((t64 - gd) ** 2) / (2 * sigma ** 2))
+    empty_loss = (w64.square() * empty).sum(-1, keepdim=True).mean()
+    near_loss = ((w64 - delta).square() * near).sum(-1, keepdim=True).mean()
+    sight = ((empty_loss + near_loss) * (g64 > 0)).mean() * coef
+    want = depth_loss + sight
+    (want * 3.0).backward()
+    np.testing.assert_allclose(float(loss), float(want), rtol=2e-5)
+    np.testing.assert_allclose(dd.grad.cpu().numpy(), d64.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), w64.grad.numpy(), rtol=1e-4, atol=1e-7 * float(w64.grad.abs().max()))

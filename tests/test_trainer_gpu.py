@@ -29,3 +29,85 @@ def test_graph_replay_equals_eager(hip_lib):
     assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-5 * max(abs(v) for v in le)
     pe, pg = eager.flat.params, graph.flat.params
     assert float((pe - pg).abs().max()) <= 2e-4 * float(pe.abs().max())
+
+
+def test_render_pixels_loop(hip_lib):
+    """emernerf_amd.video_utils.render_pixels (reference: radiance_fields/video_utils.py:50-468) over a synthetic split:
+    reference key names, image shapes, chunked rendering == one-shot rendering of the same rays."""
+    import numpy as np
+    from emernerf_amd.pixel_source import PixelSource
+    from emernerf_amd.render_utils import render_rays
+    from emernerf_amd.trainer import Trainer, render_config
+    from emernerf_amd.video_utils import render_pixels
+    dev = torch.device("cuda:0")
+    tr = Trainer(kind="dynamic", device=dev, num_samples=32, prop_samples=(32, 16), table_init=0.3, seed=2)
+    src = PixelSource.synthetic(dev, num_imgs=4, height=24, width=40, seed=1)
+    cfg = render_config(32, (32, 16), chunk=256)  # 960 rays per image -> 4 chunks
+    out = render_pixels(cfg, tr.model, tr.estimator, src, proposal_networks=tr.props, compute_metrics=True, vis_indices=[0, 2])
+    for k in ("rgbs", "gt_rgbs", "depths", "opacities", "static_rgbs", "dynamic_rgbs", "static_depths", "dynamic_depths",
+              "static_opacities", "dynamic_opacities", "shadow_reduced_static_rgbs", "shadow_only_static_rgbs", "sky_masks"):
+        assert k in out and len(out[k]) == 2, k
+    assert out["rgbs"][0].shape == (24, 40, 3) and out["depths"][0].shape == (24, 40) and np.isfinite(out["psnr"])
+    assert out["render_rays_per_s"] > 0
+    big = render_config(32, (32, 16), chunk=1 << 20)
+    with torch.no_grad():
+        one = render_rays(radiance_field=tr.model, proposal_estimator=tr.estimator, proposal_networks=tr.props, data_dict=src[2],
+                          cfg=big, return_decomposition=True)
+    np.testing.assert_allclose(out["rgbs"][1], one["rgb"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["depths"][1], one["depth"].squeeze(-1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_lidar_step_runs_and_matches_oracle_gradients(hip_lib, oracle):
+    """Trainer.lidar_step (train_emernerf.py:747-826): density-only render of lidar rays + depth / line-of-sight losses;
+    gradients vs oracle/ref_path.py with the losses restated in torch."""
+    import math
+    import numpy as np
+    from oracle.ref_path import prop_loss
+    from emernerf_amd import fused
+    from emernerf_amd.render_utils import render_rays
+    from emernerf_amd.trainer import Trainer, synthetic_lidar_rays
+    from tests.test_a_metric_shape_gpu import _ref_from_trainer
+    dev = torch.device("cuda:0")
+    R, S = 768, 64
+    tr = Trainer(kind="static", device=dev, num_samples=S, prop_samples=(64, 32), table_init=0.3, seed=4)
+    tr.step_count = 4000  # line of sight active: eps = 6 - 3.5 * 2000 / 23000, coefficient 0.1
+    ref = _ref_from_trainer(oracle, tr)
+    data = synthetic_lidar_rays(R, dev, seed=3)
+    cpu = {k: v.cpu() for k, v in data.items()}
+    g = torch.Generator().manual_seed(1)
+    jit = [torch.rand(R, generator=g) for _ in range(3)]
+    it = iter([j.to(dev) for j in jit])
+    tr.estimator.jitter_fn = lambda n, d: next(it)
+    tr.flat.zero_grad()
+    with fused.grad_sinks(True):
+        res = render_rays(radiance_field=tr.model, proposal_estimator=tr.estimator, proposal_networks=tr.props, data_dict=data,
+                          cfg=tr.rcfg, proposal_requires_grad=False, prefix="lidar_")
+        loss_hip = tr.lidar_losses(res, data, 4000)
+        (loss_hip * 1024.0).backward()
+    tr.flat.finish_grads("main")
+    torch.cuda.synchronize()
+    assert set(res) - {"extras"} == {"depth", "opacity", "median_depth"}
+    r = ref.render_rays(cpu, S, [64, 32], jitters=jit, requires_grad=False, prefix="lidar_")
+    gt = cpu["lidar_ranges"].squeeze(-1)
+    eps = 6.0 + (2.5 - 6.0) / (25000 - 2000) * (4000 - 2000)
+    valid = (gt > 0.01) & (gt < 80)
+    nd = lambda v: torch.clamp(v / 80.0, 0.0, 1.0)  # noqa: E731
+    depth_loss = ((nd(r["depth"].squeeze(-1)[valid]) - nd(gt[valid])) ** 2).mean()
+    w, t = r["extras"]["weights"], r["extras"]["t_vals"]
+    gd = gt[:, None]
+    sigma = eps / 3
+    delta = (1 / math.sqrt(2 * math.pi * sigma ** 2)) * torch.exp(-((t - gd) ** 2) / (2 * sigma ** 2))
+    sight = ((w.square() * (t < gd - eps)).sum(-1, keepdim=True).mean()
+             + ((w - delta).square() * ((t > gd - eps) & (t < gd + eps))).sum(-1, keepdim=True).mean())
+    loss = depth_loss + 0.1 * (sight * (gt > 0)).mean()
+    (loss * 1024.0).backward()
+    np.testing.assert_allclose(float(loss_hip), float(loss), rtol=1e-4)
+    for k in ("xyz_encoder.tcnn_encoding.params", "base_mlp.0.weight", "base_mlp.2.weight"):
+        want = ref.t["model/" + k].grad
+        got = dict(tr.model.named_parameters())[k].grad.cpu()
+        assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max()), k
+    # and the whole step runs (second optimizer step of an iteration)
+    p0 = tr.flat.params.clone()
+    tr.estimator.jitter_fn = lambda n, d: torch.rand(n, device=d)
+    out = tr.lidar_step(synthetic_lidar_rays(R, dev, seed=5))
+    assert torch.isfinite(out["loss"]) and not torch.equal(p0, tr.flat.params)
