@@ -56,6 +56,8 @@ SIGNATURES = {
     "emer_scale": [_P, _P, c_float, _P, c_int64, _P],
     "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
+    "emer_blend_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P],
+    "emer_blend_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_ray_epilogue_fwd": [_P, _P, _P, c_int64, _P, _P, _P, _P, _P],
     "emer_ray_epilogue_bwd": [_P, _P, _P, _P, _P, c_int64, _P, _P, _P],
     "emer_pixel_loss_fwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],

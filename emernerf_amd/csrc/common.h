@@ -41,7 +41,8 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // hipGraph (core.hip).
 int reserve_lds(const void *kernel, size_t bytes, const char *what);
 
-// ---- wave-level scans (DPP-backed __shfl; no LDS) ------------------------------------------
+// ---- wave-level scans on __shfl (ds_bpermute: the LDS crossbar, no LDS memory).  The grid kernels use DPP-based scans
+// instead (csrc/hashgrid.hip); these serve the per-ray kernels, where a scan is a small part of the work. ----------------
 __device__ __forceinline__ float wave_inclusive_sum(float v, int lane) {
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {

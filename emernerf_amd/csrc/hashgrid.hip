@@ -501,31 +501,29 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 
 
 // ------------------------------------------------------- backward (params), owner-computes
-// Measured on MI355X (tools/atomic_probe.hip): L2 float atomics retire ~21 G cache-line requests/s
-// no matter the table size, dtype (f32 = pk_f16 = f64) or scope, so the tcnn-style global scatter
-// (2^D * L * F * N = 268 M requests at the metric shape) costs 13-20 ms.  LDS atomics are an order
-// of magnitude faster and need no L2 round trip, so the scatter is turned inside out:
-//   * LDS fp32 atomics are themselves slow on gfx950 (tools/lds_probe.hip: ds_add_f32 0.37 lane-ops/clk/CU
-//     regardless of conflicts, ds_add_f64 2.6, ds_add_u32 3.6), so slices accumulate in DOUBLE -- 7x
-//     faster and more accurate than the fp32 atomics of the upstream kernel;
-//   * the table of a level is cut into <= 64 slices that fit the CU's LDS (T = 2^19, F = 2: 64 slices
-//     x 8192 entries x 2 x 8 B = 128 KiB each).  Hashed levels are cut by the HIGH index
-//     bits (the hash already spreads samples evenly); dense levels are cut by the LOW index bits
-//     (interleaved), otherwise a slice is a z-slab and a flat driving scene lands in two or three
-//     of them;
-//   * the FORWARD kernel, which has every sample's cell in registers anyway, also emits a 64-bit
-//     slice-membership mask per (level, sample): bit s is set iff one of the 2^D corners lives in
-//     slice s.  8 B per (level, sample), level-major, coalesced;
-//   * a backward workgroup OWNS one (level, slice).  It streams the masks of its level (coalesced,
-//     shared by the XCD's 32 CUs through L2): test one bit -> wave-private compaction of the hit
-//     sample ids into LDS (ballot + popcount prefix: no atomics, no workgroup barrier).  Whenever a
-//     wave has 64 hits queued it reprocesses them on DENSE lanes: recompute cell + weights,
-//     ds_add_f32 the corners that fall in the slice;
-//   * at the end the slice is written with plain coalesced stores -- every table entry is written
-//     by exactly one workgroup: no global atomics, and the gradient buffer needs no memset.
-// Work items are dealt XCD-aware (block b -> XCD b % 8): an XCD finishes all slices of one level
-// before starting its next level, so the streamed inputs of that level stay L2-resident.
-// Placement only affects speed, never results.
+// Measured on MI355X (tools/atomic_probe.hip): L2 float atomics retire ~21 G cache-line requests/s no matter the table
+// size, dtype (f32 = pk_f16 = f64) or scope, so the tcnn-style global scatter (2^D * L * F * N = 268 M requests at the
+// metric shape) costs 13-20 ms.  The scatter is turned inside out instead (DESIGN.md section 4.1 has the full account):
+//   * a level's table is cut into <= 64 contiguous slices that fit a CU's LDS as DOUBLE accumulators (T = 2^19, F = 2:
+//     64 x 8192 entries x 16 B = 128 KiB).  gfx950's ds_add_f32 runs at 0.37 lane-ops/clk/CU, ds_add_f64 at 2.6
+//     (tools/lds_probe.hip), so double is both faster and more accurate than the upstream fp32 atomics;
+//   * the FORWARD kernel emits, per (level, slice), a bitmap with ONE bit per sample (bit-transposed across the wave,
+//     4 words per row and workgroup through LDS): a slice owner reads 128 KiB of bitmap instead of touching every sample;
+//   * a persistent workgroup (1024 threads, one per CU) OWNS one (level, slice[, sample range]) work item at a time.  Each
+//     lane holds one 64-sample bitmap word; the hits of a wave's 64 words are compacted analytically (DPP scans, ranks
+//     through a 4096-bit head vector, LUT-assisted select of the k-th set bit) so that lane l of chunk c materialises
+//     hit 64 c + l directly -- dense lanes, sample order, no queue, no barrier in the loop;
+//   * the hits are reprocessed six chunks at a time with all x / dout gathers in flight (32-bit offsets from scalar
+//     bases): recompute cell + weights, then ds_add_f64 the corners that live in the slice.  Hashed power-of-two levels
+//     add one x-pair per hit (a rare second pair goes through a small per-wave queue); dense coarse levels reduce runs of
+//     equal cells with a segmented DPP scan first, so one lane per run touches the LDS;
+//   * at the end the slice is written with plain coalesced stores (every entry of a hashed level is owned by exactly one
+//     workgroup: no global atomics, no memset of the 49 MB gradient); dense levels, whose sample stream is also cut in
+//     ranges for balance, merge their non-zero entries into a pre-zeroed level with L2 atomics.
+// Work items are consumed through per-XCD atomic cursors in ONE global order (longest items first, blocks of 32 dealt to
+// the XCDs round-robin); a workgroup whose list is empty steals from the others.  Placement only affects speed.
+// Determinism: the accumulation order inside a slice depends on wave scheduling, but sums are formed in double and rounded
+// to fp32 once, so two runs agree to the last ulp or two (tests/test_a_metric_shape_gpu.py: <= 1e-6 relative).
 #ifdef EMER_SLICED_TRACE
 // Debug build only (tools/trace_sliced.py): per-work-item timeline of the owner-computes backward.
 // trace[0] = item counter; record i at trace[8 + 4 i] = {level | slice << 8 | range << 24 | block << 40, start, end, hits}

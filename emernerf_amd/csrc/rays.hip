@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t race_key(uint64_t seed, int64_t i, float w) 
     if (!(w > 0.0f)) return 0x7F800000u;
     const float u = ((float)(rnd32(seed, (uint64_t)i) >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
     const float key = -logf(u) / w;
-    return __float_as_uint(key < 0.0f ? 0.0f : key);  // (-log(1) = -0 -> 0)
+    return __float_as_uint(key) & 0x7FFFFFFFu;  // u = 1 gives -log(1) / w = -0.0: the sign bit must not reach the radix digits
 }
 
 // state (device): [0] prefix value of the bits fixed so far, [1] winners still to be found inside the prefix bucket,

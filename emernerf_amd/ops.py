@@ -655,3 +655,49 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
     with torch.cuda.device(params.device):
         _lib.call("emer_adam_step", _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), float(lr),
                   float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), int(step), _stream(params))
+
+
+# ------------------------------------------------------------------ static / dynamic / shadow blend + accumulation
+class _BlendAccumulateFn(torch.autograd.Function):
+    """(acc_rgb [R,3], acc_shadow_sq [R,1] | None) of rendering's decomposed colour path (render_utils.py:125-175)."""
+
+    @staticmethod
+    def forward(ctx, weights, density, static_density, dynamic_density, static_rgb, dynamic_rgb, shadow_ratio):
+        ctx.set_materialize_grads(False)
+        w, sg, ss, sd = _f32c(weights), _f32c(density), _f32c(static_density), _f32c(dynamic_density)
+        rs, rd = _f32c(static_rgb), _f32c(dynamic_rgb)
+        sh = None if shadow_ratio is None else _f32c(shadow_ratio).reshape(w.shape)
+        R, S = w.shape
+        with torch.cuda.device(w.device):
+            acc = torch.empty((R, 3), device=w.device, dtype=torch.float32)
+            acs = torch.empty((R, 1), device=w.device, dtype=torch.float32) if sh is not None else None
+            _lib.call("emer_blend_accumulate_fwd", _ptr(w), _ptr(sg), _ptr(ss), _ptr(sd), _ptr(rs), _ptr(rd), _ptr(sh), R, S, _ptr(acc),
+                      _ptr(acs), _stream(w))
+        ctx.save_for_backward(w, sg, ss, sd, rs, rd, sh)
+        ctx.sh_shape = None if shadow_ratio is None else shadow_ratio.shape
+        return acc, acs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sh):
+        w, sg, ss, sd, rs, rd, sh = ctx.saved_tensors
+        R, S = w.shape
+        if g_rgb is None and g_sh is None:
+            return (None,) * 7
+        gr = None if g_rgb is None else _f32c(g_rgb)
+        gs = None if g_sh is None else _f32c(g_sh).view(-1)
+        need = ctx.needs_input_grad
+        with torch.cuda.device(w.device):
+            mk = lambda t, on: torch.empty_like(t) if on else None  # noqa: E731
+            dw, dsg, dss, dsd = mk(w, need[0]), mk(sg, need[1]), mk(ss, need[2]), mk(sd, need[3])
+            drs, drd = mk(rs, need[4]), mk(rd, need[5])
+            dsh = mk(sh, need[6]) if sh is not None else None
+            _lib.call("emer_blend_accumulate_bwd", _ptr(w), _ptr(sg), _ptr(ss), _ptr(sd), _ptr(rs), _ptr(rd), _ptr(sh), _ptr(gr), _ptr(gs), R, S,
+                      _ptr(dw), _ptr(dsg), _ptr(dss), _ptr(dsd), _ptr(drs), _ptr(drd), _ptr(dsh), _stream(w))
+        return dw, dsg, dss, dsd, drs, drd, (None if dsh is None else dsh.view(ctx.sh_shape))
+
+
+def blend_accumulate(weights: Tensor, density: Tensor, static_density: Tensor, dynamic_density: Tensor, static_rgb: Tensor,
+                     dynamic_rgb: Tensor, shadow_ratio: Optional[Tensor] = None):
+    """sum_s w (sigma_s / (sigma + 1e-6) rgb_s (1 - shadow) + sigma_d / (sigma + 1e-6) rgb_d) and sum_s w shadow^2."""
+    _check_cuda(weights, density, static_density, dynamic_density, static_rgb, dynamic_rgb, shadow_ratio)
+    return _BlendAccumulateFn.apply(weights, density, static_density, dynamic_density, static_rgb, dynamic_rgb, shadow_ratio)

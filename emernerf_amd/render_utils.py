@@ -49,8 +49,6 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
     if "static_density" in results and "dynamic_density" in results:  # :125-155
         extras["static_density"] = results["static_density"]
         extras["dynamic_density"] = results["dynamic_density"]
-        static_ratio = results["static_density"] / (results["density"] + 1e-6)
-        dynamic_ratio = results["dynamic_density"] / (results["density"] + 1e-6)
         if return_decomposition:
             static_weights, static_opacities, static_depths = render_weights_opacity_depth_from_density(
                 t_starts, t_ends, results["static_density"])
@@ -63,13 +61,14 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
     if "rgb" in results:  # :158-159
         acc_rgb = accumulate_along_rays(weights, values=results["rgb"])
     elif "static_rgb" in results and "dynamic_rgb" in results:  # :160-214
-        shadow_ratio = 0.0
-        if "shadow_ratio" in results:
-            shadow_ratio = results["shadow_ratio"]
-            results_dict["shadow_ratio"] = accumulate_along_rays(weights, values=shadow_ratio.square())
-        rgb = static_ratio[..., None] * results["static_rgb"] * (1 - shadow_ratio) \
-            + dynamic_ratio[..., None] * results["dynamic_rgb"]
-        acc_rgb = accumulate_along_rays(weights, values=rgb)
+        # ratios, shadowed blend and both accumulations in one kernel each way (:131-136,165-175)
+        shadow_ratio = results.get("shadow_ratio", 0.0)
+        acc_rgb, acc_shadow_sq = ops.blend_accumulate(weights, results["density"].reshape(weights.shape),
+                                                      results["static_density"].reshape(weights.shape),
+                                                      results["dynamic_density"].reshape(weights.shape), results["static_rgb"],
+                                                      results["dynamic_rgb"], results.get("shadow_ratio"))
+        if acc_shadow_sq is not None:
+            results_dict["shadow_ratio"] = acc_shadow_sq
         if return_decomposition:
             results_dict["static_rgb"] = accumulate_along_rays(static_weights, values=results["static_rgb"])
             if "shadow_ratio" in results:
@@ -105,6 +104,8 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
         results_dict["dino_feat"] = accumulate_along_rays(weights, values=results["dino_feat"])
         _finish_dino()
     elif "static_dino_feat" in results and "dynamic_dino_feat" in results:  # :247-282
+        static_ratio = results["static_density"] / (results["density"] + 1e-6)  # (:131-136; the colour path has them fused)
+        dynamic_ratio = results["dynamic_density"] / (results["density"] + 1e-6)
         dino_feat = static_ratio[..., None] * results["static_dino_feat"] + dynamic_ratio[..., None] * results["dynamic_dino_feat"]
         results_dict["dino_feat"] = accumulate_along_rays(weights, values=dino_feat)
         _finish_dino()

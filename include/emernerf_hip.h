@@ -200,6 +200,22 @@ int emer_render_weights_bwd(const float *t_starts, const float *t_ends, const fl
                             const float *d_weights, const float *d_trans, const float *d_alphas,
                             const float *d_ray_stats, int64_t n_rays, int32_t n_samples, float *d_sigma,
                             void *stream);
+/* Static / dynamic / shadow colour blend + accumulation of `rendering` (radiance_fields/render_utils.py:125-175):
+ *   a = static_density / (density + 1e-6), b = dynamic_density / (density + 1e-6),
+ *   acc_rgb[r] = sum_s w (a rgb_s (1 - shadow) + b rgb_d),   acc_shadow_sq[r] = sum_s w shadow^2
+ * weights / densities / shadow_ratio [R,S] (shadow_ratio may be NULL = 0), rgb [R,S,3]; acc_rgb [R,3], acc_shadow_sq [R]
+ * (may be NULL). */
+int emer_blend_accumulate_fwd(const float *weights, const float *density, const float *static_density,
+                              const float *dynamic_density, const float *static_rgb, const float *dynamic_rgb,
+                              const float *shadow_ratio, int64_t n_rays, int32_t n_samples, float *acc_rgb,
+                              float *acc_shadow_sq, void *stream);
+/* Gradients of the above w.r.t. every input (each output pointer may be NULL); d_acc_* may be NULL (zero). */
+int emer_blend_accumulate_bwd(const float *weights, const float *density, const float *static_density,
+                              const float *dynamic_density, const float *static_rgb, const float *dynamic_rgb,
+                              const float *shadow_ratio, const float *d_acc_rgb, const float *d_acc_shadow_sq,
+                              int64_t n_rays, int32_t n_samples, float *d_weights, float *d_density,
+                              float *d_static_density, float *d_dynamic_density, float *d_static_rgb,
+                              float *d_dynamic_rgb, float *d_shadow_ratio, void *stream);
 /* Per-ray epilogue of `rendering` (radiance_fields/render_utils.py:102-105,217-226):
  *   opacity = clamp(sum w, 1e-6, 1); depth = (sum w*mid) / opacity; median_depth = ray_stats[:,2];
  *   rgb = acc_rgb + rgb_sky * (1 - opacity)   (rgb_sky NULL: rgb = acc_rgb; rgb NULL: geometry only, lidar rays).

@@ -25,7 +25,8 @@ def _free_port() -> int:
 def _make(world_size):
     from emernerf_amd.trainer import Trainer
     tr = Trainer(kind="static", device="cuda:0", num_samples=S, prop_samples=(32, 16), table_init=0.3, seed=SEED, world_size=world_size)
-    tr.step_count = 7  # a step that also trains the proposal nets (the schedule fires on every early step)
+    tr.requires_grad_fn(0)  # (the schedule never fires on its very first call)
+    tr.step_count = 7       # ... and on every early step after it: this step also trains the proposal nets
     return tr
 
 
