@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libemernerf_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -40,6 +41,18 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // every launch -- it is not a stream operation, so it must not run while the launch stream is being captured into a
 // hipGraph (core.hip).
 int reserve_lds(const void *kernel, size_t bytes, const char *what);
+
+// Measurement hook (emer_profile_next): a pair of caller-owned HIP events that the NEXT instrumented launch of this thread
+// records immediately before / after its kernel (hipExtLaunchKernelGGL), so bench.py times the kernel itself and not
+// the host's enqueue latency around it.  One-shot; both null when not armed.
+struct ProfileEvents { hipEvent_t start, stop; };
+ProfileEvents take_profile_events();
+// plain launch unless a measurement armed the events (the extended launch is kept out of hipGraph captures)
+#define EMER_LAUNCH_PROFILED(ev, kern, grid, block, lds, st, ...)                                                  \
+    do {                                                                                                           \
+        if ((ev).start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, (ev).start, (ev).stop, 0, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                          \
+    } while (0)
 
 // ---- wave-level scans on __shfl (ds_bpermute: the LDS crossbar, no LDS memory).  The grid kernels use DPP-based scans
 // instead (csrc/hashgrid.hip); these serve the per-ray kernels, where a scan is a small part of the work. ----------------

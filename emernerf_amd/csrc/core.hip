@@ -31,7 +31,19 @@ int reserve_lds(const void *kernel, size_t bytes, const char *what) {
     have = bytes;
     return EMER_OK;
 }
+static thread_local ProfileEvents g_profile = {nullptr, nullptr};
+ProfileEvents take_profile_events() {
+    const ProfileEvents e = g_profile;
+    g_profile = ProfileEvents{nullptr, nullptr};
+    return e;
+}
+void arm_profile_events(hipEvent_t a, hipEvent_t b) { g_profile = ProfileEvents{a, b}; }
 }  // namespace emer
+
+extern "C" int emer_profile_next(void *start_event, void *stop_event) {
+    emer::arm_profile_events(reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event));
+    return EMER_OK;
+}
 
 extern "C" const char *emer_last_error(void) { return emer::g_err; }
 extern "C" int emer_version(void) { return 1; }

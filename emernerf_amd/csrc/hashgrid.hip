@@ -1194,11 +1194,12 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     const SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice bitmaps requested but a level needs more than 64 x 64 LDS slices");
+    const ProfileEvents ev = take_profile_events();  // (null unless emer_profile_next armed them)
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
         if (param_dtype == EMER_F32)
-            hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+            EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                 (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
         else
             hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
                                (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
@@ -1293,7 +1294,8 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
         if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
-        hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
+        const ProfileEvents ev = take_profile_events();
+        EMER_LAUNCH_PROFILED(ev, kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
                            slice_masks, work_ctr, grad, n);
         return check_launch("hashgrid_bwd_params_sliced");
     });

@@ -44,6 +44,7 @@ def model_config(kind: str = "static", num_train_timesteps: int = 50, num_cams: 
              rgb head 113->64->[64+113]->64->3, sky head, per-image appearance embedding.
     dynamic (configs[2]): configs/default_dynamic.yaml on top of default_config.yaml:60-105.
     flow    (configs[3]): configs/default_flow.yaml.
+    feature (configs[4]): flow + enable_feature_head + enable_learnable_pe (default_config.yaml:19,93-94: 64-d features).
     """
     if kind == "static":
         xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=16, n_features_per_level=2, base_resolution=16,
@@ -51,16 +52,17 @@ def model_config(kind: str = "static", num_train_timesteps: int = 50, num_cams: 
     else:
         xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=10, n_features_per_level=4, base_resolution=16,
                    max_resolution=8192, log2_hashmap_size=20)
-    dyn = kind in ("dynamic", "flow")
+    dyn = kind in ("dynamic", "flow", "feature")
+    feat = kind == "feature"  # BASELINE configs[4]: the flow model + DINO feature head (64-d after PCA) + learnable PE map
     return ns(
         xyz_encoder=xyz,
         dynamic_xyz_encoder=dict(type="HashEncoder", n_input_dims=4, n_levels=10, n_features_per_level=4, base_resolution=32,
                                  max_resolution=8192, log2_hashmap_size=18),
         neck=dict(base_mlp_layer_width=64, geometry_feature_dim=64, semantic_feature_dim=64),
         head=dict(head_mlp_layer_width=64, enable_cam_embedding=False, enable_img_embedding=True, appearance_embedding_dim=16,
-                  enable_sky_head=True, enable_feature_head=False, feature_embedding_dim=64, feature_mlp_layer_width=64,
+                  enable_sky_head=True, enable_feature_head=feat, feature_embedding_dim=64, feature_mlp_layer_width=64,
                   enable_learnable_pe=True, enable_dynamic_branch=dyn, enable_shadow_head=dyn,
-                  interpolate_xyz_encoding=True, enable_temporal_interpolation=False, enable_flow_branch=kind == "flow"),
+                  interpolate_xyz_encoding=True, enable_temporal_interpolation=False, enable_flow_branch=kind in ("flow", "feature")),
         unbounded=True, num_cams=num_cams, num_train_timesteps=num_train_timesteps)
 
 
@@ -76,7 +78,7 @@ PROP_KW = [dict(n_levels=8, max_resolution=512, log2_hashmap_size=20, n_features
            dict(n_levels=8, max_resolution=2048, log2_hashmap_size=20, n_features_per_level=1)]
 
 
-def synthetic_rays(R: int, device, seed: int = 0, n_timesteps: int = 50, num_cams: int = 1) -> Dict[str, Tensor]:
+def synthetic_rays(R: int, device, seed: int = 0, n_timesteps: int = 50, num_cams: int = 1, feature_dim: int = 0) -> Dict[str, Tensor]:
     """Seeded synthetic ray batch of SURVEY.md section 8d / BASELINE.md 2.2 (no dataset on the box)."""
     g = torch.Generator().manual_seed(seed)
     o = torch.stack([torch.rand(R, generator=g) * 60, torch.rand(R, generator=g) * 4 - 2, torch.rand(R, generator=g) + 1.5], -1)
@@ -86,6 +88,8 @@ def synthetic_rays(R: int, device, seed: int = 0, n_timesteps: int = 50, num_cam
             "normed_timestamps": torch.randint(0, n_timesteps, (R,), generator=g).float() / (n_timesteps - 1),
             "img_idx": img_idx, "cam_idx": img_idx % num_cams, "pixels": torch.rand(R, 3, generator=g),
             "sky_masks": (torch.rand(R, generator=g) < 0.15).float()}
+    if feature_dim:
+        data["features"] = torch.rand(R, feature_dim, generator=g)
     return {k: v.to(device) for k, v in data.items()}
 
 
@@ -214,7 +218,7 @@ class Trainer:
                  world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False):
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial parameters on every rank
-        self.cfg = model_config(kind)
+        self.cfg = model_config(kind, num_cams=3 if kind == "feature" else 1)
         self.rcfg = render_config(num_samples, prop_samples)
         self.model: RadianceField = build_radiance_field_from_cfg(self.cfg, verbose=False)
         self.model.set_aabb(AABB)
@@ -268,6 +272,8 @@ class Trainer:
             loss = loss + 0.01 * results["extras"]["dynamic_density"].mean()
         if "shadow_ratio" in results:
             loss = loss + 0.01 * results["shadow_ratio"].mean()
+        if "dino_feat" in results and "features" in data:  # feature supervision: l2, coefficient 0.5 (default_config.yaml:141-143)
+            loss = loss + 0.5 * F.mse_loss(results["dino_feat"], data["features"])
         if "forward_flow" in results["extras"]:
             ex = results["extras"]
             loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2

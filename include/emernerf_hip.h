@@ -46,6 +46,9 @@ extern "C" {
 #define EMER_STOT_UNIFORM_LINDISP_0 5
 
 const char *emer_last_error(void);
+/* Measurement hook: the next emer_hashgrid_fwd / emer_hashgrid_bwd_params_sliced call of this thread records the two
+ * caller-owned HIP events (hipEvent_t) immediately around its main kernel.  One-shot. */
+int emer_profile_next(void *start_event, void *stop_event);
 int emer_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -111,3 +111,17 @@ def test_lidar_step_runs_and_matches_oracle_gradients(hip_lib, oracle):
     tr.estimator.jitter_fn = lambda n, d: torch.rand(n, device=d)
     out = tr.lidar_step(synthetic_lidar_rays(R, dev, seed=5))
     assert torch.isfinite(out["loss"]) and not torch.equal(p0, tr.flat.params)
+
+
+@pytest.mark.parametrize("kind", ["dynamic", "flow", "feature"])
+def test_other_configs_step(hip_lib, kind):
+    """BASELINE configs[2..4] take optimizer steps on the fused path (dynamic + shadow, flow, flow + feature head + PE)."""
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = torch.device("cuda:0")
+    tr = Trainer(kind=kind, device=dev, num_samples=32, prop_samples=(32, 16), table_init=0.2, seed=1)
+    kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
+    data = synthetic_rays(512, dev, seed=3, **kw)
+    l0 = float(tr.train_step(data)["loss"])
+    for _ in range(6):
+        l1 = float(tr.train_step(data)["loss"])
+    assert torch.isfinite(torch.tensor([l0, l1])).all() and l1 < l0
