@@ -703,8 +703,15 @@ __device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], c
     if (has) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
+#if EMER_ABL & 4
+            acc[(size_t)l0 * F + f] = (double)(wa * go[f]);
+            acc[(size_t)l1 * F + f] = (double)(wb * go[f]);
+#elif EMER_ABL & 8
+            if (wa * go[f] == 12345.0f && wb * go[f] == 54321.0f) acc[(size_t)(l0 ^ l1) * F + f] = 1.0;
+#else
             atomicAdd(acc + (size_t)l0 * F + f, (double)(wa * go[f]));  // ds_add_f64
             atomicAdd(acc + (size_t)l1 * F + f, (double)(wb * go[f]));
+#endif
         }
     }
 }
@@ -737,6 +744,34 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
     while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go, match, local_mask);
 }
 
+#ifndef EMER_PIPELINE
+#define EMER_PIPELINE 1
+#endif
+// Timing-only ablation builds (tools/ab_grid.sh; results are WRONG, never in the product library): bit 0 = gathers from a
+// 16 K-sample window (L2 hits), bit 1 = gathers from a 1 K-sample window (L1 hits), bit 2 = plain LDS stores instead of
+// ds_add_f64, bit 3 = no LDS accumulation at all, bit 4 = hit -> sample mapping without the compaction look-ups.
+#ifndef EMER_ABL
+#define EMER_ABL 0
+#endif
+// chunks (of 64 hits) per register set of the software-pipelined drain: two sets are live, D + F + 1 registers per chunk
+#ifndef EMER_PIPE_K
+#define EMER_PIPE_K 2
+#endif
+#ifndef EMER_SKIP_DEAD
+#define EMER_SKIP_DEAD 1
+#endif
+template <int D, int F> constexpr int kPipeK() {
+    constexpr int per = D + F + 1, k = 28 / per;  // register budget of one set
+    return k > EMER_PIPE_K ? EMER_PIPE_K : (k < 1 ? 1 : k);
+}
+// one group of hits: sample ids, validity and the gathered x / dout values of up to K chunks of 64 hits
+template <int D, int F, int K>
+struct HitGroup {
+    float xs[K][D], go[K][F];
+    uint32_t ns[K];      // sample ids (the second-pair queue stores them)
+    bool vld[K];
+    uint32_t take;       // hits in the group (wave-uniform)
+};
 constexpr int kScanWords = 64 + 64 + 32 + 32;  // per-wave LDS scratch of the compaction, in u64: words, head bit-vector, offsets, head bases
 
 template <int D, int F>
@@ -796,9 +831,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const unsigned long long trace_t0 = wall_clock64();
     unsigned long long trace_hits = 0;
 #endif
-    const bool dense = !li.hashed;
-    const bool consecutive = dense || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
-    const bool pairable = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
+    const bool dense_rt = !li.hashed;
+    const bool consecutive = dense_rt || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
+    const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
     const uint32_t first = slice << shift;
     const uint32_t n_local = ((li.size - first) < (1u << shift)) ? (li.size - first) : (1u << shift);
@@ -821,8 +856,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // second-pair queue (pairable levels): wave-private ring of kPairQueue words behind the compaction scratch
     uint32_t *Qw = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
                    + (size_t)wave * kPairQueue;
-    uint32_t q_head = 0, q_len = 0;
-    const bool use_queue = EMER_PAIR_QUEUE && pairable && N <= (1ll << kPairQueueShift) && (1u << (D - 1)) <= 8u;
+    const bool use_queue = EMER_PAIR_QUEUE && pairable_rt && N <= (1ll << kPairQueueShift) && (1u << (D - 1)) <= 8u;
     const uint32_t slice_bits = (li.size - 1u) & ~((1u << shift) - 1u), slice_want = first, local_mask = (1u << shift) - 1u;
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
@@ -841,199 +875,286 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // already in sample order (which the dense levels' run reduction needs).
     // Word of a trip held by this lane: hashed = thread id; dense = interleaved over the waves so that short ranges
     // still occupy all 16 waves (lane t of wave w holds word t * 16 + w; words of a wave stay in increasing order).
+    //
+    // The whole hit stream of the item is instantiated once per KIND of level (0 dense, 1 hashed with x-pairs that share a
+    // slice, 2 any other hashed level): one consume path per copy keeps the software-pipelined loop below small enough for
+    // the register allocator to leave the in-flight gathers alone (with all three paths in one loop body it split their
+    // live ranges with copies placed right behind the loads, i.e. it waited for them at once).
+    auto run_item = [&](auto kind_c) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr bool dense = KIND == 0, pairable = KIND == 1;
+    uint32_t q_head = 0, q_len = 0;
     const int64_t my_word = dense ? (int64_t)lane * kSliceWaves + wave : (int64_t)threadIdx.x;
     const int64_t wave_word0 = dense ? wave : wave * 64;
     const uint32_t lane_word_shift = dense ? 4u : 0u;  // log2 of the word stride between neighbouring lanes (kSliceWaves = 16)
     static_assert(kSliceWaves == 16, "lane_word_shift assumes 16 waves");
+    // ---- the hit stream of this item, as GROUPS of up to KG chunks of 64 hits --------------------------------------
+    // next_trip() compacts the next non-empty 1024-word trip into the wave's scratch (hv / hexcl / total / n_chunks);
+    // issue(G) materialises the next KG chunks of the current trip -- sample ids, then the x / dout gathers, left IN
+    // FLIGHT in G's registers -- and consume(G) does the arithmetic and the LDS adds.  With EMER_PIPELINE the two are
+    // software-pipelined over two register sets: the gathers of group g + 1 (and the compaction of its trip) are issued
+    // before group g is consumed, so a wave overlaps its own gather latency instead of relying on the three other
+    // waves of its SIMD (the slice fills the LDS: one 1024-thread workgroup per CU, four waves per SIMD).
+    constexpr int KG = EMER_PIPELINE ? kPipeK<D, F>() : kDrainK;
+    int64_t wbase = w_begin;          // next trip to compact
+    uint32_t trip_w0 = 0;             // first word (32-bit) of the trip held in the scratch
+    uint32_t total = 0, n_chunks = 0, c0 = 0, hexcl = 0;
+    uint64_t hv = 0;
     uint64_t pre = (w_begin + my_word < w_end) ? bm[w_begin + my_word] : 0ull;
-    for (int64_t wbase = w_begin; wbase < w_end; wbase += kSliceThreads) {
-        const uint64_t wv = pre;
-        pre = (wbase + kSliceThreads + my_word < w_end) ? bm[wbase + kSliceThreads + my_word] : 0ull;
-        const uint32_t p = (uint32_t)__popcll(wv);
-        const uint32_t incl = wave_inclusive_sum_u32(p, lane);
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, kWave);
-        if (total == 0u) continue;
+    auto next_trip = [&]() __attribute__((always_inline)) -> bool {
+        while (wbase < w_end) {
+            const uint64_t wv = pre;
+            trip_w0 = (uint32_t)wbase;
+            wbase += kSliceThreads;
+            pre = (wbase + my_word < w_end) ? bm[wbase + my_word] : 0ull;
+            const uint32_t p = (uint32_t)__popcll(wv);
+            const uint32_t incl = wave_inclusive_sum_u32(p, lane);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);  // (an SGPR: everything derived from it -- chunk counts, group sizes -- stays scalar)
+            if (total == 0u) continue;
 #ifdef EMER_SLICED_TRACE
-        if (lane == 0) trace_hits += total;
+            if (lane == 0) trace_hits += total;
 #endif
-        const uint32_t excl = incl - p;
-        const unsigned long long nzm = __ballot(p != 0u);
-        Hv[lane] = 0ull;
-        if (p != 0u) {
-            const uint32_t rk = (uint32_t)__popcll(nzm & lt_mask);
-            Wl[rk] = wv;
-            El[rk] = excl | ((uint32_t)lane << 16);
-            atomicOr(Hv + (excl >> 6), 1ull << (excl & 63u));  // ds_or_b64
+            const uint32_t excl = incl - p;
+            const unsigned long long nzm = __ballot(p != 0u);
+            Hv[lane] = 0ull;
+            if (p != 0u) {
+                const uint32_t rk = (uint32_t)__popcll(nzm & lt_mask);
+                Wl[rk] = wv;
+                El[rk] = excl | ((uint32_t)lane << 16);
+                atomicOr(Hv + (excl >> 6), 1ull << (excl & 63u));  // ds_or_b64
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the packed words / head bits of all lanes are visible
+            hv = Hv[lane];
+            const uint32_t hp = (uint32_t)__popcll(hv);
+            hexcl = wave_inclusive_sum_u32(hp, lane) - hp;  // head bits before this lane's head word
+            if (!consecutive) { Hx[lane] = hexcl; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+            n_chunks = (total + 63u) >> 6;
+            c0 = 0;
+            return true;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the packed words / head bits of all lanes are visible
-        const uint64_t hv = Hv[lane];
-        const uint32_t hp = (uint32_t)__popcll(hv);
-        const uint32_t hexcl = wave_inclusive_sum_u32(hp, lane) - hp;  // head bits before this lane's head word
-        if (!consecutive) { Hx[lane] = hexcl; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-        const uint32_t n_chunks = (total + 63u) >> 6;
-        for (uint32_t c0 = 0; c0 < n_chunks; c0 += kDrainK) {
-            const uint32_t take = (total - 64u * c0) < 64u * kDrainK ? (total - 64u * c0) : 64u * kDrainK;
-            float xs[kDrainK][D], go[kDrainK][F];
-            bool vld[kDrainK];
-            uint32_t ns[kDrainK];  // sample ids (the second-pair queue stores them)
+        return false;
+    };
+    auto issue = [&](HitGroup<D, F, KG> &G) __attribute__((always_inline)) -> bool {
+        bool have = true;
+        if (c0 >= n_chunks) {  // wave-uniform
+            have = next_trip();
+            if (!have) { total = 0u; n_chunks = 0u; c0 = 0u; }  // stream exhausted: the group below is empty (dummy gathers of sample 0)
+        }
+        // (the gathers below are issued unconditionally, in straight-line code: a group that is merged with another
+        // definition of its registers makes the compiler copy the loaded values -- and wait for them -- right here)
+        G.take = (total - 64u * c0) < 64u * KG ? (total - 64u * c0) : 64u * KG;
+        const uint32_t last_hit = total ? total - 1u : 0u, last_chunk = n_chunks ? n_chunks - 1u : 0u;
 #pragma unroll
-            for (int k = 0; k < kDrainK; ++k) {
-                uint32_t c = c0 + (uint32_t)k;
-                c = c < n_chunks ? c : n_chunks - 1u;                               // wave-uniform
-                // Lane l takes hit 64 c + l (sample order) on dense levels -- the run reduction needs it -- and on FINE hashed
-                // levels, where neighbouring hits share x / dout cache lines.  On COARSE hashed levels consecutive samples
-                // of a ray share cells and would serialise on the same LDS address: there lane l takes hit l * n_chunks +
-                // c, so the lanes of one instruction work on hits far apart (different rays).
-                uint32_t j = consecutive ? 64u * c + (uint32_t)lane : (uint32_t)lane * n_chunks + c;
-                const bool in_range = j < total;
-                j = in_range ? j : total - 1u;                                       // out-of-range lanes repeat the last hit (masked below)
-                uint64_t hr;
-                uint32_t hx;
-                if (consecutive) {
-                    const uint32_t hr_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, (int)c);
-                    const uint32_t hr_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), (int)c);
-                    hx = (uint32_t)__builtin_amdgcn_readlane((int)hexcl, (int)c);
-                    hr = ((uint64_t)hr_hi << 32) | hr_lo;
-                } else {
-                    hr = Hv[j >> 6];
-                    hx = Hx[j >> 6];
-                }
-                const uint64_t upto = ((j & 63u) == 63u) ? ~0ull : ((2ull << (j & 63u)) - 1ull);
-                const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
-                const uint64_t wq = Wl[rank];
-                const uint32_t el = El[rank];
+        for (int k = 0; k < KG; ++k) {
+            uint32_t c = c0 + (uint32_t)k;
+            const bool live = c < n_chunks;                                          // wave-uniform
+            c = live ? c : last_chunk;
+            // Lane l takes hit 64 c + l (sample order) on dense levels -- the run reduction needs it -- and on FINE hashed
+            // levels, where neighbouring hits share x / dout cache lines.  On COARSE hashed levels consecutive samples
+            // of a ray share cells and would serialise on the same LDS address: there lane l takes hit l * n_chunks +
+            // c, so the lanes of one instruction work on hits far apart (different rays).
+            uint32_t n = 0u;               // chunks past the end of the trip fetch sample 0 (cached) and are never consumed
+            bool in_range = false;
+#if EMER_SKIP_DEAD
+            if (live) {                     // wave-uniform: only the sample id is merged (one register), the gathers below are unconditional
+#endif
+            uint32_t j = consecutive ? 64u * c + (uint32_t)lane : (uint32_t)lane * n_chunks + c;
+            in_range = j < total;
+            j = in_range ? j : last_hit;                                             // out-of-range lanes repeat the last hit (masked below)
+            uint64_t hr;
+            uint32_t hx;
+            if (consecutive) {
+                const uint32_t hr_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, (int)c);
+                const uint32_t hr_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), (int)c);
+                hx = (uint32_t)__builtin_amdgcn_readlane((int)hexcl, (int)c);
+                hr = ((uint64_t)hr_hi << 32) | hr_lo;
+            } else {
+                hr = Hv[j >> 6];
+                hx = Hx[j >> 6];
+            }
+            const uint64_t upto = ((j & 63u) == 63u) ? ~0ull : ((2ull << (j & 63u)) - 1ull);
+            const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
+            const uint64_t wq = Wl[rank];
+            const uint32_t el = El[rank];
 #if EMER_SELECT_LUT
-                const uint32_t bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
+            const uint32_t bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
 #else
-                const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
+            const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
 #endif
-                const uint32_t n = (((uint32_t)wbase + (uint32_t)wave_word0 + ((el >> 16) << lane_word_shift)) << 6) + bit;  // (32-bit: n < 2^28)
-                vld[k] = in_range && (c0 + (uint32_t)k) < n_chunks;
-                ns[k] = n;
-                // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
-                // scalar-base + 32-bit-offset addressing mode instead of 64-bit multiply-adds per lane (sn == F)
-                // (n * 12 as shifts: v_mul_lo_u32 is a quarter-rate instruction)
-                const uint32_t xoff = (D == 3) ? ((n << 3) + (n << 2)) : (n * (uint32_t)(D * 4));
-                const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + xoff);
-                const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dl) + (uint32_t)(n * (uint32_t)(F * 4)));
-                load_x<D>(xp, 0, xs[k]);
-                if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(gp); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; }
-                else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(gp); go[k][0] = t.x; go[k][1 < F ? 1 : 0] = t.y; go[k][2 < F ? 2 : 0] = t.z; go[k][3 < F ? 3 : 0] = t.w; }
-                else {
-#pragma unroll
-                    for (int f = 0; f < F; ++f) go[k][f] = gp[f];
-                }
+            n = ((trip_w0 + (uint32_t)wave_word0 + ((el >> 16) << lane_word_shift)) << 6) + bit;  // (32-bit: n < 2^28)
+#if EMER_SKIP_DEAD
             }
+#else
+            n = live ? n : 0u;
+#endif
+#if EMER_ABL & 16
+            n = live ? (((trip_w0 + (uint32_t)wave_word0) << 6) + ((j * 16u + (j >> 8)) & 4095u)) : 0u;
+#endif
+#if EMER_ABL & 1
+            n &= 0x3FFFu;
+#elif EMER_ABL & 2
+            n &= 0x3FFu;
+#endif
+            G.vld[k] = in_range && live;
+            G.ns[k] = n;
+            // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
+            // scalar-base + 32-bit-offset addressing mode instead of 64-bit multiply-adds per lane (sn == F)
+            // (n * 12 as shifts: v_mul_lo_u32 is a quarter-rate instruction)
+            const uint32_t xoff = (D == 3) ? ((n << 3) + (n << 2)) : (n * (uint32_t)(D * 4));
+            const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + xoff);
+            const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dl) + (uint32_t)(n * (uint32_t)(F * 4)));
+            load_x<D>(xp, 0, G.xs[k]);
+            if (F == 2) { float2 t = *reinterpret_cast<const float2 *>(gp); G.go[k][0] = t.x; G.go[k][1 < F ? 1 : 0] = t.y; }
+            else if (F == 4) { float4 t = *reinterpret_cast<const float4 *>(gp); G.go[k][0] = t.x; G.go[k][1 < F ? 1 : 0] = t.y; G.go[k][2 < F ? 2 : 0] = t.z; G.go[k][3 < F ? 3 : 0] = t.w; }
+            else {
 #pragma unroll
-            for (int k = 0; k < kDrainK; ++k) {
-                if ((uint32_t)(k * 64) >= take) break;  // wave-uniform
-                const bool valid = vld[k];
-                float w[D];
-                uint32_t gi[D];
-                cell_of<D>(li, xs[k], gi, w);
-                if (!valid) {
+                for (int f = 0; f < F; ++f) G.go[k][f] = gp[f];
+            }
+        }
+        c0 += (uint32_t)KG;
+        return have;
+    };
+    auto consume = [&](HitGroup<D, F, KG> &G) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int f = 0; f < F; ++f) go[k][f] = 0.0f;
+        for (int k = 0; k < KG; ++k) {
+            if ((uint32_t)(k * 64) >= G.take) break;  // wave-uniform
+            const bool valid = G.vld[k];
+            float w[D];
+            uint32_t gi[D];
+            cell_of<D>(li, G.xs[k], gi, w);
+            if (!valid) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) G.go[k][f] = 0.0f;
+            }
+            if constexpr (dense) {
+                // ---- run-segmented reduction: lanes with the same cell as their predecessor join its run
+                uint32_t cell = 0, mul = 1;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
+                if (!valid) cell = 0xFFFFFFFFu;
+#if EMER_DPP_SCANS
+                const uint32_t prev = wave_prev_u32(cell, ~cell);
+                const bool head = cell != prev;  // (lane 0 compares with ~cell: always a head)
+                const RunMasks rm = run_masks(head);
+                const bool next_head = wave_next_u32(head ? 1u : 0u, 1u) != 0u;
+#else
+                const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
+                const bool head = lane == 0 || cell != prev;
+                int run_start = head ? lane : 0;
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
+                    const int t = __shfl_up(run_start, off, kWave);
+                    if (lane >= off) run_start = run_start > t ? run_start : t;
                 }
-                if (dense) {
-                    // ---- run-segmented reduction: lanes with the same cell as their predecessor join its run
-                    uint32_t cell = 0, mul = 1;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
-                    if (!valid) cell = 0xFFFFFFFFu;
-#if EMER_DPP_SCANS
-                    const uint32_t prev = wave_prev_u32(cell, ~cell);
-                    const bool head = cell != prev;  // (lane 0 compares with ~cell: always a head)
-                    const RunMasks rm = run_masks(head);
-                    const bool next_head = wave_next_u32(head ? 1u : 0u, 1u) != 0u;
-#else
-                    const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
-                    const bool head = lane == 0 || cell != prev;
-                    int run_start = head ? lane : 0;
-#pragma unroll
-                    for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
-                        const int t = __shfl_up(run_start, off, kWave);
-                        if (lane >= off) run_start = run_start > t ? run_start : t;
-                    }
-                    const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
+                const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
 #endif
-                    const bool tail = valid && (lane == 63 || next_head);
+                const bool tail = valid && (lane == 63 || next_head);
 #pragma unroll
-                    for (uint32_t m = 0; m < (1u << D); ++m) {
-                        uint32_t c[D];
-                        float wt = 1.0f;
+                for (uint32_t m = 0; m < (1u << D); ++m) {
+                    uint32_t c[D];
+                    float wt = 1.0f;
 #pragma unroll
-                        for (int d = 0; d < D; ++d) {
-                            c[d] = gi[d] + ((m >> d) & 1u);
-                            wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
-                        }
-                        float v[F];
-#pragma unroll
-                        for (int f = 0; f < F; ++f) v[f] = wt * go[k][f];
-#if EMER_DPP_SCANS
-                        run_reduce_dpp<F>(v, rm);
-#else
-                        run_reduce<F>(v, run_start, lane);
-#endif
-                        const uint32_t idx = grid_index<D>(li, c);
-                        if (tail && (idx >> shift) == slice) {
-#pragma unroll
-                            for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
-                        }
+                    for (int d = 0; d < D; ++d) {
+                        c[d] = gi[d] + ((m >> d) & 1u);
+                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
                     }
-                } else if (pairable && !__ballot(valid && gi[0] >= li.res)) {
-                    // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
-                    // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
-                    // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
-                    // (tcnn semantics) and may put the two x-corners in different slices: a wave holding such a hit
-                    // takes the generic per-corner path below (wave-uniform test, never taken by EmerNeRF's own inputs).
-                    // A hit has ONE pair in this slice, now and then a second one (the 2^(D-1) pairs of a sample fall in
-                    // ~independent slices): every lane adds its first matching pair here on dense lanes; the rare further
-                    // pairs are queued (sample id + remaining pair mask) and drained a few at a time, again on dense
-                    // lanes, instead of running a second, 95 % masked, pair body after every chunk.
-                    uint32_t hd[D][2];
-                    hash_terms<D>(gi, hd);
-                    uint32_t match = valid ? pair_matches<D>(hd, slice_want, slice_bits) : 0u;
-                    add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
-                    if (use_queue) {
-                        const bool more = match != 0u;
-                        const unsigned long long mb = __ballot(more);
-                        if (mb) {  // wave-uniform
-                            if (more) Qw[(q_head + q_len + (uint32_t)__popcll(mb & lt_mask)) % kPairQueue] = (ns[k] << 8) | match;
-                            q_len += (uint32_t)__popcll(mb);
+                    float v[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) v[f] = wt * G.go[k][f];
+#if EMER_DPP_SCANS
+                    run_reduce_dpp<F>(v, rm);
+#else
+                    run_reduce<F>(v, run_start, lane);
+#endif
+                    const uint32_t idx = grid_index<D>(li, c);
+                    if (tail && (idx >> shift) == slice) {
+#pragma unroll
+                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
+                    }
+                }
+            } else if (pairable && !__ballot(valid && gi[0] >= li.res)) {
+                // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
+                // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
+                // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
+                // (tcnn semantics) and may put the two x-corners in different slices: a wave holding such a hit
+                // takes the generic per-corner path below (wave-uniform test, never taken by EmerNeRF's own inputs).
+                // A hit has ONE pair in this slice, now and then a second one (the 2^(D-1) pairs of a sample fall in
+                // ~independent slices): every lane adds its first matching pair here on dense lanes; the rare further
+                // pairs are queued (sample id + remaining pair mask) and drained a few at a time, again on dense
+                // lanes, instead of running a second, 95 % masked, pair body after every chunk.
+                uint32_t hd[D][2];
+                hash_terms<D>(gi, hd);
+                uint32_t match = valid ? pair_matches<D>(hd, slice_want, slice_bits) : 0u;
+#if EMER_ABL & (1 | 2 | 16)
+                match = valid ? 1u : 0u;
+#endif
+                add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
+                if (use_queue) {
+                    const bool more = match != 0u;
+                    const unsigned long long mb = __ballot(more);
+                    if (mb) {  // wave-uniform
+                        const uint32_t n_more = (uint32_t)__popcll(mb);
+                        if (q_len + n_more <= kPairQueue) {
+                            if (more) Qw[(q_head + q_len + (uint32_t)__popcll(mb & lt_mask)) % kPairQueue] = (G.ns[k] << 8) | match;
+                            q_len += n_more;
 #ifdef EMER_QUEUE_DEBUG
-                            if (lane == 0) atomicAdd(g_queue_dbg + 1, (uint32_t)__popcll(mb));
+                            if (lane == 0) atomicAdd(g_queue_dbg + 1, n_more);
 #endif
-                            if (q_len >= kPairQueueDrain) {  // (checked after every chunk: a chunk appends at most 64 entries)
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                const uint32_t done = q_len < 64u ? q_len : 64u;
-                                drain_pair_queue<D, F>(acc, li, x, dl, sn, Qw, q_head, done, slice_want, slice_bits, local_mask, lane);
-                                q_head = (q_head + done) % kPairQueue; q_len -= done;
-                            }
+                        } else {
+                            // ring full (the queue is drained between groups, see below): add the further pairs right here,
+                            // on masked lanes -- no gathers inside the chunk loop, so the compiler's wait counts for the
+                            // in-flight gathers of the following chunks stay exact
+                            while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
                         }
-                    } else {
-                        add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
-                        while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go[k], match, local_mask);
                     }
                 } else {
+                    add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
+                    while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
+                }
+            } else {
 #pragma unroll
-                    for (uint32_t m = 0; m < (1u << D); ++m) {
-                        uint32_t c[D];
-                        float wt = 1.0f;
+                for (uint32_t m = 0; m < (1u << D); ++m) {
+                    uint32_t c[D];
+                    float wt = 1.0f;
 #pragma unroll
-                        for (int d = 0; d < D; ++d) {
-                            c[d] = gi[d] + ((m >> d) & 1u);
-                            wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
-                        }
-                        const uint32_t idx = grid_index<D>(li, c);
-                        if (valid && (idx >> shift) == slice) {
+                    for (int d = 0; d < D; ++d) {
+                        c[d] = gi[d] + ((m >> d) & 1u);
+                        wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                    }
+                    const uint32_t idx = grid_index<D>(li, c);
+                    if (valid && (idx >> shift) == slice) {
 #pragma unroll
-                            for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)(wt * go[k][f]));  // ds_add_f64
-                        }
+                        for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)(wt * G.go[k][f]));  // ds_add_f64
                     }
                 }
             }
         }
+        if constexpr (pairable) {
+            // queued second pairs are drained BETWEEN groups (its gathers would otherwise sit inside the chunk loop and make
+            // the wait counts of the pipelined gathers conservative: vmcnt(0) after every chunk)
+            if (q_len >= kPairQueueDrain) {  // wave-uniform
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t done = q_len < 64u ? q_len : 64u;
+                drain_pair_queue<D, F>(acc, li, x, dl, sn, Qw, q_head, done, slice_want, slice_bits, local_mask, lane);
+                q_head = (q_head + done) % kPairQueue; q_len -= done;
+            }
+        }
+    };
+    {
+        HitGroup<D, F, KG> ga;
+#if EMER_PIPELINE
+        HitGroup<D, F, KG> gb;
+        bool more = issue(ga);
+        while (more) {
+            const bool more_b = issue(gb);   // gathers of the next group in flight ...
+            consume(ga);                     // ... while this one is consumed
+            if (!more_b) break;
+            more = issue(ga);
+            consume(gb);
+        }
+#else
+        while (issue(ga)) consume(ga);
+#endif
     }
     while (q_len) {  // wave-uniform: second pairs still queued
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1041,6 +1162,10 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         drain_pair_queue<D, F>(acc, li, x, dl, sn, Qw, q_head, done, slice_want, slice_bits, local_mask, lane);
         q_head = (q_head + done) % kPairQueue; q_len -= done;
     }
+    };  // run_item
+    if (dense_rt) run_item(std::integral_constant<int, 0>{});
+    else if (pairable_rt) run_item(std::integral_constant<int, 1>{});
+    else run_item(std::integral_constant<int, 2>{});
     __syncthreads();
     // write the slice.  One range: every entry is owned by exactly this workgroup -> plain coalesced stores.
     // Several ranges (dense levels): the host zeroed the level; merge the non-zero entries with L2 atomics.
