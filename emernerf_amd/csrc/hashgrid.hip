@@ -573,8 +573,30 @@ __device__ __forceinline__ RunMasks run_masks(bool head) {
     m.keep[5] = f ? 0.0f : 1.0f;
     return m;
 }
+// One scan step = ONE instruction per value: v_fmac_f32 with the DPP modifier on its first source, v += dpp(v) * keep.
+// Lanes whose source lane does not exist, or whose row is masked off, are disabled by the modifier (bound_ctrl off) and
+// keep v -- exactly "add nothing".  The compiler does not fold update_dpp into the multiply-add (it emitted a zero
+// initialisation, a v_mov_b32_dpp and a v_fmac_f32 per step: 288 instead of 96 instructions for the 16 reductions of a
+// chunk), so the step is written out.  A DPP source written by the previous VALU instruction needs two wait states, the
+// assembler does not add them inside inline asm: every step starts with s_nop 1 and walks all values before the next.
+#ifndef EMER_FMAC_DPP
+#define EMER_FMAC_DPP 1
+#endif
+#define EMER_DPP_STEP(CTRL, KEEP)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                                      \
+        if (i == 0) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " CTRL " bank_mask:0xf" : "+v"(v[i]) : "v"(KEEP)); \
+        else asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bank_mask:0xf" : "+v"(v[i]) : "v"(KEEP));                  \
+    }
 template <int NV>
 __device__ __forceinline__ void run_reduce_dpp(float (&v)[NV], const RunMasks &m) {
+#if EMER_FMAC_DPP
+    EMER_DPP_STEP("row_shr:1 row_mask:0xf", m.keep[0])
+    EMER_DPP_STEP("row_shr:2 row_mask:0xf", m.keep[1])
+    EMER_DPP_STEP("row_shr:4 row_mask:0xf", m.keep[2])
+    EMER_DPP_STEP("row_shr:8 row_mask:0xf", m.keep[3])
+    EMER_DPP_STEP("row_bcast:15 row_mask:0xa", m.keep[4])
+    EMER_DPP_STEP("row_bcast:31 row_mask:0xc", m.keep[5])
+#else
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = fmaf(dpp_f32<0x111, 0xF>(v[i]), m.keep[0], v[i]);
@@ -584,7 +606,9 @@ __device__ __forceinline__ void run_reduce_dpp(float (&v)[NV], const RunMasks &m
         v[i] = fmaf(dpp_f32<0x142, 0xA>(v[i]), m.keep[4], v[i]);
         v[i] = fmaf(dpp_f32<0x143, 0xC>(v[i]), m.keep[5], v[i]);
     }
+#endif
 }
+#undef EMER_DPP_STEP
 
 // Dense-level drain helper: the 64 queued samples of a wave are consecutive samples of a few rays, so
 // they form RUNS that share one cell (and therefore all 2^D corner entries).  Values are reduced per run
