@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #if EMER_SKIP_DEAD
             if (live) {                     // wave-uniform: only the sample id is merged (one register), the gathers below are unconditional
 #endif
-            uint32_t j = consecutive ? 64u * c + (uint32_t)lane : (uint32_t)lane * n_chunks + c;
+            uint32_t j = consecutive ? 64u * c + (uint32_t)lane : __umul24((uint32_t)lane, n_chunks) + c;  // (n_chunks <= 64: full-rate multiply)
             in_range = j < total;
             j = in_range ? j : last_hit;                                             // out-of-range lanes repeat the last hit (masked below)
             uint64_t hr;
@@ -1024,7 +1024,14 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
             // scalar-base + 32-bit-offset addressing mode instead of 64-bit multiply-adds per lane (sn == F)
             // (n * 12 as shifts: v_mul_lo_u32 is a quarter-rate instruction)
-            const uint32_t xoff = (D == 3) ? ((n << 3) + (n << 2)) : (n * (uint32_t)(D * 4));
+            uint32_t xoff;
+            if (D == 3) {
+                // n * 12 as shift-adds: the compiler folds (n << 3) + (n << 2) back into v_mul_lo_u32, a quarter-rate instruction
+                uint32_t n4 = n << 2;
+                asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(xoff) : "v"(n), "v"(n4));
+            } else {
+                xoff = n * (uint32_t)(D * 4);
+            }
             const float *xp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + xoff);
             const float *gp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dl) + (uint32_t)(n * (uint32_t)(F * 4)));
             load_x<D>(xp, 0, G.xs[k]);
@@ -1073,13 +1080,25 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
 #endif
                 const bool tail = valid && (lane == 63 || next_head);
-#pragma unroll
-                for (uint32_t m = 0; m < (1u << D); ++m) {
-                    uint32_t c[D];
-                    float wt = 1.0f;
+                // dense index of corner m = index of the cell + a level-uniform offset (same arithmetic mod 2^32 as
+                // grid_index: the strides are scalars, so the per-corner multiplies collapse to one add)
+                uint32_t stride_d[D], cell_idx = 0;
+                {
+                    uint32_t st = 1;
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
-                        c[d] = gi[d] + ((m >> d) & 1u);
+                        stride_d[d] = (st <= li.size) ? st : 0u;
+                        if (st <= li.size) st *= li.res;
+                        cell_idx += gi[d] * stride_d[d];
+                    }
+                }
+#pragma unroll
+                for (uint32_t m = 0; m < (1u << D); ++m) {
+                    float wt = 1.0f;
+                    uint32_t off_m = 0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        if (m & (1u << d)) off_m += stride_d[d];
                         wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
                     }
                     float v[F];
@@ -1090,7 +1109,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #else
                     run_reduce<F>(v, run_start, lane);
 #endif
-                    const uint32_t idx = grid_index<D>(li, c);
+                    uint32_t idx = cell_idx + off_m;
+                    if ((li.size & (li.size - 1u)) == 0u) idx &= li.size - 1u;
+                    else if (idx >= li.size) { idx -= li.size; if (idx >= li.size) idx %= li.size; }
                     if (tail && (idx >> shift) == slice) {
 #pragma unroll
                         for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
