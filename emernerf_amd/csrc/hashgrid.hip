@@ -662,7 +662,7 @@ __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
 // the same with the last three levels replaced by one LDS byte look-up: lut[byte * 8 + k] = position of the k-th set bit
 // of `byte` (2 KiB per workgroup, filled once): 21 VALU instead of 42 per 64 hits in the hottest loop of the backward
 #ifndef EMER_SELECT_LUT
-#define EMER_SELECT_LUT 1
+#define EMER_SELECT_LUT 0  // r2: the plain VALU select is 1 % faster now (one LDS round trip less on the hit -> sample chain; the vector pipes are ~40 % busy)
 #endif
 constexpr uint32_t kSelectLutBytes = EMER_SELECT_LUT ? 2048u : 0u;
 __device__ __forceinline__ uint32_t select64_lut(uint64_t w, uint32_t k, const uint8_t *lut) {
@@ -682,7 +682,10 @@ __device__ uint32_t g_queue_dbg[8];   // [0] bad ids read back, [1] appended, [2
 __device__ int64_t g_queue_dbg_n;
 #endif
 constexpr uint32_t kPairQueue = 72;        // ring capacity per wave (words): drain threshold - 1 + one chunk of 64
-constexpr uint32_t kPairQueueDrain = 8;    // drain once this many second pairs wait (they are rare: ~1 per 1000 hits)
+#ifndef EMER_QUEUE_DRAIN
+#define EMER_QUEUE_DRAIN 8
+#endif
+constexpr uint32_t kPairQueueDrain = EMER_QUEUE_DRAIN;    // drain once this many second pairs wait (they are rare: ~1 per 1000 hits)
 constexpr uint32_t kPairQueueShift = 24;   // entry = sample id << 8 | remaining pair mask: ids below 2^24, masks up to 8 bits (D <= 4)
 // hash contributions of the non-x dimensions for both corner values: hd[d][b] = (gi[d] + b) * prime_d
 template <int D>

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-( timeout 400 python -m pytest tests/test_a_metric_shape_gpu.py tests/test_kernels_gpu.py -x -q -k "hashgrid" 2>&1 | tail -3 ) > gpurun_out/t1.log 2>&1
-( bash tools/ab_grid.sh "base prev base prev" 1 ) > gpurun_out/ab3.log 2>&1
-cat gpurun_out/t1.log gpurun_out/ab3.log
+( for t in base abl1 abl8 abl16; do if [ $t = base ]; then L=""; else L="--lib $t"; fi; timeout 200 python tools/grid_only.py --iters 6 --grid 4,10,32,8192,18,4 $L 2>/dev/null | tail -1; done; python tools/kbench.py --help 2>&1 | head -20 ) > gpurun_out/ab6.log 2>&1
+cat gpurun_out/ab6.log
