@@ -74,6 +74,9 @@ SIGNATURES = {
     "emer_neck_supported": [c_int32, c_int32, c_int32, c_int32],
     "emer_neck_fwd": [_P, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P],
     "emer_neck_bwd": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P],
+    "emer_rmlp_supported": [c_int32, c_int32, c_int32, c_int32, c_int32],
+    "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
+    "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rgb_head_fwd": [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],

@@ -452,6 +452,169 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
     }
 }
 
+// --------------------------------------------------------------- plain 2- / 3-layer heads (hidden width 64)
+// out = act(W_last relu(... relu(W0 x + b0) ...) + b_last): the flow MLP (xyzt grid 40 -> 64 -> 64 -> 6,
+// radiance_field.py:101-111), the shadow head (64 -> 64 -> 1 + sigmoid, :148-153) and the feature heads (64 -> 64 -> 64 ->
+// E, :192-198) on the same register-resident transposed chaining as the neck: a wave owns 16 rows end to end, LDS holds
+// the weights only.  (Round 1 ran these on the generic LDS-staged chain kernel: 16 KB of row buffer per wave, 6-8 waves
+// per CU, ~4x slower.)  Input: row-major [n][ldx] (F == 0) or a level-major grid encoding [L][n][F].
+struct RMlpFwdArgs {
+    const float *x; int64_t ldx;
+    int64_t n; int32_t n_levels, k0, n_out, final_act;
+    WSrc w0, w1, w2; const float *b0, *b1, *b2;   // NL == 2: w0, w1;  NL == 3: w0, w1, w2
+    float *h1, *h2;                               // [n][64] saved post-ReLU activations (null: not needed)
+    float *out; int64_t ldo;                      // [n][ldo >= n_out]
+};
+
+// row-major [rows][ldx] input with k0 <= 16 * KT valid columns (k0 and ldx multiples of 4)
+template <int KT>
+__device__ __forceinline__ void ld_rm_k(const float *rowp, bool ok, int g, int k0, f32x4 (&v)[KT]) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+        v[t] = (ok && 16 * t + 4 * g < k0) ? *reinterpret_cast<const f32x4 *>(rowp + t * 16 + 4 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+template <int KT>
+__device__ __forceinline__ void st_rm_k(float *rowp, bool ok, int g, int k0, const f32x4 (&v)[KT]) {
+    if (!ok) return;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+        if (16 * t + 4 * g < k0) *reinterpret_cast<f32x4 *>(rowp + t * 16 + 4 * g) = v[t];
+}
+// [rows][ld] tensor with n_valid <= 16 * NT columns, any ld: scalar accesses (narrow outputs: 1, 3, 6 channels)
+template <int NT>
+__device__ __forceinline__ void ld_narrow(const float *rowp, bool ok, int g, int n_valid, f32x4 (&v)[NT]) {
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[p][i] = (ok && 16 * p + 4 * g + i < n_valid) ? rowp[16 * p + 4 * g + i] : 0.0f;
+}
+template <int NT>
+__device__ __forceinline__ void st_narrow(float *rowp, bool ok, int g, int n_valid, const f32x4 (&v)[NT]) {
+    if (!ok) return;
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (16 * p + 4 * g + i < n_valid) rowp[16 * p + 4 * g + i] = v[p][i];
+}
+
+template <int KT0, int F, int NL, int NTO>
+__global__ __launch_bounds__(kNThreads, 4) void rmlp_fwd_kernel(const RMlpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P0 = KT0 * 16 + 4, P = 64 + 4;
+    float *w0l = smem, *w1l = w0l + 64 * P0, *w2l = w1l + (NL == 3 ? 64 : NTO * 16) * P;
+    float *b0l = w2l + (NL == 3 ? NTO * 16 * P : 0), *b1l = b0l + 64, *b2l = b1l + 64;
+    stage_w(w0l, P0, 64, KT0 * 16, a.w0);
+    stage_w(w1l, P, NL == 3 ? 64 : NTO * 16, 64, a.w1);
+    if (NL == 3) stage_w(w2l, P, NTO * 16, 64, a.w2);
+    stage_b(b0l, 64, a.b0, a.w0.n);
+    stage_b(b1l, 64, a.b1, a.w1.n);
+    if (NL == 3) stage_b(b2l, 64, a.b2, a.w2.n);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const float *w0p = w0l + m * P0 + 4 * g, *w1p = w1l + m * P + 4 * g, *w2p = w2l + m * P + 4 * g;
+    const bool wide_out = (a.n_out & 3) == 0 && (a.ldo & 3) == 0;
+    const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
+    auto load_x = [&](int64_t row, f32x4 (&v)[KT0]) {
+        if constexpr (F == 0) ld_rm_k<KT0>(a.x + row * a.ldx, row < a.n, g, a.k0, v);
+        else ld_lm<KT0, F>(a.x, a.n, a.n_levels, row, row < a.n, g, v);
+    };
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t t0 = c * kNeckChunk;
+        f32x4 xn[KT0];
+        load_x(t0 * 16 + m, xn);
+        for (int j = 0; j < kNeckChunk && t0 + j < n_tiles; ++j) {
+            const int64_t row = (t0 + j) * 16 + m;
+            const bool ok = row < a.n;
+            f32x4 x[KT0];
+#pragma unroll
+            for (int t = 0; t < KT0; ++t) x[t] = xn[t];
+            if (j + 1 < kNeckChunk && t0 + j + 1 < n_tiles) load_x(row + 16, xn);
+            f32x4 h[4];
+            init_bias<4>(b0l, g, h);
+            tgemm<KT0, 4, false>(w0p, P0, x, h);
+            relu<4>(h);
+            if (a.h1) st_rm<4>(a.h1 + row * 64, ok, g, h);
+            if constexpr (NL == 3) {
+                f32x4 h2[4];
+                init_bias<4>(b1l, g, h2);
+                tgemm<4, 4, false>(w1p, P, h, h2);
+                relu<4>(h2);
+                if (a.h2) st_rm<4>(a.h2 + row * 64, ok, g, h2);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) h[p] = h2[p];
+            }
+            f32x4 o[NTO];
+            init_bias<NTO>(NL == 3 ? b2l : b1l, g, o);
+            tgemm<4, NTO, false>(NL == 3 ? w2p : w1p, P, h, o);
+            if (a.final_act == EMER_ACT_SIGMOID) {
+#pragma unroll
+                for (int p = 0; p < NTO; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[p][i] = 1.0f / (1.0f + expf(-o[p][i]));
+            }
+            if (wide_out) st_rm_k<NTO>(a.out + row * a.ldo, ok, g, a.n_out, o);
+            else st_narrow<NTO>(a.out + row * a.ldo, ok, g, a.n_out, o);
+        }
+    }
+}
+
+struct RMlpBwdArgs {
+    const float *dlast; int64_t ldd;   // [n][ldd >= n_out] gradient at the LAST pre-activation (sigmoid' applied by the caller)
+    const float *h1, *h2;              // saved activations
+    int64_t n; int32_t n_levels, k0, n_out;
+    WSrc wlt, w1t, w0t;                // W_last^T (64 x n_out), W1^T (64 x 64, NL == 3), W0^T (k0 x 64)
+    float *dpre1, *dpre0;              // [n][64] gradients at the hidden pre-activations (dpre1: NL == 3 only)
+    float *dx; int64_t lddx;           // gradient of the input: row-major [n][lddx] or level-major; null: not needed
+};
+
+template <int KT0, int F, int NL, int NTO>
+__global__ __launch_bounds__(kNThreads, 4) void rmlp_bwd_kernel(const RMlpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PL = NTO * 16 + 4, P = 64 + 4;
+    float *wll = smem, *w1l = wll + 64 * PL, *w0l = w1l + (NL == 3 ? 64 * P : 0);
+    stage_w(wll, PL, 64, NTO * 16, a.wlt);
+    if (NL == 3) stage_w(w1l, P, 64, 64, a.w1t);
+    stage_w(w0l, P, KT0 * 16, 64, a.w0t);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const float *wlp = wll + m * PL + 4 * g, *w1p = w1l + m * P + 4 * g, *w0p = w0l + m * P + 4 * g;
+    const bool wide_in = (a.n_out & 3) == 0 && (a.ldd & 3) == 0;
+    const int64_t n_tiles = (a.n + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; t < n_tiles; t += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t row = t * 16 + m;
+        const bool ok = row < a.n;
+        f32x4 d[NTO];
+        if (wide_in) ld_rm_k<NTO>(a.dlast + row * a.ldd, ok, g, a.n_out, d);
+        else ld_narrow<NTO>(a.dlast + row * a.ldd, ok, g, a.n_out, d);
+        f32x4 da[4];
+        zero<4>(da);
+        tgemm<NTO, 4, false>(wlp, PL, d, da);
+        if constexpr (NL == 3) {
+            f32x4 mk2[4];
+            ld_rm<4>(a.h2 + row * 64, ok, g, mk2);
+            relu_mask<4>(da, mk2);
+            st_rm<4>(a.dpre1 + row * 64, ok, g, da);
+            f32x4 db[4];
+            zero<4>(db);
+            tgemm<4, 4, false>(w1p, P, da, db);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) da[p] = db[p];
+        }
+        f32x4 mk1[4];
+        ld_rm<4>(a.h1 + row * 64, ok, g, mk1);
+        relu_mask<4>(da, mk1);
+        st_rm<4>(a.dpre0 + row * 64, ok, g, da);
+        if (a.dx) {
+            f32x4 de[KT0];
+            zero<KT0>(de);
+            tgemm<4, KT0, false>(w0p, P, da, de);
+            if constexpr (F == 0) st_rm_k<KT0>(a.dx + row * a.lddx, ok, g, a.k0, de);
+            else st_lm<KT0, F>(a.dx, a.n, a.n_levels, row, ok, g, de);
+        }
+    }
+}
+
 static inline uint32_t fused_grid(int64_t work_items, int threads = kFThreads) {
     const int waves = threads / 64;
     int64_t blocks = (work_items + waves - 1) / waves;
@@ -601,4 +764,89 @@ extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const floa
     if (int rc = set_lds(rgb_bwd_kernel, lds, "rgb_head_bwd")) return rc;
     hipLaunchKernelGGL(rgb_bwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_bwd");
+}
+
+// ---- plain 2- / 3-layer heads -------------------------------------------------------------------------------------
+// 1 when emer_rmlp_fwd / emer_rmlp_bwd cover this stack: n_layers Linear layers (2 or 3) with hidden width 64, k0 <= 64
+// inputs (row-major: n_feat == 0, k0 a multiple of 4; level-major grid encoding: n_feat == 4), n_out <= 64 outputs.
+extern "C" int emer_rmlp_supported(int32_t n_layers, int32_t k0, int32_t n_feat, int32_t hidden, int32_t n_out) {
+    const bool in_ok = (n_feat == 0 && k0 % 4 == 0) || (n_feat == 4 && k0 % 4 == 0);
+    return ((n_layers == 2 || n_layers == 3) && in_ok && k0 >= 4 && k0 <= 64 && hidden == 64 && n_out >= 1 && n_out <= 64) ? 1 : 0;
+}
+
+#define EMER_RMLP_DISPATCH(KERNEL, ARGS, LDS, WHAT)                                                                      \
+    do {                                                                                                               \
+        int rc_ = EMER_E_INVALID;                                                                                      \
+        auto go = [&](auto kern) {                                                                                     \
+            if (int r = set_lds(kern, LDS, WHAT)) return r;                                                            \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kNThreads), LDS, st, ARGS);                                      \
+            return check_launch(WHAT);                                                                                 \
+        };                                                                                                             \
+        if (n_feat == 0) {                                                                                             \
+            if (n_layers == 2) { if (nto == 1) rc_ = go(KERNEL<4, 0, 2, 1>); else rc_ = go(KERNEL<4, 0, 2, 4>); }      \
+            else               { if (nto == 1) rc_ = go(KERNEL<4, 0, 3, 1>); else rc_ = go(KERNEL<4, 0, 3, 4>); }      \
+        } else if (kt0 <= 2) {                                                                                         \
+            if (n_layers == 2) { if (nto == 1) rc_ = go(KERNEL<2, 4, 2, 1>); else rc_ = go(KERNEL<2, 4, 2, 4>); }      \
+            else               { if (nto == 1) rc_ = go(KERNEL<2, 4, 3, 1>); else rc_ = go(KERNEL<2, 4, 3, 4>); }      \
+        } else if (kt0 == 3) {                                                                                         \
+            if (n_layers == 2) { if (nto == 1) rc_ = go(KERNEL<3, 4, 2, 1>); else rc_ = go(KERNEL<3, 4, 2, 4>); }      \
+            else               { if (nto == 1) rc_ = go(KERNEL<3, 4, 3, 1>); else rc_ = go(KERNEL<3, 4, 3, 4>); }      \
+        } else {                                                                                                       \
+            if (n_layers == 2) { if (nto == 1) rc_ = go(KERNEL<4, 4, 2, 1>); else rc_ = go(KERNEL<4, 4, 2, 4>); }      \
+            else               { if (nto == 1) rc_ = go(KERNEL<4, 4, 3, 1>); else rc_ = go(KERNEL<4, 4, 3, 4>); }      \
+        }                                                                                                              \
+        return rc_;                                                                                                    \
+    } while (0)
+
+// x: row-major [n][ldx] (n_feat == 0, n_levels ignored) or level-major [n_levels][n][n_feat] with k0 = n_levels * n_feat.
+// Weights in torch Linear layout: w0 [64][k0], (w1 [64][64],) w_last [n_out][64]; for two layers pass w2 = b2 = NULL and
+// the output layer as w1 / b1.  h1 / h2 [n][64]: saved activations for the backward (NULL: inference).
+extern "C" int emer_rmlp_fwd(const float *x, int64_t ldx, int32_t n_levels, int32_t n_feat, int32_t k0, int64_t n, int32_t n_layers,
+                             const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
+                             int32_t n_out, int32_t final_act, float *h1, float *h2, float *out, int64_t ldo, void *stream) {
+    EMER_REQUIRE(n >= 0, "rmlp_fwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(emer_rmlp_supported(n_layers, k0, n_feat, 64, n_out), "rmlp_fwd: unsupported stack (layers=%d k0=%d F=%d n_out=%d)", n_layers, k0, n_feat, n_out);
+    EMER_REQUIRE(x && w0 && w1 && out && (n_layers == 2 || w2) && ldo >= n_out, "rmlp_fwd: bad arguments");
+    EMER_REQUIRE(n_feat != 0 || (ldx >= k0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0), "rmlp_fwd: row-major input needs ldx %% 4 == 0 and 16-byte alignment");
+    EMER_REQUIRE(n_feat == 0 || n_levels * n_feat == k0, "rmlp_fwd: k0 != n_levels * n_feat");
+    EMER_REQUIRE(final_act == EMER_ACT_NONE || final_act == EMER_ACT_SIGMOID, "rmlp_fwd: final activation must be none or sigmoid");
+    RMlpFwdArgs a;
+    a.x = x; a.ldx = ldx; a.n = n; a.n_levels = n_levels; a.k0 = k0; a.n_out = n_out; a.final_act = final_act;
+    a.w0 = WSrc{w0, k0, 1, 64, k0};
+    a.w1 = WSrc{w1, 64, 1, n_layers == 2 ? n_out : 64, 64};
+    a.w2 = WSrc{w2, 64, 1, n_out, 64};
+    a.b0 = b0; a.b1 = b1; a.b2 = b2; a.h1 = h1; a.h2 = h2; a.out = out; a.ldo = ldo;
+    const int kt0 = n_feat == 0 ? 4 : (k0 + 15) / 16, nto = n_out <= 16 ? 1 : 4;
+    const int kt0i = n_feat == 0 ? 4 : (kt0 <= 2 ? 2 : kt0);
+    const size_t lds = (size_t)(64 * (kt0i * 16 + 4) + (n_layers == 3 ? 64 : nto * 16) * 68 + (n_layers == 3 ? nto * 16 * 68 : 0) + 3 * 64) * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
+    EMER_RMLP_DISPATCH(rmlp_fwd_kernel, a, lds, "rmlp_fwd");
+}
+
+// Data-gradient chain of emer_rmlp_fwd.  dlast [n][ldd]: gradient at the last pre-activation (the caller applies
+// sigmoid').  Writes dpre0 (and dpre1 for three layers) [n][64] -- the operands of the weight gradients -- and, when dx
+// is non-null, the input gradient in the input's own layout.
+extern "C" int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float *h2, int32_t n_levels, int32_t n_feat,
+                             int32_t k0, int64_t n, int32_t n_layers, const float *w0, const float *w1, const float *w2, int32_t n_out,
+                             float *dpre1, float *dpre0, float *dx, int64_t lddx, void *stream) {
+    EMER_REQUIRE(n >= 0, "rmlp_bwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(emer_rmlp_supported(n_layers, k0, n_feat, 64, n_out), "rmlp_bwd: unsupported stack (layers=%d k0=%d F=%d n_out=%d)", n_layers, k0, n_feat, n_out);
+    EMER_REQUIRE(dlast && h1 && w0 && w1 && dpre0 && ldd >= n_out && (n_layers == 2 || (w2 && h2 && dpre1)), "rmlp_bwd: bad arguments");
+    EMER_REQUIRE(!dx || n_feat != 0 || (lddx >= k0 && lddx % 4 == 0 && ((uintptr_t)dx % 16) == 0), "rmlp_bwd: row-major dx needs lddx %% 4 == 0 and 16-byte alignment");
+    RMlpBwdArgs a;
+    a.dlast = dlast; a.ldd = ldd; a.h1 = h1; a.h2 = h2; a.n = n; a.n_levels = n_levels; a.k0 = k0; a.n_out = n_out;
+    const float *wl = n_layers == 2 ? w1 : w2;
+    a.wlt = WSrc{wl, 1, 64, 64, n_out};   // (n = hidden, k = output) = wl[k][n]
+    a.w1t = WSrc{w1, 1, 64, 64, 64};
+    a.w0t = WSrc{w0, 1, k0, k0, 64};      // (n = input feature, k = hidden) = w0[k][n]
+    a.dpre1 = dpre1; a.dpre0 = dpre0; a.dx = dx; a.lddx = lddx;
+    const int kt0 = n_feat == 0 ? 4 : (k0 + 15) / 16, nto = n_out <= 16 ? 1 : 4;
+    const int kt0i = n_feat == 0 ? 4 : (kt0 <= 2 ? 2 : kt0);
+    const size_t lds = (size_t)(64 * (nto * 16 + 4) + (n_layers == 3 ? 64 * 68 : 0) + kt0i * 16 * 68) * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    const uint32_t grid = fused_grid((n + 15) / 16, kNThreads);
+    EMER_RMLP_DISPATCH(rmlp_bwd_kernel, a, lds, "rmlp_bwd");
 }

@@ -662,8 +662,103 @@ class _SeqMLPFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+# ------------------------------------------------------------- plain 2- / 3-layer heads (register-resident)
+def rmlp_supported(weights, k0: int, n_feat: int) -> bool:
+    """Linear(k0, 64)-ReLU-[Linear(64, 64)-ReLU-]Linear(64, n_out <= 64) on row-major (n_feat 0) or level-major input."""
+    n = len(weights)
+    if n not in (2, 3):
+        return False
+    if any(w.shape[0] != 64 for w in weights[:-1]) or any(w.shape[1] != 64 for w in weights[1:]) or weights[0].shape[1] != k0:
+        return False
+    return bool(_lib.load().emer_rmlp_supported(n, k0, n_feat, 64, weights[-1].shape[0]))
+
+
+class _RMlpFn(torch.autograd.Function):
+    """final_act(Linear(ReLU(... ReLU(Linear(x))))) with hidden width 64 as ONE register-resident kernel each way
+    (csrc/mlp_fused.hip: rmlp_fwd / rmlp_bwd): the flow MLP on the level-major xyzt encoding (radiance_field.py:101-111,
+    359-389), the shadow head (:148-153) and the feature heads (:192-198)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, level_major: bool, final_act: int, *wb):
+        ctx.set_materialize_grads(False)
+        X = _c(x)
+        Ws, Bs = [_c(w) for w in wb[0::2]], [None if b is None else _c(b) for b in wb[1::2]]
+        n = len(Ws)
+        if level_major:
+            L, N, F = X.shape
+            K0, ldx = L * F, 0
+        else:
+            N, K0 = X.shape
+            L, F, ldx = 0, 0, K0
+        dev = X.device
+        n_out = Ws[-1].shape[0]
+        need_bwd = any(ctx.needs_input_grad)
+        h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if need_bwd else None
+        h2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (need_bwd and n == 3) else None
+        out = torch.empty((N, n_out), device=dev, dtype=torch.float32)
+        w2, b2 = (Ws[2], Bs[2]) if n == 3 else (None, None)
+        with torch.cuda.device(dev):
+            _lib.call("emer_rmlp_fwd", _p(X), ldx, L, F, K0, N, n, _p(Ws[0]), _p(Bs[0]), _p(Ws[1]), _p(Bs[1]), _p(w2), _p(b2),
+                      n_out, final_act, _p(h1), _p(h2), _p(out), n_out, _stream(X))
+        ctx.save_for_backward(X, out, *Ws, *([h1] if h1 is not None else []), *([h2] if h2 is not None else []))
+        ctx.n, ctx.final_act, ctx.level_major = n, final_act, level_major
+        ctx.sinks = tuple(_sink(p) for p in wb)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Optional[Tensor]):
+        n = ctx.n
+        if dout is None:
+            return (None,) * (3 + 2 * n)
+        saved = ctx.saved_tensors
+        X, out, Ws = saved[0], saved[1], saved[2:2 + n]
+        h1 = saved[2 + n]
+        h2 = saved[3 + n] if n == 3 else None
+        dev = X.device
+        if ctx.level_major:
+            L, N, F = X.shape
+            K0 = L * F
+        else:
+            N, K0 = X.shape
+            L, F = 0, 0
+        n_out = Ws[-1].shape[0]
+        d = _c(dout)
+        dlast = (d * out * (1.0 - out)).contiguous() if ctx.final_act == ACT_SIGMOID else d
+        dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
+        dpre1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if n == 3 else None
+        dx = torch.empty_like(X) if ctx.need_dx else None
+        w2 = Ws[2] if n == 3 else None
+        with torch.cuda.device(dev):
+            _lib.call("emer_rmlp_bwd", _p(dlast), n_out, _p(h1), _p(h2), L, F, K0, N, n, _p(Ws[0]), _p(Ws[1]), _p(w2), n_out,
+                      _p(dpre1), _p(dpre0), _p(dx), (0 if ctx.level_major else K0), _stream(X))
+        dpre = [dpre0, dpre1, dlast] if n == 3 else [dpre0, dlast]
+        operands = [None, [seg(h1, 0, 64)], [seg(h2, 0, 64)]] if n == 3 else [None, [seg(h1, 0, 64)]]
+        operands[0] = [seg_lm(X, 0)] if ctx.level_major else [seg(X, 0, K0)]
+        grads = []
+        for i in range(n):
+            sw, sb = ctx.sinks[2 * i], ctx.sinks[2 * i + 1]
+            tw, rw = _target(sw, tuple(Ws[i].shape), dev)
+            has_b = ctx.needs_input_grad[3 + 2 * i + 1]
+            tb, rb = _target(sb, (Ws[i].shape[0],), dev) if has_b else (None, None)
+            wgrad(dpre[i], operands[i], Ws[i].shape[1], want_bias=has_b, out_w=tw, out_b=tb)
+            grads += [rw, rb]
+        return (dx, None, None, *grads)
+
+
 def seq_mlp(x: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:
-    """Chain-fused nn.Sequential(Linear, ReLU, ..., Linear[, Sigmoid]); x [rows, K0] row-major."""
+    """Fused nn.Sequential(Linear, ReLU, ..., Linear[, Sigmoid]); x [rows, K0] row-major.  Stacks of hidden width 64
+    run on the register-resident kernels, everything else on the LDS-staged chain."""
     assert final_act in (ACT_NONE, ACT_SIGMOID)
     wb = [t for pair in zip(weights, biases) for t in pair]
+    if x.shape[-1] % 4 == 0 and rmlp_supported(weights, x.shape[-1], 0):
+        return _RMlpFn.apply(x, False, final_act, *wb)
     return _SeqMLPFn.apply(x, final_act, *wb)
+
+
+def seq_mlp_lm(enc_lm: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:
+    """The same stack fed by a LEVEL-MAJOR grid encoding [L, N, F] (no row-major copy of the encoding, the input gradient
+    comes back level-major for the grid backward).  Requires ``rmlp_supported(weights, L * F, F)``."""
+    assert final_act in (ACT_NONE, ACT_SIGMOID)
+    wb = [t for pair in zip(weights, biases) for t in pair]
+    return _RMlpFn.apply(enc_lm, True, final_act, *wb)

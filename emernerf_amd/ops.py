@@ -85,6 +85,25 @@ def layout_transpose(src: Tensor, L: int, N: int, F: int, to_row_major: bool) ->
     return dst
 
 
+class _LmToRmFn(torch.autograd.Function):
+    """Level-major grid encoding [L, N, F] -> the reference's row-major [N, L*F] (differentiable; one transpose kernel)."""
+
+    @staticmethod
+    def forward(ctx, enc_lm: Tensor):
+        L, N, F = enc_lm.shape
+        ctx.shape = (L, N, F)
+        return layout_transpose(_f32c(enc_lm), L, N, F, to_row_major=True)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        L, N, F = ctx.shape
+        return layout_transpose(_f32c(dout), L, N, F, to_row_major=False)
+
+
+def lm_to_rm(enc_lm: Tensor) -> Tensor:
+    return _LmToRmFn.apply(enc_lm)
+
+
 class _HashGridFn(torch.autograd.Function):
     """tcnn ``_module_function`` (third_party/tcnn_modules.py:115-174) on HIP.
 

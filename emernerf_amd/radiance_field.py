@@ -297,6 +297,18 @@ class RadianceField(nn.Module):
                                                  temporal_positions.reshape(-1, self.num_dims + 1))
             feats = (geo.view(*lead, -1), None if sem is None else sem.view(*lead, -1))  # already split (see _base_split)
             return feats, None, (density.view(*lead) if want_density else None)
+        enc_t = self.dynamic_xyz_encoder.tcnn_encoding
+        mlp = self.dynamic_base_mlp
+        n_out = mlp[2].out_features
+        if (temporal_positions.is_cuda and self.geometry_feature_dim == 64 and n_out == 64 + self.semantic_feature_dim
+                and fused.neck_supported(enc_t.desc.n_levels, enc_t.desc.n_features, mlp[0].out_features, n_out)):
+            # level-major encoding -> register-resident neck; the row-major hash encodings the reference hands back
+            # (:457-459, 615-617, "to be studied") are one transpose of the same tensor, not a second path through the MLP
+            enc_lm = enc_t.forward_level_major(temporal_positions.reshape(-1, self.num_dims + 1))
+            geo, sem, density = fused.neck(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+            feats = geo if sem is None else torch.cat([geo, sem], dim=-1)
+            enc = ops.lm_to_rm(enc_lm)
+            return feats.view(*lead, -1), enc.view(*lead, -1), (density.view(*lead) if want_density else None)
         enc = self.dynamic_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
         if want_density:
             feats, density = _run_sequential(self.dynamic_base_mlp, enc, density_from_col0=True)
@@ -314,8 +326,16 @@ class RadianceField(nn.Module):
         if normed_timestamps.shape[-1] != 1:
             normed_timestamps = normed_timestamps.unsqueeze(-1)
         temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
-        enc = self.flow_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
-        flow = _run_sequential(self.flow_mlp, enc)
+        enc_t = self.flow_xyz_encoder.tcnn_encoding
+        lins = [m for m in self.flow_mlp if isinstance(m, nn.Linear)]
+        if (temporal_positions.is_cuda and len(lins) == 3 and all(l.bias is not None for l in lins)
+                and fused.rmlp_supported([l.weight for l in lins], enc_t.desc.n_levels * enc_t.desc.n_features, enc_t.desc.n_features)):
+            # level-major xyzt encoding straight into the register-resident 3-layer MLP (no row-major copy either way)
+            enc_lm = enc_t.forward_level_major(temporal_positions.reshape(-1, self.num_dims + 1))
+            flow = fused.seq_mlp_lm(enc_lm, [l.weight for l in lins], [l.bias for l in lins])
+        else:
+            enc = self.flow_xyz_encoder(temporal_positions.reshape(-1, self.num_dims + 1))
+            flow = _run_sequential(self.flow_mlp, enc)
         return flow.view(*temporal_positions.shape[:-1], 6)
 
     def _noise(self, like: Tensor) -> Tensor:

@@ -367,6 +367,23 @@ int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const fl
                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1,
                   int32_t n_out, float *dpre1, float *dcol0, float *dpre0, float *denc_lm, void *stream);
 
+/* Plain heads: nn.Sequential(Linear(k0, 64), ReLU, [Linear(64, 64), ReLU,] Linear(64, n_out)[, Sigmoid]) -- the flow MLP
+ * (radiance_field.py:101-111, fed by the level-major xyzt encoding), the shadow head (:148-153) and the feature heads
+ * (:192-198, dino_head / dino_sky_head) -- register-resident like the neck.  x: row-major [n][ldx] (n_feat == 0; k0 and
+ * ldx multiples of 4) or level-major [n_levels][n][n_feat] (n_feat == 4, k0 = n_levels * n_feat).  Weights in torch
+ * Linear layout; for two layers pass the output layer as w1 / b1 and w2 = b2 = NULL.  h1 / h2 [n][64]: post-ReLU
+ * activations saved for the backward (NULL: inference).  emer_rmlp_supported == 0: use emer_mlp_chain. */
+int emer_rmlp_supported(int32_t n_layers, int32_t k0, int32_t n_feat, int32_t hidden, int32_t n_out);
+int emer_rmlp_fwd(const float *x, int64_t ldx, int32_t n_levels, int32_t n_feat, int32_t k0, int64_t n, int32_t n_layers,
+                  const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
+                  int32_t n_out, int32_t final_act, float *h1, float *h2, float *out, int64_t ldo, void *stream);
+/* Data gradients of emer_rmlp_fwd.  dlast [n][ldd]: gradient at the LAST pre-activation (the caller multiplies by
+ * sigmoid').  Writes dpre0 [n][64] (and dpre1 [n][64] for three layers), the operands of emer_wgrad_segmented, and -- when
+ * dx is non-NULL -- the input gradient in the input's layout (row-major [n][lddx] or level-major). */
+int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float *h2, int32_t n_levels, int32_t n_feat,
+                  int32_t k0, int64_t n, int32_t n_layers, const float *w0, const float *w1, const float *w2, int32_t n_out,
+                  float *dpre1, float *dpre0, float *dx, int64_t lddx, void *stream);
+
 /* rgb head: mlp.MLP(in = kh + 64, hidden 64, 3 layers, skip connection at layer 1) + sigmoid
  * (radiance_field.py:130-143,622-658, mlp.py:20-46) on input [hray[ray] | geo[sample]], where hray
  * (dir-PE | appearance embedding, kh columns) is constant along a ray.  The per-ray part arrives as

@@ -247,3 +247,42 @@ def test_seq_mlp(hip_lib, dims, sig, N):
     (out * w.to(dev)).sum().backward(); (ref * w.double()).sum().backward()
     for i, (a, b) in enumerate(zip(t, r)):
         _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+
+
+@pytest.mark.parametrize("L,F,dims,N", [(10, 4, (64, 64, 6), 1000), (10, 4, (64, 6), 333), (4, 4, (64, 64, 64), 50), (16, 4, (64, 64, 3), 4099)])
+def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
+    """fused.seq_mlp_lm (flow MLP on the level-major xyzt encoding, radiance_field.py:359-389) vs fp64 torch on the
+    row-major view of the same encoding, including the level-major input gradient."""
+    from emernerf_amd import fused, _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L * 100 + N)
+    K0 = L * F
+    enc = torch.randn(L, N, F, generator=g)
+    widths = (K0,) + dims
+    Ws = [torch.randn(widths[i + 1], widths[i], generator=g) / widths[i] ** 0.5 for i in range(len(dims))]
+    Bs = [torch.randn(widths[i + 1], generator=g) * 0.1 for i in range(len(dims))]
+    assert fused.rmlp_supported(Ws, K0, F)
+    t = [v.to(dev).requires_grad_(True) for v in [enc] + Ws + Bs]
+    r = [v.double().requires_grad_(True) for v in [enc] + Ws + Bs]
+    n = len(Ws)
+    out = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
+    h = r[0].permute(1, 0, 2).reshape(N, K0)
+    for i in range(n):
+        h = torch.nn.functional.linear(h, r[1 + i], r[1 + n + i])
+        if i + 1 < n:
+            h = torch.relu(h)
+    _close("out", out, h)
+    w = torch.randn(N, dims[-1], generator=g)
+    (out * w.to(dev)).sum().backward(); (h * w.double()).sum().backward()
+    for i, (a, b) in enumerate(zip(t, r)):
+        _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+
+
+def test_seq_mlp_routes_to_register_resident_kernels(hip_lib):
+    """The shipped head shapes must not fall back to the LDS-staged chain."""
+    from emernerf_amd import fused
+    mk = lambda *d: [torch.empty(d[i + 1], d[i]) for i in range(len(d) - 1)]
+    assert fused.rmlp_supported(mk(64, 64, 1), 64, 0)          # shadow head
+    assert fused.rmlp_supported(mk(64, 64, 64, 64), 64, 0)     # feature heads
+    assert fused.rmlp_supported(mk(40, 64, 64, 6), 40, 4)      # flow MLP on the xyzt grid (L10 x F4)
+    assert not fused.rmlp_supported(mk(43, 32, 5), 43, 0)
