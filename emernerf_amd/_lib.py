@@ -45,6 +45,7 @@ SIGNATURES = {
     "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
     "emer_hashgrid_slice_masks": [_GP, _P, _P, c_int64, _P],
     "emer_hashgrid_sliced_supported": [_GP],
+    "emer_hashgrid_mask_rows": [_P],
     "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],

@@ -179,6 +179,7 @@ struct SlicePlan {
     uint32_t n_slices[EMER_MAX_LEVELS];
     uint32_t gsub[EMER_MAX_LEVELS];      // log2(slices per bitmap group): bitmap row = slice >> gsub (<= 64 rows per level)
     uint32_t n_ranges[EMER_MAX_LEVELS];  // dense levels: the sample stream is also cut in ranges (2-D decomposition)
+    uint32_t mask_q;                     // 64-row groups of bitmap rows per level (1 or 4): bitmaps[(level * 64 * mask_q + row) * n_words + word]
     uint32_t max_local;                  // largest slice (entries)
     uint32_t ok;                         // 0 when some level would need more than 64 bitmap groups of 64 slices
     // (32-bit on purpose: a uint8_t array in this by-value kernel argument, indexed in a loop, was read back wrong by
@@ -248,12 +249,20 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         }
         p.shift[l] = k;
         p.n_slices[l] = (uint32_t)ceil_div(size, 1ll << k);
-        // The forward emits at most 64 bitmaps per level.  A table with more slices shares one bitmap among 2^gsub
-        // neighbouring slices; their owners scan the same bitmap and keep only the hits of their own slice.
-        while (((p.n_slices[l] + (1u << p.gsub[l]) - 1u) >> p.gsub[l]) > 64u) ++p.gsub[l];
         const uint32_t local = 1u << k;
-        if (local > max_entries || p.gsub[l] > 6u) p.ok = 0;
+        if (local > max_entries) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
+    }
+    // Bitmap rows.  The forward emits 64 rows per level, or 256 when some level has more slices (T = 2^20 with F = 4:
+    // 256 slices): every slice then still has its OWN bitmap.  (Round 1 / first half of round 2 shared one 64-row bitmap
+    // among 2^gsub neighbouring slices, whose owners each scanned -- gathered, hashed and mostly discarded -- the hits of
+    // all of them: 4x the work on the default static grid.)  Beyond 256 slices the sharing remains.
+    p.mask_q = 1;
+    for (uint32_t l = 0; l < g->n_levels; ++l)
+        if (p.n_slices[l] > 64u) p.mask_q = 4;
+    for (uint32_t l = 0; l < g->n_levels; ++l) {
+        while (((p.n_slices[l] + (1u << p.gsub[l]) - 1u) >> p.gsub[l]) > 64u * p.mask_q) ++p.gsub[l];
+        if (p.gsub[l] > 6u) p.ok = 0;
     }
     // Scheduling.  ONE global order of work items -- levels sorted by the cost of a single item, heaviest first (below) --
     // dealt to the eight XCD lists in blocks of kSchedBlock consecutive items (block b -> XCD b % 8).  A block is one
@@ -336,28 +345,41 @@ __device__ __forceinline__ uint64_t wave_bit_transpose(uint64_t x, int lane) {
 // workgroup (256 consecutive samples) stage their columns in LDS and wave 0 writes 32 contiguous bytes per bitmap row
 // (one store instruction touches 64 lines instead of four doing so).  Layout: bitmaps[(level * 64 + s) * n_words + word].
 // Must be called by ALL 256 threads of the workgroup (it synchronises).
-__device__ __forceinline__ void store_slice_bitmaps(uint64_t *__restrict__ bitmaps, uint64_t mask, uint32_t level, uint32_t n_slices,
+template <int Q>
+__device__ __forceinline__ void store_slice_bitmaps(uint64_t *__restrict__ bitmaps, const uint64_t (&mask)[Q], uint32_t level, uint32_t n_rows,
                                                     int64_t n0_block, int64_t n_words, int tid) {
-    __shared__ uint64_t tile[4][64];  // [wave][row]: conflict-free writes and reads
+    __shared__ uint64_t tile[Q][4][64];  // [row group][wave][row]: conflict-free writes and reads
     const int lane = tid & 63, wave = tid >> 6;
-    tile[wave][lane] = wave_bit_transpose(mask, lane);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) tile[q][wave][lane] = wave_bit_transpose(mask[q], lane);
     __syncthreads();
-    if (wave == 0 && (uint32_t)lane < n_slices) {
+    // Q == 1: wave 0 writes the 64 rows; Q == 4: wave q writes rows 64 q .. 64 q + 63
+    const int q = Q == 1 ? 0 : wave;
+    const uint32_t row = (uint32_t)(q * 64 + lane);
+    if ((Q > 1 || wave == 0) && row < n_rows) {
         const int64_t w0 = n0_block >> 6;  // first word of this workgroup (a multiple of 4)
-        uint64_t *dst = bitmaps + ((int64_t)level * 64 + lane) * n_words + w0;
+        uint64_t *dst = bitmaps + ((int64_t)level * (64 * Q) + row) * n_words + w0;
         if ((n_words & 3) == 0 && w0 + 4 <= n_words) {
-            reinterpret_cast<ulonglong2 *>(dst)[0] = make_ulonglong2(tile[0][lane], tile[1][lane]);
-            reinterpret_cast<ulonglong2 *>(dst)[1] = make_ulonglong2(tile[2][lane], tile[3][lane]);
+            reinterpret_cast<ulonglong2 *>(dst)[0] = make_ulonglong2(tile[q][0][lane], tile[q][1][lane]);
+            reinterpret_cast<ulonglong2 *>(dst)[1] = make_ulonglong2(tile[q][2][lane], tile[q][3][lane]);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (w0 + q < n_words) dst[q] = tile[q][lane];
+            for (int w = 0; w < 4; ++w)
+                if (w0 + w < n_words) dst[w] = tile[q][w][lane];
         }
     }
 }
+// set bit `row` of a Q x 64-bit row mask held in registers
+template <int Q>
+__device__ __forceinline__ void set_row(uint64_t (&mask)[Q], uint32_t row) {
+    const uint64_t b = 1ull << (row & 63u);
+    if (Q == 1) { mask[0] |= b; return; }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mask[q] |= ((row >> 6) == (uint32_t)q) ? b : 0ull;
+}
 
 // ------------------------------------------------------------------------------------ forward
-template <int D, int F, typename PT>
+template <int D, int F, typename PT, int Q>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc g, const float *__restrict__ x,
                                                            const PT *__restrict__ params, float *__restrict__ out,
                                                            int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks, const LevelMap lmap,
@@ -370,7 +392,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
     const LevelInfo li = level_info(g, level);
     const PT *__restrict__ table = params + (size_t)li.offset * F;
 
-    uint64_t mask = 0;
+    uint64_t mask[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mask[q] = 0ull;
     if (valid) {
         float xv[D], w[D];
         uint32_t gi[D];
@@ -424,8 +448,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
 #pragma unroll
                 for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
                 if (masks) {
-                    mask |= 1ull << slice_of(plan, level, idx0);
-                    if (!x_pair_one_slice) mask |= 1ull << slice_of(plan, level, idx1);  // (level-uniform)
+                    set_row<Q>(mask, slice_of(plan, level, idx0));
+                    if (!x_pair_one_slice) set_row<Q>(mask, slice_of(plan, level, idx1));  // (level-uniform)
                 }
             }
         }
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             load_feats<F, PT>(table + (size_t)idx * F, v);
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
-            if (masks) mask |= 1ull << slice_of(plan, level, idx);  // by-product for the owner-computes backward
+            if (masks) set_row<Q>(mask, slice_of(plan, level, idx));  // by-product for the owner-computes backward
         }
         }
         float *o = out + n * sn + (int64_t)level * sl;
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         }
     }
     if (masks)  // the whole workgroup takes part (tail lanes carry an empty mask)
-        store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
+        store_slice_bitmaps<Q>(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------ backward (params)
@@ -887,7 +911,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const uint32_t slice_bits = (li.size - 1u) & ~((1u << shift) - 1u), slice_want = first, local_mask = (1u << shift) - 1u;
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
-    const uint64_t *__restrict__ bm = masks + ((int64_t)level * 64 + (slice >> plan.gsub[level])) * n_words;  // 1 bit per sample
+    const uint64_t *__restrict__ bm = masks + ((int64_t)level * (64 * plan.mask_q) + (slice >> plan.gsub[level])) * n_words;  // 1 bit per sample
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     // Every lane holds one 64-sample word of the bitmap; a trip of the workgroup covers 1024 words and the next trip's
@@ -1250,7 +1274,7 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions z) 
 }
 
 // Slice bitmaps for callers that did not get them from the forward pass.
-template <int D>
+template <int D, int Q>
 __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_grid_desc g, const SlicePlan plan,
                                                                    const float *__restrict__ x, uint64_t *__restrict__ masks,
                                                                    int64_t N, uint32_t n_chunks, const LevelMap lmap) {
@@ -1258,7 +1282,9 @@ __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_gr
     if (!map_block(blockIdx.x, lmap, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
     const LevelInfo li = level_info(g, level);
-    uint64_t mask = 0;
+    uint64_t mask[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mask[q] = 0ull;
     if (n < N) {
         float xv[D], w[D];
         uint32_t gi[D];
@@ -1269,10 +1295,10 @@ __global__ __launch_bounds__(256) void hashgrid_slice_masks_kernel(const emer_gr
             uint32_t c[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) c[d] = gi[d] + ((m >> d) & 1u);
-            mask |= 1ull << slice_of(plan, level, grid_index<D>(li, c));
+            set_row<Q>(mask, slice_of(plan, level, grid_index<D>(li, c)));
         }
     }
-    store_slice_bitmaps(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
+    store_slice_bitmaps<Q>(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------- backward (input)
@@ -1370,12 +1396,22 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     const ProfileEvents ev = take_profile_events();  // (null unless emer_profile_next armed them)
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
-        if (param_dtype == EMER_F32)
-            EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                 (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
-        else
-            hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                               (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+        const bool wide = slice_masks && plan.mask_q == 4;  // 256 bitmap rows per level
+        if (param_dtype == EMER_F32) {
+            if (wide)
+                EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+            else
+                EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+        } else {
+            if (wide)
+                hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                   (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+            else
+                hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                   (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+        }
         return check_launch("hashgrid_fwd");
     });
 }
@@ -1412,7 +1448,15 @@ extern "C" int emer_hashgrid_sliced_supported(const emer_grid_desc *g) {
     return make_slice_plan(g).ok ? 1 : 0;
 }
 
-// Slice bitmaps [L][64][ceil(N/64)] (u64) for emer_hashgrid_bwd_params_sliced when the forward did not emit them.
+// Bitmap rows per level (64 or 256): the slice bitmaps of emer_hashgrid_fwd / emer_hashgrid_slice_masks hold
+// n_levels * rows * ceil(n / 64) words (+ EMER_SLICE_MASK_SCRATCH).  0 when the grid is not supported.
+extern "C" int emer_hashgrid_mask_rows(const emer_grid_desc *g) {
+    if (check_desc(g)) return 0;
+    const SlicePlan plan = make_slice_plan(g);
+    return plan.ok ? (int)(64u * plan.mask_q) : 0;
+}
+
+// Slice bitmaps [L][rows][ceil(N/64)] (u64) for emer_hashgrid_bwd_params_sliced when the forward did not emit them.
 extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x, uint64_t *slice_masks, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
     EMER_REQUIRE(n >= 0, "hashgrid_slice_masks: negative n");
@@ -1425,8 +1469,12 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto) {
         constexpr int D = decltype(d)::value;
-        hipLaunchKernelGGL((hashgrid_slice_masks_kernel<D>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, plan, x, slice_masks, n,
-                           n_chunks, lmap);
+        if (plan.mask_q == 4)
+            hipLaunchKernelGGL((hashgrid_slice_masks_kernel<D, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, plan, x, slice_masks, n,
+                               n_chunks, lmap);
+        else
+            hipLaunchKernelGGL((hashgrid_slice_masks_kernel<D, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, plan, x, slice_masks, n,
+                               n_chunks, lmap);
         return check_launch("hashgrid_slice_masks");
     });
 }
@@ -1450,7 +1498,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     // memset nodes proved unreliable on ROCm 7.2 (gradients drifted after a few replays).
     ZeroRegions zr;
     zr.count = 0;
-    uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * 64 * (size_t)ceil_div(n, 64));
+    uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * (64 * plan.mask_q) * (size_t)ceil_div(n, 64));
     zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = 8; ++zr.count;
     for (uint32_t l = 0; l < g->n_levels; ++l) {
         if (plan.n_ranges[l] > 1u) {

@@ -51,8 +51,17 @@ def sliced_supported(desc: GridDesc) -> bool:
     return bool(_lib.load().emer_hashgrid_sliced_supported(ctypes.byref(desc)))
 
 
+def mask_words(desc: GridDesc, n: int) -> int:
+    """64-bit words of the slice bitmaps for n samples: n_levels x rows x ceil(n / 64) + the backward's work cursors
+    (rows = 64, or 256 for tables with more than 64 LDS slices per level: emer_hashgrid_mask_rows)."""
+    rows = int(_lib.load().emer_hashgrid_mask_rows(ctypes.byref(desc)))
+    if rows <= 0:
+        raise _lib.EmerError("slice bitmaps requested for a grid the owner-computes backward does not support")
+    return desc.n_levels * rows * ((n + 63) // 64) + MASK_SCRATCH
+
+
 def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True, want_masks: bool = False):
-    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32 (and the [L * 64 * ceil(N/64) + 16] int64 slice bitmaps if asked)."""
+    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32 (and the int64 slice bitmaps, ``mask_words(desc, N)`` long, if asked)."""
     _check_cuda(x, params)
     N, L, F = x.shape[0], desc.n_levels, desc.n_features
     assert x.shape[1] == desc.n_dims and params.numel() == desc.n_entries * F
@@ -63,7 +72,7 @@ def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: boo
         else:
             out = torch.empty((N, L * F), device=x.device, dtype=torch.float32)
             sn, sl = L * F, F
-        masks = torch.empty((L * 64 * ((N + 63) // 64) + MASK_SCRATCH,), device=x.device, dtype=torch.int64) if want_masks else None
+        masks = torch.empty((mask_words(desc, N),), device=x.device, dtype=torch.int64) if want_masks else None
         _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl,
                   _ptr(masks), N, _stream(x))
     return (out, masks) if want_masks else out
@@ -72,7 +81,7 @@ def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: boo
 def slice_masks(desc: GridDesc, x: Tensor) -> Tensor:
     _check_cuda(x)
     with torch.cuda.device(x.device):
-        masks = torch.empty((desc.n_levels * 64 * ((x.shape[0] + 63) // 64) + MASK_SCRATCH,), device=x.device, dtype=torch.int64)
+        masks = torch.empty((mask_words(desc, x.shape[0]),), device=x.device, dtype=torch.int64)
         _lib.call("emer_hashgrid_slice_masks", ctypes.byref(desc), _ptr(x), _ptr(masks), x.shape[0], _stream(x))
     return masks
 

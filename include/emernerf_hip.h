@@ -80,7 +80,7 @@ int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_l
  * out element (n, l, f) is written at out[n*out_stride_n + l*out_stride_l + f] (f32):
  *   row-major [N, L*F] (the reference's layout): stride_n = L*F, stride_l = F;
  *   level-major [L][N][F] (coalesced, what the fused heads read): stride_n = F, stride_l = N*F.
- * slice_masks (may be NULL): [L][64][ceil(N/64)] u64 by-product consumed by emer_hashgrid_bwd_params_sliced:
+ * slice_masks (may be NULL): [L][rows][ceil(N/64)] u64 (rows = emer_hashgrid_mask_rows) by-product consumed by emer_hashgrid_bwd_params_sliced:
  *   one bitmap per (level l, LDS slice s); bit (n % 64) of word n/64 is set iff a corner of sample n
  *   lives in slice s of level l.  The buffer must hold EMER_SLICE_MASK_SCRATCH more words behind the bitmaps
  *   (work cursors of the backward).
@@ -100,7 +100,8 @@ int emer_hashgrid_bwd_params(const emer_grid_desc *host_desc, const float *x, co
 /* Same result as emer_hashgrid_bwd_params with an f32 gradient table, but OVERWRITES grad (no
  * memset needed) and uses no global atomics: each workgroup owns one LDS-resident table slice (accumulated in double) and
  * streams its 1-bit-per-sample slice bitmap ("owner computes"; see csrc/hashgrid.hip).  The training path.
- * slice_masks [L][64][ceil(N/64)] (+ EMER_SLICE_MASK_SCRATCH words the call overwrites): from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x.
+ * slice_masks [L][rows][ceil(N/64)] (+ EMER_SLICE_MASK_SCRATCH words the call overwrites), rows = emer_hashgrid_mask_rows(desc):
+ * from emer_hashgrid_fwd / emer_hashgrid_slice_masks for the same x.
  * dout is level-major: dout_stride_n == n_features (dout_stride_l free); n < 2^28. */
 int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float *x,
                                     const float *dout, int64_t dout_stride_n,
@@ -111,6 +112,9 @@ int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
 /* 1 when the owner-computes backward covers the grid: every level cuts into LDS slices (128 KiB of double accumulators
  * each) that share at most 64 bitmaps, i.e. up to 4096 slices per level -- every shipped grid.  Else use emer_hashgrid_bwd_params. */
 int emer_hashgrid_sliced_supported(const emer_grid_desc *host_desc);
+/* Bitmap rows per level: 64, or 256 when a level has more than 64 LDS slices (T = 2^20 with 4 features: every slice
+ * keeps its own bitmap).  The bitmaps hold n_levels * rows * ceil(n / 64) words + EMER_SLICE_MASK_SCRATCH.  0: unsupported grid. */
+int emer_hashgrid_mask_rows(const emer_grid_desc *host_desc);
 
 /* dX[n, d] = sum_l scale_l sum_f dOut * d(interp)/dx.  Replaces the input path of native.bwd
  * (needed by the flow configs, radiance_fields/radiance_field.py:572-608). */
