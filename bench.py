@@ -312,7 +312,7 @@ def main():
         tags = timer.tags
 
         def main_grid(name):  # launches on the main (L-level, F-feature) grid only, not the proposal grids
-            return [u for u, tg in zip(us[name], tags[name]) if tg == (L, F)]
+            return [u for u, tg in zip(us[name], tags[name]) if tg == (D, L, F)]
 
         fwd_b, bwd_b = grid_alg_bytes(D, L, F)
         f_us, b_us = main_grid("emer_hashgrid_fwd"), main_grid("emer_hashgrid_bwd_params_sliced")
@@ -329,8 +329,8 @@ def main():
         roof2 = None
         if clustered is not None:
             us2, tg2 = clustered.elapsed_us(), clustered.tags
-            f2 = [u for u, tg in zip(us2["emer_hashgrid_fwd"], tg2["emer_hashgrid_fwd"]) if tg == (L, F)]
-            b2 = [u for u, tg in zip(us2["emer_hashgrid_bwd_params_sliced"], tg2["emer_hashgrid_bwd_params_sliced"]) if tg == (L, F)]
+            f2 = [u for u, tg in zip(us2["emer_hashgrid_fwd"], tg2["emer_hashgrid_fwd"]) if tg == (D, L, F)]
+            b2 = [u for u, tg in zip(us2["emer_hashgrid_bwd_params_sliced"], tg2["emer_hashgrid_bwd_params_sliced"]) if tg == (D, L, F)]
             if f2 and b2:
                 fa, ba = sum(f2) / len(f2), sum(b2) / len(b2)
                 roof2 = {"table_init": 0.3, "bound": "hbm", "kernel": "emer_hashgrid_bwd_params_sliced", "avg_us": ba,
@@ -338,6 +338,28 @@ def main():
                          "frac": bwd_b * N / (ba * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "grid_encode_plus_bwd": {"fwd_avg_us": fa, "bwd_avg_us": ba,
                                                   "frac": (fwd_b + bwd_b) * N / ((fa + ba) * 1e-6) / 1e9 / HBM_PEAK_GBPS}}
+        # xyzt grids of the dynamic / flow configs (dynamic and flow encoders share one shape): their own roofline block
+        roof_xyzt = None
+        dyn = getattr(trainer.cfg, "dynamic_xyz_encoder", None)
+        if args.kind != "static" and dyn is not None:
+            D4, L4, F4 = dyn.n_input_dims, dyn.n_levels, dyn.n_features_per_level
+            f4 = [u for u, tg in zip(us["emer_hashgrid_fwd"], tags["emer_hashgrid_fwd"]) if tg == (D4, L4, F4)]
+            b4 = [u for u, tg in zip(us["emer_hashgrid_bwd_params_sliced"], tags["emer_hashgrid_bwd_params_sliced"]) if tg == (D4, L4, F4)]
+            if f4 and b4:
+                fb4, bb4 = grid_alg_bytes(D4, L4, F4)
+                fa4, ba4 = sum(f4) / len(f4), sum(b4) / len(b4)
+                roof_xyzt = {"grid": f"D{D4}/L{L4}/F{F4}/T2^{dyn.log2_hashmap_size} (dynamic and flow encoders)", "bound": "hbm",
+                             "launches_per_step": {"fwd": len(f4) / args.steps, "bwd": len(b4) / args.steps},
+                             "fwd_avg_us": fa4, "bwd_avg_us": ba4, "algorithmic_bytes_per_sample": {"fwd": fb4, "bwd": bb4},
+                             "frac_bwd": bb4 * N / (ba4 * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "frac_encode_plus_bwd": (fb4 + bb4) * N / ((fa4 + ba4) * 1e-6) / 1e9 / HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+        workloads = {
+            "static": "BASELINE.json configs[1]: static-only RadianceField",
+            "dynamic": "BASELINE.json configs[2] (default_dynamic.yaml): static + dynamic xyzt grid D4/L10/F4/T2^18 + shadow head",
+            "flow": "BASELINE.json configs[3] (default_flow.yaml): static + dynamic + flow xyzt grids, flow-warped temporal aggregation "
+                    "(8192 rays per GPU; the config names 16384 rays over 8 GPUs)",
+            "feature": "BASELINE.json configs[4]: flow model + feature head (E=64) + learnable PE, 3 cameras (8192 rays per GPU)",
+        }
         # fp32-MFMA rooflines of the head kernels (static configuration only: hidden 64, geo 64): algorithmic flops of
         # one launch / its average duration in the instrumented pass, vs the dense fp32 matrix peak
         mfma = {}
@@ -367,7 +389,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: static-only RadianceField, hash grid D{D}/L{L}/F{F}/T2^{c.log2_hashmap_size} "
+            "config": {"workload": f"{workloads[args.kind]}, xyz hash grid D{D}/L{L}/F{F}/T2^{c.log2_hashmap_size} "
                                    f"(fp32 tables, the reference's precision) + base MLP {L * F}->64->64 + rgb head 113->64->[177]->64->3 "
                                    f"+ sky head, 2 proposal nets (L8/F1/T2^20), {args.rays} rays x {args.samples} samples per GPU, "
                                    "proposal rounds 128+64, full optimizer step (Adam)",
@@ -381,6 +403,7 @@ def main():
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
             "roofline_trained_like": roof2,
+            "roofline_xyzt": roof_xyzt,
             "lidar_step": extra.get("lidar_step"),
             "eval_render": extra.get("eval_render"),
             "roofline_mfma": mfma,

@@ -160,7 +160,7 @@ def call(name: str, *args) -> None:
         tag = None
         if name.startswith("emer_hashgrid"):  # distinguish the main grid from the proposal grids
             d = args[0]._obj
-            tag = (d.n_levels, d.n_features)
+            tag = (d.n_dims, d.n_levels, d.n_features)
         t.tags[name].append(tag)
     else:
         rc = getattr(lib, name)(*args)

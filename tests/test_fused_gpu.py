@@ -249,7 +249,8 @@ def test_seq_mlp(hip_lib, dims, sig, N):
         _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
-@pytest.mark.parametrize("L,F,dims,N", [(10, 4, (64, 64, 6), 1000), (10, 4, (64, 6), 333), (4, 4, (64, 64, 64), 50), (16, 4, (64, 64, 3), 4099)])
+@pytest.mark.parametrize("L,F,dims,N", [(10, 4, (64, 64, 6), 1000), (10, 4, (64, 6), 333), (4, 4, (64, 64, 64), 50), (16, 4, (64, 64, 3), 4099),
+                                         (10, 4, (64, 64, 6), 262144)])
 def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
     """fused.seq_mlp_lm (flow MLP on the level-major xyzt encoding, radiance_field.py:359-389) vs fp64 torch on the
     row-major view of the same encoding, including the level-major input gradient."""

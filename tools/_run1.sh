@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout 600 python -m pytest tests/test_a_metric_shape_gpu.py tests/test_kernels_gpu.py -x -q -k "hashgrid" 2>&1 | tail -4 ) > gpurun_out/t3.log 2>&1
-cat gpurun_out/t3.log
-( for g in 3,16,16,2048,19,2 3,10,16,8192,20,4 4,10,32,8192,18,4; do for t in base nocarry; do if [ $t = base ]; then L=""; else L="--lib $t"; fi; timeout 200 python tools/grid_only.py --iters 8 --grid $g $L 2>/dev/null | tail -1; done; done ) > gpurun_out/ab7.log 2>&1
-cat gpurun_out/ab7.log
+( timeout 600 python -m pytest tests/test_fused_gpu.py -x -q -k "seq_mlp" 2>&1 | tail -3 ) > gpurun_out/t4.log 2>&1
+cat gpurun_out/t4.log
+timeout 300 python bench.py --kind flow --no-cpu-baseline --no-extras --no-second-state --steps 20 --warmup 5 2>gpurun_out/bf_err.log > gpurun_out/bf.json; tail -3 gpurun_out/bf_err.log; python -c "
+import json; b=json.loads(open('gpurun_out/bf.json').read().strip().splitlines()[-1]); print(b['value'], b['config']['workload'][:150]); print(b['roofline']['avg_us'], b['roofline']['grid_encode_plus_bwd']); print(b['roofline_xyzt'])"

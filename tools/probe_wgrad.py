@@ -1,6 +1,10 @@
 """Time emer_wgrad_segmented on the shapes of one training step (1M rows)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import emernerf_amd._lib as _L0
+if "--lib" in sys.argv:  # A/B: emernerf_amd/lib/libemernerf_<tag>.so (tools/build_variant.sh)
+    _L0.LIB_PATH = os.path.join(os.path.dirname(_L0.LIB_PATH), f"libemernerf_{sys.argv[sys.argv.index('--lib') + 1]}.so")
+    print("lib", sys.argv[sys.argv.index('--lib') + 1])
 from emernerf_amd import fused
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); R, S = 8192, 128; N = R * S
