@@ -751,6 +751,23 @@ __device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], c
         wa *= t; wb *= t;
     }
     const uint32_t l0 = (gi[0] ^ h) & local_mask, l1 = ((gi[0] + 1u) ^ h) & local_mask;  // offsets inside the slice
+#if EMER_ROT_FEATS
+    if (F == 2) {
+        // An entry is F doubles, so "feature f of a random entry" reaches only half of the 32 bank pairs; odd lanes
+        // therefore add feature 1 in the first instruction and feature 0 in the second: each instruction's addresses cover
+        // all bank pairs (-1.5 % on the main grid; nothing on the F = 4 grids, whose limit is the LDS atomic rate itself).
+        const bool odd = (__lane_id() & 1u) != 0u;
+        const float g0 = odd ? go[1 % F] : go[0], g1 = odd ? go[0] : go[1 % F];
+        const uint32_t f0 = odd ? 1u : 0u, f1 = f0 ^ 1u;
+        if (has) {
+            atomicAdd(acc + (size_t)l0 * F + f0, (double)(wa * g0));  // ds_add_f64
+            atomicAdd(acc + (size_t)l1 * F + f0, (double)(wb * g0));
+            atomicAdd(acc + (size_t)l0 * F + f1, (double)(wa * g1));
+            atomicAdd(acc + (size_t)l1 * F + f1, (double)(wb * g1));
+        }
+        return;
+    }
+#endif
     if (has) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
@@ -807,6 +824,9 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
 // chunks (of 64 hits) per register set of the software-pipelined drain: two sets are live, D + F + 1 registers per chunk
 #ifndef EMER_PIPE_K
 #define EMER_PIPE_K 2
+#endif
+#ifndef EMER_ROT_FEATS
+#define EMER_ROT_FEATS 1
 #endif
 #ifndef EMER_SKIP_DEAD
 #define EMER_SKIP_DEAD 1
