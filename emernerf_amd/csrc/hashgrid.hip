@@ -535,12 +535,14 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 //     4 words per row and workgroup through LDS): a slice owner reads 128 KiB of bitmap instead of touching every sample;
 //   * a persistent workgroup (1024 threads, one per CU) OWNS one (level, slice[, sample range]) work item at a time.  Each
 //     lane holds one 64-sample bitmap word; the hits of a wave's 64 words are compacted analytically (DPP scans, ranks
-//     through a 4096-bit head vector, LUT-assisted select of the k-th set bit) so that lane l of chunk c materialises
+//     through a 4096-bit head vector, select of the k-th set bit) so that lane l of chunk c materialises
 //     hit 64 c + l directly -- dense lanes, sample order, no queue, no barrier in the loop;
-//   * the hits are reprocessed six chunks at a time with all x / dout gathers in flight (32-bit offsets from scalar
-//     bases): recompute cell + weights, then ds_add_f64 the corners that live in the slice.  Hashed power-of-two levels
-//     add one x-pair per hit (a rare second pair goes through a small per-wave queue); dense coarse levels reduce runs of
-//     equal cells with a segmented DPP scan first, so one lane per run touches the LDS;
+//   * the hits are reprocessed in GROUPS of two 64-hit chunks, software-pipelined over two register sets: the x / dout
+//     gathers of group g + 1 (32-bit offsets from scalar bases) are in flight while group g is consumed -- recompute cell +
+//     weights, then ds_add_f64 the corners that live in the slice.  Hashed power-of-two levels add one x-pair per hit (a
+//     rare second pair goes through a small per-wave queue, drained between groups); dense coarse levels reduce runs of
+//     equal cells with a segmented DPP scan first (one v_fmac_f32_dpp per value and step), so one lane per run touches
+//     the LDS.  The stream is instantiated once per kind of level (dense / paired hashed / other hashed);
 //   * at the end the slice is written with plain coalesced stores (every entry of a hashed level is owned by exactly one
 //     workgroup: no global atomics, no memset of the 49 MB gradient); dense levels, whose sample stream is also cut in
 //     ranges for balance, merge their non-zero entries into a pre-zeroed level with L2 atomics.
@@ -559,7 +561,7 @@ constexpr int kSliceWaves = kSliceThreads / 64;
 #define EMER_STRIDED_MAX_RES 420
 #endif
 constexpr uint32_t kStridedHitsMaxRes = EMER_STRIDED_MAX_RES;          // hashed levels up to this resolution spread a wave's hits over distant samples
-constexpr int kDrainK = 6;                            // hits per lane per drain (loads in flight)
+constexpr int kDrainK = 6;                            // chunks per drain of the NON-pipelined build (-DEMER_PIPELINE=0, A/B only)
 
 
 // ---- DPP wave scans (gfx9 data-parallel primitives: a VALU operand modifier, no LDS round trip) -------------------
@@ -1412,7 +1414,7 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
     uint32_t blocks = 0;
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice bitmaps requested but a level needs more than 64 x 64 LDS slices");
+    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd: slice bitmaps requested but a level needs more than 256 x 64 LDS slices");
     const ProfileEvents ev = take_profile_events();  // (null unless emer_profile_next armed them)
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, F = decltype(f)::value;
@@ -1483,7 +1485,7 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(x && slice_masks, "hashgrid_slice_masks: null pointer");
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 64 x 64 LDS slices");
+    EMER_REQUIRE(plan.ok, "hashgrid_slice_masks: a level needs more than 256 x 64 LDS slices");
     const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
     uint32_t blocks = 0;
     const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
@@ -1510,7 +1512,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
     const SlicePlan plan = make_slice_plan(g);
-    EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 64 x 64 LDS slices; use emer_hashgrid_bwd_params");
+    EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 256 x 64 LDS slices; use emer_hashgrid_bwd_params");
     uint32_t total_items = 0;
     for (int i = 0; i < 8; ++i) total_items += plan.items_per_xcd[i];
     // Zero, in ONE launch, the levels that are merged with atomics and the work cursors (the 16 scratch words behind

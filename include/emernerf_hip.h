@@ -110,7 +110,8 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
 int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
                               uint64_t *slice_masks, int64_t n, void *stream);
 /* 1 when the owner-computes backward covers the grid: every level cuts into LDS slices (128 KiB of double accumulators
- * each) that share at most 64 bitmaps, i.e. up to 4096 slices per level -- every shipped grid.  Else use emer_hashgrid_bwd_params. */
+ * each) that share at most 256 bitmaps (one per slice up to 256 slices per level, the case of every shipped grid; beyond
+ * that 2^k neighbouring slices share one), i.e. up to 16384 slices per level.  Else use emer_hashgrid_bwd_params. */
 int emer_hashgrid_sliced_supported(const emer_grid_desc *host_desc);
 /* Bitmap rows per level: 64, or 256 when a level has more than 64 LDS slices (T = 2^20 with 4 features: every slice
  * keeps its own bitmap).  The bitmaps hold n_levels * rows * ceil(n / 64) words + EMER_SLICE_MASK_SCRATCH.  0: unsupported grid. */
