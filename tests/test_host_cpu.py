@@ -182,3 +182,22 @@ def test_data_parallel_flat_allreduce_gloo():
         ret = mgr.dict()
         mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
         assert len(ret) == world and all(v < 1e-6 for v in ret.values()), dict(ret)
+
+
+@pytest.mark.parametrize("grid,rows", [((3, 16, 16, 2048, 19, 2), 64),     # BASELINE configs[1] main grid: 64 slices per hashed level
+                                       ((3, 10, 16, 8192, 20, 4), 256),    # default static grid: 256 LDS slices -> 256 bitmap rows
+                                       ((4, 10, 32, 8192, 18, 4), 64),     # dynamic / flow xyzt grids
+                                       ((3, 8, 16, 2048, 20, 1), 64)])     # proposal net
+def test_slice_plan_host_logic(hip_lib, grid, rows):
+    """Host side of the owner-computes backward (no kernel launched): every shipped grid is supported and gets one bitmap
+    row per LDS slice; the rmlp / neck dispatch predicates answer for the shipped head shapes."""
+    import ctypes
+    from emernerf_amd import _lib
+    D, L, base, mx, T, F = grid
+    growth = float(np.exp((np.log(mx) - np.log(base)) / (L - 1)))
+    desc = _lib.make_grid_desc(D, L, F, T, base, growth)
+    assert hip_lib.emer_hashgrid_sliced_supported(ctypes.byref(desc)) == 1
+    assert hip_lib.emer_hashgrid_mask_rows(ctypes.byref(desc)) == rows
+    assert hip_lib.emer_rmlp_supported(3, 40, 4, 64, 6) == 1 and hip_lib.emer_rmlp_supported(2, 64, 0, 64, 1) == 1
+    assert hip_lib.emer_rmlp_supported(3, 64, 0, 64, 64) == 1 and hip_lib.emer_rmlp_supported(2, 43, 0, 32, 5) == 0
+    assert hip_lib.emer_neck_supported(16, 2, 64, 64) == 1 and hip_lib.emer_neck_supported(10, 4, 64, 128) == 1
