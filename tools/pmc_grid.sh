@@ -22,7 +22,6 @@ SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC S
 SQ_INSTS_FLAT SQ_INSTS_GDS SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_INSTS_SENDMSG
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TCC_HIT_sum TCC_MISS_sum
-TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_BUSY_avr
 GRBM_GUI_ACTIVE
 SETS
 python - "$OUT" <<'PY'
