@@ -785,6 +785,56 @@ __device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], c
         }
     }
 }
+// Coarse hashed levels: consecutive samples of a ray share cells, so the hits of a slice come in RUNS of equal cells whose
+// first matching pair -- and therefore the two LDS entries -- coincide.  Like the dense levels, the 2 F values of a run
+// are summed with a segmented DPP scan and only the run's last lane touches the LDS: r-fold fewer ds_add_f64 and no
+// same-address serialisation (round 1 / first half of round 2 spread such hits over distant lanes instead and still paid
+// every add).  Lanes of a run have the same cell, hence the same match mask.
+// Measured (same-session A/B, training distribution): main grid D3/F2 592 -> 532 us, xyzt D4/F4 1955 -> 1422 us, default static
+// D3/F4 842 -> 661 us with EVERY paired hashed level on this path (a threshold at res 420 / 900 gives 552 / 545 and 1496 / 1437);
+// the one-feature proposal grids lose (243 -> 251 at res 900, 280 on all levels: two adds per hit do not pay for the scan),
+// so F = 1 keeps the plain path with strided hit order on its coarse levels.
+#ifndef EMER_RUN_RES
+#define EMER_RUN_RES 0x40000000   // hashed levels up to this resolution take the run-reduced path (0: off)
+#endif
+template <int D, int F>
+__device__ __forceinline__ void add_pair_runs(double *acc, const uint32_t (&gi)[D], const float (&w)[D], const uint32_t (&hd)[D][2],
+                                              const float (&go)[F], uint32_t &match, uint32_t local_mask, bool valid, int lane) {
+    // run heads: a lane whose cell differs from its predecessor's (invalid lanes are runs of their own)
+    uint32_t diff = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const uint32_t key = valid ? gi[d] : 0xFFFFFFFFu - (uint32_t)lane;
+        diff |= key ^ wave_prev_u32(key, ~key);
+    }
+    const bool head = diff != 0u;  // (lane 0 compares with ~key: always a head)
+    const RunMasks rm = run_masks(head);
+    const bool next_head = wave_next_u32(head ? 1u : 0u, 1u) != 0u;
+    const bool has = match != 0u;
+    const uint32_t m = has ? (uint32_t)__ffs((int)match) - 1u : 0u;
+    match &= match - 1u;
+    uint32_t h = 0;
+    float wa = 1.0f - w[0], wb = w[0];
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+        const bool bit = (m >> (d - 1)) & 1u;
+        h ^= bit ? hd[d][1] : hd[d][0];
+        const float t = bit ? w[d] : 1.0f - w[d];
+        wa *= t; wb *= t;
+    }
+    const uint32_t l0 = (gi[0] ^ h) & local_mask, l1 = ((gi[0] + 1u) ^ h) & local_mask;
+    float v[2 * F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { v[f] = has ? wa * go[f] : 0.0f; v[F + f] = has ? wb * go[f] : 0.0f; }
+    run_reduce_dpp<2 * F>(v, rm);
+    if (has && (lane == 63 || next_head)) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            atomicAdd(acc + (size_t)l0 * F + f, (double)v[f]);  // ds_add_f64
+            atomicAdd(acc + (size_t)l1 * F + f, (double)v[F + f]);
+        }
+    }
+}
 // Queued second pairs: lane l takes entry l, reloads the sample (cache hits: it was loaded a moment ago), and adds the
 // queued pairs.
 template <int D, int F>
@@ -905,8 +955,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     unsigned long long trace_hits = 0;
 #endif
     const bool dense_rt = !li.hashed;
-    const bool consecutive = dense_rt || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
+    const bool run_reduced = pairable_rt && EMER_DPP_SCANS && F >= 2 && li.res <= (uint32_t)EMER_RUN_RES;  // coarse hashed level: runs of equal cells are summed before the LDS
+    const bool consecutive = dense_rt || run_reduced || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
     const uint32_t first = slice << shift;
     const uint32_t n_local = ((li.size - first) < (1u << shift)) ? (li.size - first) : (1u << shift);
@@ -1182,7 +1233,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #if EMER_ABL & (1 | 2 | 16)
                 match = valid ? 1u : 0u;
 #endif
-                add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
+                if (run_reduced) add_pair_runs<D, F>(acc, gi, w, hd, G.go[k], match, local_mask, valid, lane);  // (level-uniform)
+                else add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
                 if (use_queue) {
                     const bool more = match != 0u;
                     const unsigned long long mb = __ballot(more);
