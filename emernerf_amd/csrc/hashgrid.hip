@@ -560,7 +560,7 @@ constexpr int kSliceWaves = kSliceThreads / 64;
 #ifndef EMER_STRIDED_MAX_RES
 #define EMER_STRIDED_MAX_RES 420
 #endif
-constexpr uint32_t kStridedHitsMaxRes = EMER_STRIDED_MAX_RES;          // hashed levels up to this resolution spread a wave's hits over distant samples
+constexpr uint32_t kStridedHitsMaxRes = EMER_STRIDED_MAX_RES;          // one-feature hashed levels (no run reduction) up to this resolution spread a wave's hits over distant samples
 constexpr int kDrainK = 6;                            // chunks per drain of the NON-pipelined build (-DEMER_PIPELINE=0, A/B only)
 
 
@@ -1073,10 +1073,11 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             uint32_t c = c0 + (uint32_t)k;
             const bool live = c < n_chunks;                                          // wave-uniform
             c = live ? c : last_chunk;
-            // Lane l takes hit 64 c + l (sample order) on dense levels -- the run reduction needs it -- and on FINE hashed
-            // levels, where neighbouring hits share x / dout cache lines.  On COARSE hashed levels consecutive samples
-            // of a ray share cells and would serialise on the same LDS address: there lane l takes hit l * n_chunks +
-            // c, so the lanes of one instruction work on hits far apart (different rays).
+            // Lane l takes hit 64 c + l (sample order) wherever runs of equal cells are reduced before the LDS (dense levels,
+            // paired hashed levels with F >= 2) and on FINE levels, where neighbouring hits share x / dout cache lines.  On the
+            // COARSE levels of one-feature grids (plain adds) consecutive samples of a ray share cells and would serialise
+            // on the same LDS address: there lane l takes hit l * n_chunks + c, so the lanes of one instruction work on hits
+            // far apart (different rays).
             uint32_t n = 0u;               // chunks past the end of the trip fetch sample 0 (cached) and are never consumed
             bool in_range = false;
 #if EMER_SKIP_DEAD
