@@ -259,6 +259,7 @@ class Trainer:
         a, b = self.flat.ranges["main"]
         self._early_ranges = [(lo, hi) for lo, hi in self.flat._dense_ranges if a <= lo and hi <= b]
         self._early_done, self._early_work = False, []
+        self._prop_work = None  # async all-reduce of the trained proposal net's range (launched right after ITS backward)
         if world_size > 1:
             self.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = self._launch_early_bucket
         self.model.train(); self.estimator.train()
@@ -308,6 +309,7 @@ class Trainer:
                                   data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad, prefix="lidar_")
             if prop_grad:
                 self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale).backward()
+                self._launch_prop_bucket()
             loss = self.lidar_losses(results, data, step)
             (loss * self.loss_scale).backward()
         fused.join_side_stream()
@@ -328,6 +330,16 @@ class Trainer:
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
             self._early_done = True
 
+    def _launch_prop_bucket(self) -> None:
+        """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
+        is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
+        starts here and is hidden completely.  Eager launches only (a collective cannot be captured into the step's graph)."""
+        if self.world_size > 1 and self._prop_work is None and not torch.cuda.is_current_stream_capturing():
+            fused.join_side_stream()
+            self.flat.finish_grads("prop")
+            a, b = self.flat.ranges["prop"]
+            self._prop_work = dist.all_reduce(self.flat.grads[a:b], async_op=True)
+
     def _exchange_grads(self, prop_grad: bool) -> None:
         """The data-parallel exchange of a step (sum; 1/W is folded into Adam's grad_scale): the table bucket (and, on the
         steps that train them -- same schedule on every rank -- the proposal net's range), after the early MLP bucket.
@@ -337,7 +349,7 @@ class Trainer:
             self.flat.finish_grads("prop")
         if self.world_size > 1:
             a, b = self.flat.ranges["main"]
-            if prop_grad:
+            if prop_grad and self._prop_work is None:
                 b = self.flat.ranges["prop"][1]  # main and the trained proposal net are adjacent in the flat buffer
             if self._early_done:
                 late = _subtract_ranges((a, b), self._early_ranges)
@@ -347,7 +359,9 @@ class Trainer:
                     w.wait()
             else:
                 dist.all_reduce(self.flat.grads[a:b])
-        self._early_done, self._early_work = False, []
+            if self._prop_work is not None:
+                self._prop_work.wait()
+        self._early_done, self._early_work, self._prop_work = False, [], None
 
     def _adam(self, group: str, lr: float):
         a, b = self.flat.ranges[group]
@@ -364,6 +378,7 @@ class Trainer:
             if prop_grad:
                 prop_loss = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
                 prop_loss.backward()
+                self._launch_prop_bucket()
             loss = self.losses(results, data)
             (loss * self.loss_scale).backward()
         fused.join_side_stream()  # weight gradients written on the side stream are complete from here on
