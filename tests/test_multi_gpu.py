@@ -45,8 +45,22 @@ def _worker(rank, port, out_dir):
     data, jit = _data(rank * R_HALF, (rank + 1) * R_HALF)
     it = iter(jit)
     tr.estimator.jitter_fn = lambda n, d: next(it)
+    calls = {"prop": 0, "early": 0}
+    orig_prop, orig_early = tr._launch_prop_bucket, tr._launch_early_bucket
+
+    def spy_prop():
+        calls["prop"] += 1
+        orig_prop()
+        assert tr._prop_work is not None, "the proposal bucket must be in flight before the main backward"
+
+    def spy_early():
+        calls["early"] += 1
+        orig_early()
+    tr._launch_prop_bucket = spy_prop
+    tr.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = spy_early
     out = tr.train_step(data)
     assert out["prop_grad"], "the test step must exercise the proposal-net range of the exchange"
+    assert calls["prop"] == 1 and calls["early"] >= 1, f"buckets not launched early: {calls}"
     torch.cuda.synchronize()
     torch.save(tr.flat.params.cpu(), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
