@@ -161,8 +161,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # Test hooks (a 1-GPU box cannot run RCCL with two ranks): EMER_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # EMER_BENCH_BACKEND=gloo exchanges through gloo -- the same code path end to end, not a measurement.
+    share_gpu = os.environ.get("EMER_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("EMER_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     rccl_log = None
     if world > 1:
         # RCCL's own account of the communicator (ranks, rings / trees, transport) goes to a per-rank file, not to stdout
@@ -171,7 +176,10 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
         os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from emernerf_amd import _build, _lib
     if rank == 0:  # one builder; the others wait (a concurrent build would write the same object files)
@@ -238,18 +246,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # untimed: per-kernel breakdown with every entry point instrumented.  EVERY rank takes these steps (a step contains the
+    # gradient collectives: rank 0 alone would wait for its peers forever); only rank 0 records events.
     breakdown, breakdown_steps = None, min(args.steps, 12)
-    if rank == 0:  # untimed: per-kernel breakdown with every entry point instrumented
+    if rank == 0:
         breakdown = _lib.KernelTimer(all_names)
         _lib.TIMER = breakdown
-        graphed, trainer.use_graph = trainer.use_graph, False  # the instrumented pass launches eagerly
-        for _ in range(breakdown_steps):
-            trainer.train_step(next_batch())
-        torch.cuda.synchronize()
-        trainer.use_graph = graphed
-        _lib.TIMER = None
-        if timer is None:
-            timer = breakdown
+    graphed, trainer.use_graph = trainer.use_graph, False  # the instrumented pass launches eagerly
+    for _ in range(breakdown_steps):
+        trainer.train_step(next_batch())
+    torch.cuda.synchronize()
+    trainer.use_graph = graphed
+    _lib.TIMER = None
+    if rank == 0 and timer is None:
+        timer = breakdown
     # CPU baseline + render parity (PSNR / depth error of the HIP path vs the oracle on the same parameters), evaluated
     # on the state the timed region left -- before the extra measurements below train the model further
     cpu_res = None
@@ -262,7 +272,7 @@ def main():
     # the lidar optimizer step of a reference iteration (train_emernerf.py:747-826) and the evaluation render loop
     # (video_utils.py:50-468: eval mode, return_decomposition, 16 384-ray chunks, results copied to the host).
     extra = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # single-GPU measurements (the lidar step contains the collectives)
         from emernerf_amd.trainer import synthetic_lidar_rays
         lidar = [synthetic_lidar_rays(args.rays, dev, seed=2000 + i) for i in range(4)]
         for i in range(8):
