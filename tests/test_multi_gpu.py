@@ -88,3 +88,23 @@ def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path):
     # between the two summation orders are the only possible mismatches
     bad = (du - dv).abs() > 1e-3 * dv.abs().clamp_min(1e-12)
     assert int(bad.sum()) <= max(10, int(touched.sum()) // 2000), f"{int(bad.sum())} of {int(touched.sum())} updates differ"
+
+
+def test_bench_runs_with_two_ranks(hip_lib, tmp_path):
+    """bench.py's N > 1 path end to end on this one-GPU box: two ranks share cuda:0 and exchange through gloo (test hooks;
+    on a multi-GPU node the same code runs over RCCL).  Guards the contract that EVERY rank takes every step that contains
+    a collective -- a rank-0-only training step after the timed region once hung the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMER_BENCH_SHARE_GPU="1", EMER_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--init-steps", "7", "--rays", "1024", "--samples", "32"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_rays"] == 2048 and out["value"] > 0 and out["scaling"] == "weak"
