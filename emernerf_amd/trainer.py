@@ -260,6 +260,7 @@ class Trainer:
         self._early_ranges = [(lo, hi) for lo, hi in self.flat._dense_ranges if a <= lo and hi <= b]
         self._early_done, self._early_work = False, []
         self._prop_work = None  # async all-reduce of the trained proposal net's range (launched right after ITS backward)
+        self._hold_buckets = False  # graph warm-up / capture: no collectives from inside the forward+backward
         if world_size > 1:
             self.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = self._launch_early_bucket
         self.model.train(); self.estimator.train()
@@ -326,7 +327,7 @@ class Trainer:
         encoder of the forward pass): every MLP / embedding gradient of the main model is enqueued by now, so their
         (small) all-reduce starts here and runs on RCCL's stream while the grid backward -- the longest kernel of the
         step -- computes the table gradient.  Only the table bucket is exposed at the end of the backward."""
-        if self.world_size > 1 and not self._early_done and not torch.cuda.is_current_stream_capturing():
+        if self.world_size > 1 and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
             self._early_done = True
 
@@ -334,7 +335,7 @@ class Trainer:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
         is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
         starts here and is hidden completely.  Eager launches only (a collective cannot be captured into the step's graph)."""
-        if self.world_size > 1 and self._prop_work is None and not torch.cuda.is_current_stream_capturing():
+        if self.world_size > 1 and self._prop_work is None and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()
             self.flat.finish_grads("prop")
             a, b = self.flat.ranges["prop"]
@@ -397,6 +398,7 @@ class Trainer:
                     self._static_data[k].copy_(v)
         sd = self._static_data
         if prop_grad not in self._graphs:
+            self._hold_buckets = True  # the warm-up passes and the capture must not start gradient collectives
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -407,6 +409,7 @@ class Trainer:
             with torch.cuda.graph(g):
                 out = self._forward_backward(sd, prop_grad)
             self._graphs[prop_grad] = (g, out)
+            self._hold_buckets = False
         g, out = self._graphs[prop_grad]
         g.replay()
         return out
@@ -421,6 +424,7 @@ class Trainer:
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({e!r}); continuing with eager launches")
                 self.use_graph = False
+                self._hold_buckets = False
                 loss = self._forward_backward(data, prop_grad)
         else:
             loss = self._forward_backward(data, prop_grad)
