@@ -20,6 +20,8 @@
 //                 pass per workgroup at the end.
 #include "common.h"
 
+#include <type_traits>
+
 namespace emer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -298,7 +300,7 @@ static inline int32_t dw_rows_per_block(int64_t m, int32_t n, int32_t k) {
     const int tiles = ((n + 31) / 32) * ((k + 31) / 32);
     const int64_t cap = tiles >= 6 ? 4096 : (n > 32 ? 2048 : 1024);
     int64_t r = (m + 511) / 512;
-    r = (r + 31) / 32 * 32;  // 32-row LDS tiles
+    r = (r + 63) / 64 * 64;  // 16-row blocks per wave (wgrad_stream), 32-row LDS tiles (wgrad_seg)
     if (r < 64) r = 64;
     if (r > cap) r = cap;
     return (int32_t)r;
@@ -689,13 +691,23 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
     if (want_bias && blockIdx.y == 0 && wave == 0 && lane < NG && n_base + lane < N) part[(int64_t)N * K + n_base + lane] = bsum;
 }
 
-// Streaming dW.  For v_mfma_f32_32x32x2 lane (j = lane & 31, ms = lane >> 5) supplies dPre[m + ms][n0 + j] (A) and
-// X[m + ms][k0 + j] (B): 32 lanes read 128 contiguous bytes of ONE row, i.e. row-major operands are already in the
-// matrix-core layout.  So the operands go from global memory straight into registers: no LDS staging, no transposes and
-// no barrier in the row loop.  Each wave owns a quarter of the workgroup's rows and the whole N x K tile (NT x KT
-// accumulators of 32x32); U row pairs of loads are in flight ahead of the matrix pipe.  The four waves are summed through
-// LDS once at the end.  Column k of the virtual concatenation maps to "base + m * stride" for row-major and level-major
+// Streaming dW on the bf16 matrix pipe with fp32-equivalent results [r3].
+// dW[n][k] = sum_m dPre[m][n] X[m][k] as v_mfma_f32_32x32x16_bf16: i = n, j = k, the reduction index is the ROW.  Lane
+// (j = lane & 31, kg = lane >> 5) supplies the eight rows m0 + 8 kg .. + 7 of ONE column of each operand: a load
+// instruction covers two 128-byte (x tiles) row pieces, i.e. row-major operands stream from global memory straight into
+// the matrix-core layout -- no LDS staging, no transposes, no barrier in the row loop.  Each fp32 value is split exactly
+// into three bf16 terms (row pairs share a register) and a product is the six partial products of order <= 2^-16, smallest
+// first, accumulated in fp32 (csrc/mlp_fused.hip has the error argument: the result differs from an fp32 FMA chain by
+// fp32-roundoff-sized terms).  Six K = 16 instructions of 32 cycles replace eight K = 2 instructions of 64 cycles per
+// 16 rows and tile: 0.375x the matrix time, which takes the matrix pipe off the critical path -- the kernel is a pure
+// HBM stream.  Each wave owns a quarter of the workgroup's rows and the whole N x K tile (NT x KT accumulators of 32x32);
+// two 16-row blocks of loads are in flight ahead of the block being multiplied.  The four waves are summed through LDS
+// once at the end.  Column k of the virtual concatenation maps to "base + m * stride" for row-major and level-major
 // segments alike, so the per-lane addressing is hoisted out of the loop.
+#ifndef EMER_WGRAD_2BUF_TILES
+#define EMER_WGRAD_2BUF_TILES 9  // tiles from which only one block of loads is kept in flight (9: never)
+#endif
+
 template <int W> struct VecF;
 template <> struct VecF<1> { using T = float; };
 template <> struct VecF<2> { using T = float2; };
@@ -707,53 +719,72 @@ template <int W> __device__ __forceinline__ void vec_load(const float *p, float 
     for (int i = 0; i < W; ++i) v[i] = f[i];
 }
 
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// (a, b) -> packed bf16 pairs h, m, l with a = a_h + a_m + a_l (+ <= 2^-24 |a|); both subtractions are exact
+__device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    h = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(sa, sb);
+}
+#define EMER_MF32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
 // VEC = false: tile t of an operand holds columns 32 t + j (one dword per tile per row).
 // VEC = true : tile t holds columns T j + t (T = tiles of that operand) -- the assignment of columns to MFMA tiles is
 //              free, and with this one a lane's T columns of a row are CONTIGUOUS: one 4*T-byte load per operand per row
-//              (a wave instruction covers two full 128*T-byte row pieces) instead of T dword loads.  Needs every
-//              segment boundary and leading dimension to be a multiple of T.
-template <int NT, int KT, bool VEC>
+//              instead of T dword loads.  Needs every segment boundary and leading dimension to be a multiple of T.
+// C0 = true: column 0 of dPre is replaced by its own array (sx.col0, VEC layouts; the scalar layout redirects lane 0's pointer).
+// FULL = true: every lane's column exists (N = 32 NT, K = 32 KT): no column masks.
+template <int NT, int KT, bool VEC, bool C0, bool FULL>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
                                                            float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
                                                            int32_t rows_per_block, int want_bias) {
-    // bytes in flight decide the speed (HBM needs ~60 KB per CU): 2 x U row pairs of (NT + KT) x 256 B per wave.  The widest
-    // tiles run one wave per SIMD, so they prefetch deepest.
-    constexpr int U = (NT * KT >= 6) ? 12 : (NT * KT >= 4 ? 8 : 4), KP = KT * 32;
+    constexpr int KP = KT * 32;
     constexpr int AG = VEC ? 1 : NT, AW = VEC ? NT : 1;  // A operand: AG loads of AW floats per row
     constexpr int BG = VEC ? 1 : KT, BW = VEC ? KT : 1;
     __shared__ float red[NT * 32 * KP + NT * 32];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, ms = lane >> 5;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, kg = lane >> 5;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = (r_begin + rows_per_block < M) ? r_begin + rows_per_block : M;
     const int32_t rpw = rows_per_block >> 2;  // rows_per_block is a multiple of 32
     const int64_t w_begin = r_begin + (int64_t)wave * rpw;
     const int64_t w_end = (w_begin + rpw < r_end) ? w_begin + rpw : r_end;
 
-    // first column of load group q: VEC: q = 0, columns T j .. T j + T - 1;  scalar: column 32 q + j
+    // first column of load group q: VEC: q = 0, columns T j .. T j + T - 1;  scalar: column 32 q + j.
+    // Lanes whose column does not exist read element 0 with stride 0 and multiply by 0: no predicate (= no branch, and
+    // no generic-address-space pointer: a flat_load would force s_waitcnt vmcnt(0) and serialise the stream) on any load.
     const float *ap[AG];
     int64_t ast[AG];
-    bool aok[AG];
+    float amul[AG];
 #pragma unroll
     for (int q = 0; q < AG; ++q) {
         const int32_t n0 = VEC ? NT * j : q * 32 + j;
-        aok[q] = n0 < N;  // VEC: N is a multiple of NT (host check)
-        ap[q] = dpre + (aok[q] ? n0 : 0);
-        ast[q] = ldd;
+        const bool ok = n0 < N;  // VEC: N is a multiple of NT (host check)
+        ap[q] = dpre + (ok ? n0 : 0);
+        ast[q] = ok ? ldd : 0;
+        amul[q] = ok ? 1.0f : 0.0f;
     }
     const bool c0 = sx.col0 != nullptr && j == 0;  // column 0 of dPre comes from its own array (trunc_exp side gradient merged)
     if (!VEC && c0) { ap[0] = sx.col0; ast[0] = 1; }
     const float *bp[BG];
     int64_t bst[BG];
-    bool bok[BG];
+    float bmul[BG];
 #pragma unroll
     for (int q = 0; q < BG; ++q) {
         const int32_t kk = VEC ? KT * j : q * 32 + j;
-        bok[q] = false; bp[q] = sx.s[0].ptr; bst[q] = 0;
+        bp[q] = sx.s[0].ptr; bst[q] = 0; bmul[q] = 0.0f;
 #pragma unroll
         for (int sg = 0; sg < EMER_CHAIN_MAX_SEGS; ++sg) {
             if (sg < sx.n && kk < K && kk >= sx.s[sg].col && kk < sx.s[sg].col + sx.s[sg].width) {
                 const int32_t c = kk - sx.s[sg].col;
-                bok[q] = true;
+                bmul[q] = 1.0f;
                 if (sx.s[sg].mode == 1) {
                     const int32_t f = sx.s[sg].f, lv = c / f;
                     bp[q] = sx.s[sg].ptr + (int64_t)lv * sx.s[sg].n_total * f + (c - lv * f);
@@ -775,52 +806,139 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
 #pragma unroll
     for (int a = 0; a < NT; ++a) bsum[a] = 0.0f;
 
-    float ac[U][NT], bc[U][KT], an[U][NT], bn[U][KT];
-    auto load = [&](int64_t m0, float (&av)[U][NT], float (&bv)[U][KT]) {
+    // per-lane pointers to row 8 kg of the current block; the block loop advances them by 16 rows
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t m = m0 + 2 * u + ms;
-            const bool ok = m < w_end;
+    for (int q = 0; q < AG; ++q) ap[q] += (w_begin + 8 * kg) * ast[q];
+#pragma unroll
+    for (int q = 0; q < BG; ++q) bp[q] += (w_begin + 8 * kg) * bst[q];
+    const float *c0p = C0 ? sx.col0 + (c0 ? w_begin + 8 * kg : 0) : nullptr;  // other lanes re-read element 0 (unused)
+    const int64_t c0st = c0 ? 1 : 0;
+    // one 16-row block of both operands: rows m0 + 8 kg + r
+    struct Blk { float a[8][NT], b[8][KT], c[C0 ? 8 : 1]; };
+    // `ahead` blocks past the pointers.  tail = true_type (last block of a ragged range only): rows past w_end re-read
+    // the last valid row and are multiplied by 0.
+    auto load = [&](auto tail, int64_t m0, int ahead, Blk &v) {
+        constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool ok = !TAIL || m0 + 8 * kg + r < w_end;
+            const int64_t dr = ok ? (int64_t)(16 * ahead + r) : w_end - 1 - (m0 + 8 * kg);
+            const float rmul = ok ? 1.0f : 0.0f;
 #pragma unroll
             for (int q = 0; q < AG; ++q) {
-                float v[AW];
+                float t[AW];
+                vec_load<AW>(ap[q] + dr * ast[q], t);
 #pragma unroll
-                for (int i = 0; i < AW; ++i) v[i] = 0.0f;
-                if (ok && aok[q]) vec_load<AW>(ap[q] + m * ast[q], v);
-#pragma unroll
-                for (int i = 0; i < AW; ++i) av[u][q * AW + i] = v[i];
+                for (int i = 0; i < AW; ++i) {
+                    if (!FULL) t[i] *= amul[q];
+                    if (TAIL) t[i] *= rmul;
+                    v.a[r][q * AW + i] = t[i];
+                }
             }
-            if (VEC && c0 && ok) av[u][0] = sx.col0[m];
+            if constexpr (VEC && C0) v.c[r] = c0p[dr * c0st] * (TAIL ? rmul : 1.0f);  // merged at use (no wait inside the load burst)
 #pragma unroll
             for (int q = 0; q < BG; ++q) {
-                float v[BW];
+                float t[BW];
+                vec_load<BW>(bp[q] + dr * bst[q], t);
 #pragma unroll
-                for (int i = 0; i < BW; ++i) v[i] = 0.0f;
-                if (ok && bok[q]) vec_load<BW>(bp[q] + m * bst[q], v);
-#pragma unroll
-                for (int i = 0; i < BW; ++i) bv[u][q * BW + i] = v[i];
+                for (int i = 0; i < BW; ++i) {
+                    if (!FULL) t[i] *= bmul[q];
+                    if (TAIL) t[i] *= rmul;
+                    v.b[r][q * BW + i] = t[i];
+                }
             }
         }
     };
-    load(w_begin, ac, bc);
-    for (int64_t m0 = w_begin; m0 < w_end; m0 += 2 * U) {
-        load(m0 + 2 * U, an, bn);  // predicated off past the end
+    auto advance = [&](int blocks) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int q = 0; q < AG; ++q) ap[q] += 16 * blocks * ast[q];
 #pragma unroll
-            for (int a = 0; a < NT; ++a) {
+        for (int q = 0; q < BG; ++q) bp[q] += 16 * blocks * bst[q];
+        c0p += 16 * blocks * c0st;
+    };
+    auto mult = [&](const Blk &v) {
+        u32x4 ah[NT], am[NT], al[NT];
 #pragma unroll
-                for (int b = 0; b < KT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][a], bc[u][b], acc[a][b], 0, 0, 0);
-                bsum[a] += ac[u][a];
+        for (int a = 0; a < NT; ++a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x0 = v.a[2 * q][a], x1 = v.a[2 * q + 1][a];
+                if constexpr (VEC && C0) {
+                    if (a == 0 && c0) { x0 = v.c[2 * q]; x1 = v.c[2 * q + 1]; }
+                }
+                unsigned h, m, l;
+                split3(x0, x1, h, m, l);
+                ah[a][q] = h; am[a][q] = m; al[a][q] = l;
+                bsum[a] += x0 + x1;
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int b = 0; b < KT; ++b) {
+            u32x4 bh, bm, bl;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ac[u][t] = an[u][t];
+            for (int q = 0; q < 4; ++q) {
+                unsigned h, m, l;
+                split3(v.b[2 * q][b], v.b[2 * q + 1][b], h, m, l);
+                bh[q] = h; bm[q] = m; bl[q] = l;
+            }
 #pragma unroll
-            for (int t = 0; t < KT; ++t) bc[u][t] = bn[u][t];
+            for (int a = 0; a < NT; ++a) {
+                acc[a][b] = EMER_MF32(al[a], bh, acc[a][b]);
+                acc[a][b] = EMER_MF32(ah[a], bl, acc[a][b]);
+                acc[a][b] = EMER_MF32(am[a], bm, acc[a][b]);
+                acc[a][b] = EMER_MF32(am[a], bh, acc[a][b]);
+                acc[a][b] = EMER_MF32(ah[a], bm, acc[a][b]);
+                acc[a][b] = EMER_MF32(ah[a], bh, acc[a][b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one operand tile of splits live at a time
         }
+    };
+    // Full blocks stream with one block of loads in flight ahead of the one in the matrix pipe (two for small tiles,
+    // whose accumulators leave room); the ragged remainder (< 16 rows, last workgroup only) takes the predicated path.
+    // Every load of the steady state is UNCONDITIONAL (past the end the last block is simply read again): a load under a
+    // branch merges with the buffer's previous contents, and hipcc then copies the loaded registers right behind the
+    // load burst and waits for it -- the stream degenerates to load, wait, multiply.
+    const int64_t n_full = w_end > w_begin ? (w_end - w_begin) >> 4 : 0;
+    const int64_t m_tail = w_begin + 16 * n_full;
+    constexpr std::false_type kFull{};
+    constexpr std::true_type kTail{};
+    if (n_full > 0) {
+        const int64_t last = n_full - 1;
+        auto ahead = [&](int64_t i, int d) { return (int)((i + d <= last ? i + d : last) - i); };  // blocks past the pointers (clamped)
+        int64_t i = 0;
+        if constexpr (NT * KT >= EMER_WGRAD_2BUF_TILES) {
+            Blk v0, v1;
+            load(kFull, 0, 0, v0);
+            for (; i + 1 < n_full; i += 2) {
+                load(kFull, 0, 1, v1);
+                mult(v0);
+                load(kFull, 0, ahead(i, 2), v0);
+                mult(v1);
+                advance(2);
+            }
+            if (i < n_full) { mult(v0); advance(1); }
+        } else {
+            Blk v0, v1, v2;
+            load(kFull, 0, 0, v0);
+            load(kFull, 0, ahead(0, 1), v1);
+            for (; i + 2 < n_full; i += 3) {
+                load(kFull, 0, 2, v2);
+                mult(v0);
+                load(kFull, 0, ahead(i, 3), v0);
+                mult(v1);
+                load(kFull, 0, ahead(i, 4), v1);
+                mult(v2);
+                advance(3);
+            }
+            if (i < n_full) mult(v0);
+            if (i + 1 < n_full) mult(v1);
+            advance((int)(n_full - i));
+        }
+    }
+    if (m_tail < w_end) {
+        Blk vt;
+        load(kTail, m_tail, 0, vt);
+        mult(vt);
     }
     // ---- sum the four waves through LDS (wave 0 writes, 1..3 add in turn), then one coalesced store of the partial.
     // red is indexed by ACTUAL (n, k): tile (a, b), element (i, j)  ->  VEC: n = NT i + a, k = KT j + b;  else n = 32 a + i, k = 32 b + j
@@ -834,13 +952,13 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
                 for (int b = 0; b < KT; ++b) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
-                        const int i = (v & 3) + 8 * (v >> 2) + 4 * ms;
+                        const int i = (v & 3) + 8 * (v >> 2) + 4 * kg;
                         const int n = VEC ? NT * i + a : a * 32 + i, k = VEC ? KT * j + b : b * 32 + j;
                         float *q = red + n * KP + k;
                         *q = (w == 0) ? acc[a][b][v] : *q + acc[a][b][v];
                     }
                 }
-                if (ms == 0) {
+                if (kg == 0) {
                     float *q = red + NT * 32 * KP + (VEC ? NT * j + a : a * 32 + j);
                     *q = (w == 0) ? bsum[a] : *q + bsum[a];
                 }
@@ -936,13 +1054,17 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
                   (S.mode == 1 ? (S.f % KTv == 0) : (S.ld % KTv == 0));
         }
         if (vec) KT = KTv;
-#define EMER_WS(A, B) do { if (vec) hipLaunchKernelGGL((wgrad_stream_kernel<A, B, true>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0); \
-                           else hipLaunchKernelGGL((wgrad_stream_kernel<A, B, false>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0); } while (0)
-#define EMER_WS3(A) hipLaunchKernelGGL((wgrad_stream_kernel<A, 3, false>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+        const bool full = vec && n == 32 * NT && k == 32 * KT;  // every lane owns real columns: no masks
+#define EMER_WSL(A, B, V, C, F) hipLaunchKernelGGL((wgrad_stream_kernel<A, B, V, C, F>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+#define EMER_WS(A, B) do { if (vec && col0 && full) EMER_WSL(A, B, true, true, true); else if (vec && col0) EMER_WSL(A, B, true, true, false); \
+                           else if (vec && full) EMER_WSL(A, B, true, false, true); else if (vec) EMER_WSL(A, B, true, false, false); \
+                           else EMER_WSL(A, B, false, false, false); } while (0)
+#define EMER_WS3(A) EMER_WSL(A, 3, false, false, false)
         if (NT == 1) { if (KT == 1) EMER_WS(1, 1); else if (KT == 2) EMER_WS(1, 2); else if (KT == 3) EMER_WS3(1); else EMER_WS(1, 4); }
         else         { if (KT == 1) EMER_WS(2, 1); else if (KT == 2) EMER_WS(2, 2); else if (KT == 3) EMER_WS3(2); else EMER_WS(2, 4); }
 #undef EMER_WS
 #undef EMER_WS3
+#undef EMER_WSL
         if (int rc = check_launch("wgrad_stream")) return rc;
         const int64_t stride = (int64_t)n * k + n;
         hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st,

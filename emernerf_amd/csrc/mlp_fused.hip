@@ -3,15 +3,28 @@
 // data-gradient chains.  Replaces the nn.Sequential / mlp.MLP stacks of radiance_field.py:74-198,808-840 and
 // mlp.py:7-46 on the per-sample hot path.
 //
-// Transposed chaining.  Every layer is computed as Y^T = W X^T on v_mfma_f32_16x16x4_f32 with the WEIGHTS as the
-// A operand (lane (n = lane & 15, g = lane >> 4) supplies W[16t'+n][k]) and the ACTIVATIONS as the B operand (lane
-// (m = lane & 15, g) supplies X[m][k]).  The 16x16 result tile t' leaves lane (m, g) holding features
-// 16t' + 4g + i (i = 0..3) of row m -- which is exactly a legal B operand of the next layer if its reduction
-// index is enumerated as k = 16t + 4g + i (any bijection of k is a valid GEMM as long as A uses the same one).
-// So a wave owns 16 rows END TO END in registers: no activation ever touches LDS, there is no barrier after the
-// weights are staged, and occupancy is bounded by VGPRs (~100) instead of a 16 KB-per-wave LDS row buffer.
-// LDS holds only the weights, row-major [n][kpad + 4]: one ds_read_b128 per (t', t) yields the A operands of four
-// MFMA steps, and the +4 pitch spreads the 16 rows of a read over all 64 banks.
+// Transposed chaining.  Every layer is computed as Y^T = W X^T with the WEIGHTS as the MFMA A operand and the
+// ACTIVATIONS as the B operand.  A 16x16 result tile t' leaves lane (m = lane & 15, g = lane >> 4) holding features
+// 16t' + 4g + i (i = 0..3) of row m -- which is a legal B operand of the next layer if its reduction index is
+// enumerated in that order (any bijection of k is a valid GEMM as long as A uses the same one).  So a wave owns 16
+// rows END TO END in registers: no activation ever touches LDS, there is no barrier after the weights are staged, and
+// occupancy is bounded by VGPRs instead of a 16 KB-per-wave LDS row buffer.
+//
+// Arithmetic [r3]: fp32 results on the bf16 matrix pipe.  gfx950's f32-input MFMA runs at the fp32 VECTOR rate (157
+// TFLOP/s, 1/16 of the bf16 rate) and was the wall of round 2 (heads at 42-58 % of that peak).  Every fp32 operand is
+// split EXACTLY into three bf16 terms, x = x_h + x_m + x_l (|x_m| <= 2^-8 |x|, |x_l| <= 2^-16 |x|, remainder <= 2^-24 |x|:
+// three 8-bit significands cover fp32's 24), and a product is evaluated as the six bf16 x bf16 partial products of
+// order <= 2^-16 -- w_l x_h, w_h x_l, w_m x_m, w_m x_h, w_h x_m, w_h x_h, smallest first -- on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  bf16 x bf16 is exact in fp32; the dropped terms (w_m x_l, w_l x_m,
+// w_l x_l) are <= 2^-23 relative per product, i.e. the result differs from an fp32 FMA chain by fp32-roundoff-sized
+// errors (tests: same tolerances as the fp32 kernels of round 2, 1e-4 forward / 2e-4 gradients vs fp64).  Six K = 32
+// instructions of 16 cycles replace eight K = 4 instructions of 32 cycles: 0.375x the matrix time.  Non-finite inputs
+// give NaN (inf - inf in the split) where an fp32 product would give inf.
+//
+// LDS holds only the weights, pre-split and FRAGMENT-MAJOR: fragment (p, s) = the A operand of output tile p, k-step
+// s is 64 lanes x 16 B contiguous, so one conflict-free ds_read_b128 per split yields an operand.  The k enumeration
+// of k-step s: lane group g, element j = 0..7  <->  feature 32 s + 16 (j >> 2) + 4 g + (j & 3), i.e. two consecutive
+// result tiles of the previous layer.
 //
 // Global traffic is the algorithmic minimum: each lane loads / stores 16 B pieces (row-major tensors: the four g
 // lanes of a row cover 64 contiguous bytes; level-major grid encodings: 16 lanes cover 16 consecutive rows of one
@@ -38,47 +51,109 @@ struct WSrc {
     int32_t n, k;    // real extents (zero padded in LDS)
 };
 
-__device__ __forceinline__ void stage_w(float *dst, int pitch, int npad, int kpad, const WSrc s) {
-    for (int idx = threadIdx.x; idx < npad * kpad; idx += (int)blockDim.x) {
-        const int n = idx / kpad, k = idx - n * kpad;
-        dst[n * pitch + k] = (n < s.n && k < s.k) ? s.w[n * s.sn + k * s.sk] : 0.0f;
+// ---- bf16x3 operands ---------------------------------------------------------------------------------------------
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+// (a, b) -> packed bf16 pairs h, m, l with a = a_h + a_m + a_l (+ <= 2^-24 |a|); both subtractions are exact
+__device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+    h = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(sa, sb);
+}
+
+// B operand (activations) of KS k-steps: lane (m, g) holds, for k-step s, features 32 s + 16 (j >> 2) + 4 g + (j & 3)
+template <int KS> struct Opd { u32x4 h[KS], m[KS], l[KS]; };
+
+template <int KT>
+__device__ __forceinline__ void make_opd(const f32x4 (&in)[KT], Opd<(KT + 1) / 2> &o) {
+#pragma unroll
+    for (int s = 0; s < (KT + 1) / 2; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 2 * s + (q >> 1), e = 2 * (q & 1);
+            if (t < KT) {
+                unsigned h, m, l;
+                split3(in[t][e], in[t][e + 1], h, m, l);
+                o.h[s][q] = h; o.m[s][q] = m; o.l[s][q] = l;
+            } else {
+                o.h[s][q] = 0u; o.m[s][q] = 0u; o.l[s][q] = 0u;
+            }
+        }
     }
 }
+
+// Weights in LDS: three split planes of np x ks fragments (64 lanes x 16 B each).
+constexpr int w3_units(int np, int ks) { return 3 * np * ks * 64; }  // u32x4 units
+struct W3 { const u32x4 *p; int ks, plane; };  // p: this lane's entry of fragment (0, 0) in the h plane; plane = np * ks * 64
+
+// Stage the (zero padded) matrix of `s` as np output tiles x ks k-steps.
+__device__ __forceinline__ void stage_w3(u32x4 *dst, int np, int ks, const WSrc s) {
+    const int plane = np * ks * 64;
+    for (int idx = threadIdx.x; idx < plane; idx += (int)blockDim.x) {
+        const int lane = idx & 63, fs = idx >> 6, p = fs / ks, st = fs - p * ks;
+        const int n = 16 * p + (lane & 15), g = lane >> 4;
+        u32x4 h, m, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 32 * st + 16 * (q >> 1) + 4 * g + 2 * (q & 1);
+            const float v0 = (n < s.n && c < s.k) ? s.w[n * s.sn + c * s.sk] : 0.0f;
+            const float v1 = (n < s.n && c + 1 < s.k) ? s.w[n * s.sn + (c + 1) * s.sk] : 0.0f;
+            unsigned hh, mm, ll;
+            split3(v0, v1, hh, mm, ll);
+            h[q] = hh; m[q] = mm; l[q] = ll;
+        }
+        dst[idx] = h; dst[plane + idx] = m; dst[2 * plane + idx] = l;
+    }
+}
+__device__ __forceinline__ W3 w3_at(const u32x4 *base, int np, int ks, int lane) { return W3{base + lane, ks, np * ks * 64}; }
+// the same matrix from output tile p0 on
+__device__ __forceinline__ W3 w3_tile(const W3 w, int p0) { return W3{w.p + p0 * w.ks * 64, w.ks, w.plane}; }
+
 __device__ __forceinline__ void stage_b(float *dst, int npad, const float *b, int n) {
     for (int i = threadIdx.x; i < npad; i += (int)blockDim.x) dst[i] = (b && i < n) ? b[i] : 0.0f;
 }
 
-// acc[p] (output tile p) += sum over input tiles t, steps i of W[16p + n][16t + 4g + i] * in[t][i]
-// wl already points at this lane's (n = lane & 15, 4 * g) corner of the LDS matrix.
-template <int KT, int NT, bool PIPE = true>
-__device__ __forceinline__ void tgemm(const float *wl, int pitch, const f32x4 (&in)[KT], f32x4 (&acc)[NT]) {
-    // PIPE: software pipelined by hand -- the A fragments of input tile t + 1 are read while tile t is in the matrix
-    // pipe (two fragment sets used alternately, no register rotation).  !PIPE: one fragment set (16 VGPRs less), for
-    // kernels that hide the LDS latency with a fourth wave per SIMD instead.  Either way the scheduling barrier keeps
-    // the compiler from hoisting ALL weight reads of the chain (it would otherwise trade ~100 VGPRs of fragments for
-    // latency it does not need to hide -- several waves share the SIMD).
-    f32x4 a[PIPE ? 2 : 1][NT];
-    if (PIPE) {
+#define EMER_MF(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+// acc[p] (output tile p) += W[16p .. 16p+15][:] . in, fp32-equivalent (six bf16 partial products, smallest first).
+// Two output tiles are interleaved so that consecutive instructions hit different accumulators; the scheduling barrier
+// keeps the compiler from hoisting all weight reads of a chain (it would trade ~100 VGPRs for latency that the other
+// waves of the SIMD already hide).
+template <int KS, int NT, bool PAIR = true>
+__device__ __forceinline__ void tgemm(const W3 w, const Opd<KS> &b, f32x4 (&acc)[NT]) {
 #pragma unroll
-        for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch);
-    }
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (PIPE) {
-            if (t + 1 < KT) {
-#pragma unroll
-                for (int p = 0; p < NT; ++p) a[(t + 1) & 1][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + (t + 1) * 16);
+        for (int p = 0; p < NT; p += (PAIR ? 2 : 1)) {
+            const u32x4 *f0 = w.p + (p * w.ks + s) * 64;
+            if (PAIR && p + 1 < NT) {
+                const u32x4 *f1 = f0 + w.ks * 64;
+                const u32x4 l0 = f0[2 * w.plane], l1 = f1[2 * w.plane], h0 = f0[0], h1 = f1[0], m0 = f0[w.plane], m1 = f1[w.plane];
+                acc[p] = EMER_MF(l0, b.h[s], acc[p]); acc[p + 1] = EMER_MF(l1, b.h[s], acc[p + 1]);
+                acc[p] = EMER_MF(h0, b.l[s], acc[p]); acc[p + 1] = EMER_MF(h1, b.l[s], acc[p + 1]);
+                acc[p] = EMER_MF(m0, b.m[s], acc[p]); acc[p + 1] = EMER_MF(m1, b.m[s], acc[p + 1]);
+                acc[p] = EMER_MF(m0, b.h[s], acc[p]); acc[p + 1] = EMER_MF(m1, b.h[s], acc[p + 1]);
+                acc[p] = EMER_MF(h0, b.m[s], acc[p]); acc[p + 1] = EMER_MF(h1, b.m[s], acc[p + 1]);
+                acc[p] = EMER_MF(h0, b.h[s], acc[p]); acc[p + 1] = EMER_MF(h1, b.h[s], acc[p + 1]);
+            } else {
+                const u32x4 l0 = f0[2 * w.plane], h0 = f0[0], m0 = f0[w.plane];
+                acc[p] = EMER_MF(l0, b.h[s], acc[p]);
+                acc[p] = EMER_MF(h0, b.l[s], acc[p]);
+                acc[p] = EMER_MF(m0, b.m[s], acc[p]);
+                acc[p] = EMER_MF(m0, b.h[s], acc[p]);
+                acc[p] = EMER_MF(h0, b.m[s], acc[p]);
+                acc[p] = EMER_MF(h0, b.h[s], acc[p]);
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < NT; ++p) a[0][p] = *reinterpret_cast<const f32x4 *>(wl + p * 16 * pitch + t * 16);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int p = 0; p < NT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[PIPE ? (t & 1) : 0][p][i], in[t][i], acc[p], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -191,16 +266,17 @@ struct NeckFwdArgs {
 // NT1 = output tiles of the second layer: 4 (64 features), 8 (128 features), 1 (density only: 1 feature -> trunc_exp)
 template <int KT0, int F, int NT1>
 __global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int P0 = KT0 * 16 + 4, P1 = 64 + 4;
-    float *w0l = smem, *w1l = w0l + 64 * P0, *b0l = w1l + NT1 * 16 * P1, *b1l = b0l + 64;
-    stage_w(w0l, P0, 64, KT0 * 16, a.w0);
-    stage_w(w1l, P1, NT1 * 16, 64, a.w1);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int KS0 = (KT0 + 1) / 2;
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(4, KS0);
+    float *b0l = reinterpret_cast<float *>(w1l + w3_units(NT1, 2)), *b1l = b0l + 64;
+    stage_w3(w0l, 4, KS0, a.w0);
+    stage_w3(w1l, NT1, 2, a.w1);
     stage_b(b0l, 64, a.b0, a.w0.n);
     stage_b(b1l, NT1 * 16, a.b1, a.w1.n);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const float *w0p = w0l + m * P0 + 4 * g, *w1p = w1l + m * P1 + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0p = w3_at(w0l, 4, KS0, lane), w1p = w3_at(w1l, NT1, 2, lane);
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
     for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int64_t t0 = c * kNeckChunk;
@@ -213,26 +289,30 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArg
 #pragma unroll
             for (int t = 0; t < KT0; ++t) x[t] = xn[t];
             if (j + 1 < kNeckChunk && t0 + j + 1 < n_tiles) ld_lm<KT0, F>(a.enc, a.n, a.n_levels, row + 16, row + 16 < a.n, g, xn);
+            Opd<KS0> xo;
+            make_opd<KT0>(x, xo);
             f32x4 h[4];
             init_bias<4>(b0l, g, h);
-            tgemm<KT0, 4>(w0p, P0, x, h);
+            tgemm<KS0, 4>(w0p, xo, h);
             relu<4>(h);
             if (a.h1) st_rm<4>(a.h1 + row * 64, ok, g, h);
+            Opd<2> ho;
+            make_opd<4>(h, ho);
             if constexpr (NT1 == 1) {
                 f32x4 o[1];
                 init_bias<1>(b1l, g, o);
-                tgemm<4, 1>(w1p, P1, h, o);
+                tgemm<2, 1>(w1p, ho, o);
                 if (ok && g == 0) a.dens[row] = expf(o[0][0] - 1.0f);
             } else {
                 // 64 output features at a time (16 live accumulators instead of 32)
                 f32x4 o[4];
                 init_bias<4>(b1l, g, o);
-                tgemm<4, 4>(w1p, P1, h, o);
+                tgemm<2, 4>(w1p, ho, o);
                 st_rm<4>(a.out0 + row * 64, ok, g, o);
                 if (a.dens && ok && g == 0) a.dens[row] = expf(o[0][0] - 1.0f);
                 if constexpr (NT1 == 8) {
                     init_bias<4>(b1l + 64, g, o);
-                    tgemm<4, 4>(w1p + 64 * P1, P1, h, o);
+                    tgemm<2, 4>(w3_tile(w1p, 4), ho, o);
                     st_rm<4>(a.out1 + row * 64, ok, g, o);
                 }
             }
@@ -258,15 +338,21 @@ struct NeckBwdArgs {
 // KT1 = input tiles of the transposed second layer: 4 / 8 (neck), 0 (density mode: rank-1, no MFMA)
 template <int KT0, int F, int KT1>
 __global__ __launch_bounds__(kNThreads, 4) void neck_bwd_kernel(const NeckBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K1 = (KT1 == 0 ? 1 : KT1) * 16;
-    constexpr int P1 = K1 + 4, P0 = 64 + 4;
-    float *w1l = smem, *w0l = w1l + 64 * P1;
-    stage_w(w1l, P1, 64, K1, a.w1t);
-    stage_w(w0l, P0, KT0 * 16, 64, a.w0t);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int KS1 = KT1 / 2;  // k-steps of the transposed second layer (0: density mode, W1 is one fp32 row)
+    constexpr int KS1e = KS1 > 0 ? KS1 : 1;
+    static_assert(KT1 == 0 || KT1 == 4 || KT1 == 8, "neck_bwd: 0, 64 or 128 gradient columns");
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2);
+    float *w1v = reinterpret_cast<float *>(w1l);  // density mode: W1[0][0..63]
+    stage_w3(w0l, KT0, 2, a.w0t);
+    if constexpr (KT1 == 0) {
+        for (int i = threadIdx.x; i < 64; i += (int)blockDim.x) w1v[i] = a.w1t.w[i * a.w1t.sn];
+    } else {
+        stage_w3(w1l, 4, KS1, a.w1t);
+    }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const float *w1p = w1l + m * P1 + 4 * g, *w0p = w0l + m * P0 + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, KS1e, lane);
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
     for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int64_t t0 = c * kNeckChunk;
@@ -284,9 +370,10 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_bwd_kernel(const NeckBwdArg
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) da[p][i] = w1l[(16 * p + 4 * g + i) * P1] * fix;
+                    for (int i = 0; i < 4; ++i) da[p][i] = w1v[16 * p + 4 * g + i] * fix;
             } else {
-                f32x4 d[KT1];
+                // 64 gradient columns (two k-steps) at a time: one operand set live
+                zero<4>(da);
                 {
                     f32x4 lo[4];
                     if (a.d0) ld_rm<4>(a.d0 + row * 64, ok, g, lo); else zero<4>(lo);
@@ -294,23 +381,25 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_bwd_kernel(const NeckBwdArg
                         lo[0][0] += fix;
                         if (a.dcol0 && ok) a.dcol0[row] = lo[0][0];
                     }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) d[p] = lo[p];
+                    Opd<2> dop;
+                    make_opd<4>(lo, dop);
+                    tgemm<2, 4>(w1p, dop, da);
                 }
                 if constexpr (KT1 == 8) {
                     f32x4 hi[4];
                     ld_rm<4>(a.d1 + row * 64, ok, g, hi);
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) d[4 + p] = hi[p];
+                    Opd<2> dop;
+                    make_opd<4>(hi, dop);
+                    tgemm<2, 4>(W3{w1p.p + 2 * 64, w1p.ks, w1p.plane}, dop, da);  // k-steps 2, 3
                 }
-                zero<4>(da);
-                tgemm<KT1, 4>(w1p, P1, d, da);
             }
             relu_mask<4>(da, mk);
             st_rm<4>(a.dpre0 + row * 64, ok, g, da);
+            Opd<2> dao;
+            make_opd<4>(da, dao);
             f32x4 de[KT0];
             zero<KT0>(de);
-            tgemm<4, KT0>(w0p, P0, da, de);
+            tgemm<2, KT0>(w0p, dao, de);
             st_lm<KT0, F>(a.denc, a.n, a.n_levels, row, ok, g, de);
         }
     }
@@ -327,47 +416,57 @@ struct RgbFwdArgs {
 };
 
 __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int P = 64 + 4;
-    float *w0l = smem, *w1al = w0l + 64 * P, *w1gl = w1al + 64 * P, *w2l = w1gl + 64 * P, *b2l = w2l + 16 * P;
-    stage_w(w0l, P, 64, 64, a.w0g);
-    stage_w(w1al, P, 64, 64, a.w1a);
-    stage_w(w1gl, P, 64, 64, a.w1g);
-    stage_w(w2l, P, 16, 64, a.w2);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    u32x4 *w0l = smem, *w1al = w0l + w3_units(4, 2), *w1gl = w1al + w3_units(4, 2), *w2l = w1gl + w3_units(4, 2);
+    float *b2l = reinterpret_cast<float *>(w2l + w3_units(1, 2));
+    stage_w3(w0l, 4, 2, a.w0g);
+    stage_w3(w1al, 4, 2, a.w1a);
+    stage_w3(w1gl, 4, 2, a.w1g);
+    stage_w3(w2l, 1, 2, a.w2);
     stage_b(b2l, 16, a.b2, a.w2.n);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const int off = m * P + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0p = w3_at(w0l, 4, 2, lane), w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w2p = w3_at(w2l, 1, 2, lane);
     const int tpr = a.tiles_per_ray;
+    // Addressing: the ray is wave-uniform, so every tensor gets ONE scalar base per ray and the lanes share 32-bit
+    // offsets (SGPR base + VGPR offset loads / stores) instead of a 64-bit pointer pair per tensor.
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
     for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         // the per-ray pre-activations are re-read for every tile (L1/L2 hits) instead of living in 32 VGPRs for the
         // whole ray: the kernel then fits 128 VGPRs = 4 waves per SIMD
-        const float *rb0 = a.rb0 + ray * a.ld_rb, *rb1 = a.rb1 + ray * a.ld_rb;
-        const int64_t row_base = ray * tpr * 16 + m;
-        f32x4 xn[4];
-        ld_rm<4>(a.geo + row_base * a.ld_geo, true, g, xn);
+        const float *rb0 = a.rb0 + ray * a.ld_rb + 4 * g, *rb1 = a.rb1 + ray * a.ld_rb + 4 * g;
+        const int64_t row0 = ray * tpr * 16;
+        const float *geo = a.geo + row0 * a.ld_geo;
+        float *a1 = a.a1 + row0 * 64, *a2 = a.a2 + row0 * 64, *outp = a.out + row0 * 3;
         for (int j = 0; j < tpr; ++j) {
-            const int64_t row = row_base + (int64_t)j * 16;
             f32x4 x[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) x[t] = xn[t];
-            if (j + 1 < tpr) ld_rm<4>(a.geo + (row + 16) * a.ld_geo, true, g, xn);
+            for (int p = 0; p < 4; ++p) x[p] = *reinterpret_cast<const f32x4 *>(geo + (log + (unsigned)j * 16u * (unsigned)a.ld_geo + 16u * p));
+            Opd<2> xo;
+            make_opd<4>(x, xo);
             f32x4 h[4];
-            ld_rm<4>(rb0, true, g, h);
-            tgemm<4, 4, false>(w0l + off, P, x, h);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = *reinterpret_cast<const f32x4 *>(rb0 + 16 * p);
+            tgemm<2, 4, false>(w0p, xo, h);
             relu<4>(h);
-            st_rm<4>(a.a1 + row * 64, true, g, h);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a1 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h[p];
             f32x4 h2[4];
-            ld_rm<4>(rb1, true, g, h2);
-            tgemm<4, 4, false>(w1gl + off, P, x, h2);   // geo part first: x dies here
-            tgemm<4, 4, false>(w1al + off, P, h, h2);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h2[p] = *reinterpret_cast<const f32x4 *>(rb1 + 16 * p);
+            tgemm<2, 4, false>(w1gp, xo, h2);   // geo part first: its operand dies here
+            Opd<2> ho;
+            make_opd<4>(h, ho);
+            tgemm<2, 4, false>(w1ap, ho, h2);
             relu<4>(h2);
-            st_rm<4>(a.a2 + row * 64, true, g, h2);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
+            make_opd<4>(h2, ho);
             f32x4 o[1];
             init_bias<1>(b2l, g, o);
-            tgemm<4, 1, false>(w2l + off, P, h2, o);
+            tgemm<2, 1>(w2p, ho, o);
             if (g == 0) {
-                float *op = a.out + row * 3;
+                float *op = outp + ((unsigned)j * 48u + 3u * m);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) op[i] = 1.0f / (1.0f + expf(-o[0][i]));
             }
@@ -386,60 +485,81 @@ struct RgbBwdArgs {
     float *s1, *s0;                    // [rays][64] sums of dpre1 / dpre0 over the samples of each ray
 };
 
-__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes that share g (a DPP row)
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes that share g (a DPP row); every lane gets it
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror: quad q <-> quad q ^ 1
+    v += dpp_mov<0x140>(v);  // row_mirror: lower eight <-> upper eight
     return v;
 }
 
 __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int P = 64 + 4, P2 = 16 + 4;
-    float *w2l = smem, *w1al = w2l + 64 * P2, *w1gl = w1al + 64 * P, *w0l = w1gl + 64 * P;
-    stage_w(w2l, P2, 64, 16, a.w2t);
-    stage_w(w1al, P, 64, 64, a.w1at);
-    stage_w(w1gl, P, 64, 64, a.w1gt);
-    stage_w(w0l, P, 64, 64, a.w0gt);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
+    stage_w3(w1al, 4, 2, a.w1at);
+    stage_w3(w1gl, 4, 2, a.w1gt);
+    stage_w3(w0l, 4, 2, a.w0gt);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const int off = m * P + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w0p = w3_at(w0l, 4, 2, lane);
+    // W2^T (64 x 3) stays in four registers: the K = 4 step of v_mfma_f32_16x16x4_f32 covers the three colour channels
+    // exactly (lane (n, g) supplies W2[g][16 p + n]), so the first backward layer is four exact-fp32 instructions per
+    // tile and costs no LDS.
+    float w2a[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
     const int tpr = a.tiles_per_ray;
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), lo3 = (unsigned)(3 * m + g);
     for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         f32x4 s1[4], s0[4];
         zero<4>(s1); zero<4>(s0);
-        const int64_t row_base = ray * tpr * 16 + m;
+        const int64_t row0 = ray * tpr * 16;   // wave-uniform: one scalar base per tensor, 32-bit lane offsets
+        const float *a1 = a.a1 + row0 * 64, *a2 = a.a2 + row0 * 64, *outp = a.out + row0 * 3, *doutp = a.dout + row0 * 3;
+        float *dpre2 = a.dpre2 + row0 * 3, *dpre1 = a.dpre1 + row0 * 64, *dpre0 = a.dpre0 + row0 * 64, *dgeo = a.dgeo + row0 * 64;
         for (int j = 0; j < tpr; ++j) {
-            const int64_t row = row_base + (int64_t)j * 16;
-            f32x4 m2[4];
-            ld_rm<4>(a.a2 + row * 64, true, g, m2);
-            f32x4 d2[1];
-            d2[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (g == 0) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float y = a.out[row * 3 + i];
-                    d2[0][i] = a.dout[row * 3 + i] * y * (1.0f - y);  // sigmoid'
-                    a.dpre2[row * 3 + i] = d2[0][i];
-                }
+            const unsigned o64 = lo64 + (unsigned)j * 1024u, o3 = lo3 + (unsigned)j * 48u;
+            float d2 = 0.0f;  // lane (m, g): channel g of row m
+            if (g < 3) {
+                const float y = outp[o3];
+                d2 = doutp[o3] * y * (1.0f - y);  // sigmoid'
+                dpre2[o3] = d2;
             }
             f32x4 d1[4];
             zero<4>(d1);
-            tgemm<1, 4, false>(w2l + m * P2 + 4 * g, P2, d2, d1);
-            relu_mask<4>(d1, m2);
-            st_rm<4>(a.dpre1 + row * 64, true, g, d1);
-            f32x4 m1[4];  // loaded here (behind tgemm's scheduling barrier): its live range does not overlap a2's mask
-            ld_rm<4>(a.a1 + row * 64, true, g, m1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
+            {
+                f32x4 m2[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) m2[p] = *reinterpret_cast<const f32x4 *>(a2 + (o64 + 16u * p));
+                relu_mask<4>(d1, m2);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { *reinterpret_cast<f32x4 *>(dpre1 + (o64 + 16u * p)) = d1[p]; s1[p] += d1[p]; }
+            Opd<2> d1o;
+            make_opd<4>(d1, d1o);
             f32x4 d0[4];
             zero<4>(d0);
-            tgemm<4, 4, false>(w1al + off, P, d1, d0);
-            relu_mask<4>(d0, m1);
-            st_rm<4>(a.dpre0 + row * 64, true, g, d0);
+            tgemm<2, 4, false>(w1ap, d1o, d0);
+            {
+                f32x4 m1[4];  // loaded behind tgemm's scheduling barrier: the mask is not live across the GEMM (other waves hide the latency)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) m1[p] = *reinterpret_cast<const f32x4 *>(a1 + (o64 + 16u * p));
+                relu_mask<4>(d0, m1);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { *reinterpret_cast<f32x4 *>(dpre0 + (o64 + 16u * p)) = d0[p]; s0[p] += d0[p]; }
             f32x4 dg[4];
             zero<4>(dg);
-            tgemm<4, 4, false>(w1gl + off, P, d1, dg);
-            tgemm<4, 4, false>(w0l + off, P, d0, dg);
-            st_rm<4>(a.dgeo + row * 64, true, g, dg);
+            tgemm<2, 4, false>(w1gp, d1o, dg);
+            make_opd<4>(d0, d1o);
+            tgemm<2, 4, false>(w0p, d1o, dg);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { s1[p] += d1[p]; s0[p] += d0[p]; }
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo + (o64 + 16u * p)) = dg[p];
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -500,19 +620,19 @@ __device__ __forceinline__ void st_narrow(float *rowp, bool ok, int g, int n_val
 
 template <int KT0, int F, int NL, int NTO>
 __global__ __launch_bounds__(kNThreads, 4) void rmlp_fwd_kernel(const RMlpFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int P0 = KT0 * 16 + 4, P = 64 + 4;
-    float *w0l = smem, *w1l = w0l + 64 * P0, *w2l = w1l + (NL == 3 ? 64 : NTO * 16) * P;
-    float *b0l = w2l + (NL == 3 ? NTO * 16 * P : 0), *b1l = b0l + 64, *b2l = b1l + 64;
-    stage_w(w0l, P0, 64, KT0 * 16, a.w0);
-    stage_w(w1l, P, NL == 3 ? 64 : NTO * 16, 64, a.w1);
-    if (NL == 3) stage_w(w2l, P, NTO * 16, 64, a.w2);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int KS0 = (KT0 + 1) / 2, NP1 = NL == 3 ? 4 : NTO;
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(4, KS0), *w2l = w1l + w3_units(NP1, 2);
+    float *b0l = reinterpret_cast<float *>(w2l + (NL == 3 ? w3_units(NTO, 2) : 0)), *b1l = b0l + 64, *b2l = b1l + 64;
+    stage_w3(w0l, 4, KS0, a.w0);
+    stage_w3(w1l, NP1, 2, a.w1);
+    if (NL == 3) stage_w3(w2l, NTO, 2, a.w2);
     stage_b(b0l, 64, a.b0, a.w0.n);
     stage_b(b1l, 64, a.b1, a.w1.n);
     if (NL == 3) stage_b(b2l, 64, a.b2, a.w2.n);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const float *w0p = w0l + m * P0 + 4 * g, *w1p = w1l + m * P + 4 * g, *w2p = w2l + m * P + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0p = w3_at(w0l, 4, KS0, lane), w1p = w3_at(w1l, NP1, 2, lane), w2p = w3_at(w2l, NTO, 2, lane);
     const bool wide_out = (a.n_out & 3) == 0 && (a.ldo & 3) == 0;
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
     auto load_x = [&](int64_t row, f32x4 (&v)[KT0]) {
@@ -530,23 +650,26 @@ __global__ __launch_bounds__(kNThreads, 4) void rmlp_fwd_kernel(const RMlpFwdArg
 #pragma unroll
             for (int t = 0; t < KT0; ++t) x[t] = xn[t];
             if (j + 1 < kNeckChunk && t0 + j + 1 < n_tiles) load_x(row + 16, xn);
+            Opd<KS0> xo;
+            make_opd<KT0>(x, xo);
             f32x4 h[4];
             init_bias<4>(b0l, g, h);
-            tgemm<KT0, 4, false>(w0p, P0, x, h);
+            tgemm<KS0, 4>(w0p, xo, h);
             relu<4>(h);
             if (a.h1) st_rm<4>(a.h1 + row * 64, ok, g, h);
+            Opd<2> ho;
+            make_opd<4>(h, ho);
             if constexpr (NL == 3) {
                 f32x4 h2[4];
                 init_bias<4>(b1l, g, h2);
-                tgemm<4, 4, false>(w1p, P, h, h2);
+                tgemm<2, 4>(w1p, ho, h2);
                 relu<4>(h2);
                 if (a.h2) st_rm<4>(a.h2 + row * 64, ok, g, h2);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) h[p] = h2[p];
+                make_opd<4>(h2, ho);
             }
             f32x4 o[NTO];
             init_bias<NTO>(NL == 3 ? b2l : b1l, g, o);
-            tgemm<4, NTO, false>(NL == 3 ? w2p : w1p, P, h, o);
+            tgemm<2, NTO>(NL == 3 ? w2p : w1p, ho, o);
             if (a.final_act == EMER_ACT_SIGMOID) {
 #pragma unroll
                 for (int p = 0; p < NTO; ++p)
@@ -570,15 +693,15 @@ struct RMlpBwdArgs {
 
 template <int KT0, int F, int NL, int NTO>
 __global__ __launch_bounds__(kNThreads, 4) void rmlp_bwd_kernel(const RMlpBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PL = NTO * 16 + 4, P = 64 + 4;
-    float *wll = smem, *w1l = wll + 64 * PL, *w0l = w1l + (NL == 3 ? 64 * P : 0);
-    stage_w(wll, PL, 64, NTO * 16, a.wlt);
-    if (NL == 3) stage_w(w1l, P, 64, 64, a.w1t);
-    stage_w(w0l, P, KT0 * 16, 64, a.w0t);
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int KSL = (NTO + 1) / 2;
+    u32x4 *wll = smem, *w1l = wll + w3_units(4, KSL), *w0l = w1l + (NL == 3 ? w3_units(4, 2) : 0);
+    stage_w3(wll, 4, KSL, a.wlt);
+    if (NL == 3) stage_w3(w1l, 4, 2, a.w1t);
+    stage_w3(w0l, KT0, 2, a.w0t);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const float *wlp = wll + m * PL + 4 * g, *w1p = w1l + m * P + 4 * g, *w0p = w0l + m * P + 4 * g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 wlp = w3_at(wll, 4, KSL, lane), w1p = w3_at(w1l, 4, 2, lane), w0p = w3_at(w0l, KT0, 2, lane);
     const bool wide_in = (a.n_out & 3) == 0 && (a.ldd & 3) == 0;
     const int64_t n_tiles = (a.n + 15) >> 4;
     for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; t < n_tiles; t += (int64_t)gridDim.x * (blockDim.x >> 6)) {
@@ -587,17 +710,21 @@ __global__ __launch_bounds__(kNThreads, 4) void rmlp_bwd_kernel(const RMlpBwdArg
         f32x4 d[NTO];
         if (wide_in) ld_rm_k<NTO>(a.dlast + row * a.ldd, ok, g, a.n_out, d);
         else ld_narrow<NTO>(a.dlast + row * a.ldd, ok, g, a.n_out, d);
+        Opd<KSL> dop;
+        make_opd<NTO>(d, dop);
         f32x4 da[4];
         zero<4>(da);
-        tgemm<NTO, 4, false>(wlp, PL, d, da);
+        tgemm<KSL, 4>(wlp, dop, da);
         if constexpr (NL == 3) {
             f32x4 mk2[4];
             ld_rm<4>(a.h2 + row * 64, ok, g, mk2);
             relu_mask<4>(da, mk2);
             st_rm<4>(a.dpre1 + row * 64, ok, g, da);
+            Opd<2> dao;
+            make_opd<4>(da, dao);
             f32x4 db[4];
             zero<4>(db);
-            tgemm<4, 4, false>(w1p, P, da, db);
+            tgemm<2, 4>(w1p, dao, db);
 #pragma unroll
             for (int p = 0; p < 4; ++p) da[p] = db[p];
         }
@@ -606,9 +733,11 @@ __global__ __launch_bounds__(kNThreads, 4) void rmlp_bwd_kernel(const RMlpBwdArg
         relu_mask<4>(da, mk1);
         st_rm<4>(a.dpre0 + row * 64, ok, g, da);
         if (a.dx) {
+            Opd<2> dao;
+            make_opd<4>(da, dao);
             f32x4 de[KT0];
             zero<KT0>(de);
-            tgemm<4, KT0, false>(w0p, P, da, de);
+            tgemm<2, KT0>(w0p, dao, de);
             if constexpr (F == 0) st_rm_k<KT0>(a.dx + row * a.lddx, ok, g, a.k0, de);
             else st_lm<KT0, F>(a.dx, a.n, a.n_levels, row, ok, g, de);
         }
@@ -674,13 +803,13 @@ extern "C" int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_fe
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     if (n_out == 1) {
-        auto lds = [](int kt0) { return (size_t)(64 * (kt0 * 16 + 4) + 16 * 68 + 64 + 16) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(1, 2)) * 16 + (64 + 16) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 1, a, lds, "neck_fwd");
     } else if (n_out == 64) {
-        auto lds = [](int kt0) { return (size_t)(64 * (kt0 * 16 + 4) + 64 * 68 + 64 + 64) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, 2)) * 16 + (64 + 64) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 4, a, lds, "neck_fwd");
     } else {
-        auto lds = [](int kt0) { return (size_t)(64 * (kt0 * 16 + 4) + 128 * 68 + 64 + 128) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(8, 2)) * 16 + (64 + 128) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 8, a, lds, "neck_fwd");
     }
 }
@@ -706,15 +835,15 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     if (n_out == 1) {
         a.w1t = WSrc{w1, 1, 64, 64, 1};  // (n = hidden, k = 0) = w1[0][n]
-        auto lds = [](int kt0) { return (size_t)(64 * 20 + kt0 * 16 * 68) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)w3_units(kt0, 2) * 16 + 64 * sizeof(float); };
         EMER_NECK_DISPATCH(neck_bwd_kernel, 0, a, lds, "neck_bwd");
     } else if (n_out == 64 || !d1) {
         a.w1t = WSrc{w1, 1, 64, 64, 64};  // only the first 64 outputs carry a gradient
-        auto lds = [](int kt0) { return (size_t)(64 * 68 + kt0 * 16 * 68) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(kt0, 2) + w3_units(4, 2)) * 16; };
         EMER_NECK_DISPATCH(neck_bwd_kernel, 4, a, lds, "neck_bwd");
     } else {
         a.w1t = WSrc{w1, 1, 64, 64, 128};
-        auto lds = [](int kt0) { return (size_t)(64 * 132 + kt0 * 16 * 68) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(kt0, 2) + w3_units(4, 4)) * 16; };
         EMER_NECK_DISPATCH(neck_bwd_kernel, 8, a, lds, "neck_bwd");
     }
 }
@@ -738,7 +867,7 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
     a.w1g = WSrc{w1 + 64 + kh, k1, 1, 64, 64};
     a.w2 = WSrc{w2, 64, 1, 3, 64};
     a.b2 = b2; a.a1 = a1; a.a2 = a2; a.out = out;
-    const size_t lds = (size_t)(3 * 64 * 68 + 16 * 68 + 16) * sizeof(float);
+    const size_t lds = (size_t)(3 * w3_units(4, 2) + w3_units(1, 2)) * 16 + 16 * sizeof(float);
     if (int rc = set_lds(rgb_fwd_kernel, lds, "rgb_head_fwd")) return rc;
     hipLaunchKernelGGL(rgb_fwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_fwd");
@@ -760,7 +889,7 @@ extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const floa
     a.w1gt = WSrc{w1 + 64 + kh, 1, k1, 64, 64};
     a.w0gt = WSrc{w0 + kh, 1, k0, 64, 64};
     a.dpre2 = dpre2; a.dpre1 = dpre1; a.dpre0 = dpre0; a.dgeo = dgeo; a.s1 = s1; a.s0 = s0;
-    const size_t lds = (size_t)(64 * 20 + 3 * 64 * 68) * sizeof(float);
+    const size_t lds = (size_t)(3 * w3_units(4, 2)) * 16;
     if (int rc = set_lds(rgb_bwd_kernel, lds, "rgb_head_bwd")) return rc;
     hipLaunchKernelGGL(rgb_bwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_bwd");
@@ -819,7 +948,7 @@ extern "C" int emer_rmlp_fwd(const float *x, int64_t ldx, int32_t n_levels, int3
     a.b0 = b0; a.b1 = b1; a.b2 = b2; a.h1 = h1; a.h2 = h2; a.out = out; a.ldo = ldo;
     const int kt0 = n_feat == 0 ? 4 : (k0 + 15) / 16, nto = n_out <= 16 ? 1 : 4;
     const int kt0i = n_feat == 0 ? 4 : (kt0 <= 2 ? 2 : kt0);
-    const size_t lds = (size_t)(64 * (kt0i * 16 + 4) + (n_layers == 3 ? 64 : nto * 16) * 68 + (n_layers == 3 ? nto * 16 * 68 : 0) + 3 * 64) * sizeof(float);
+    const size_t lds = (size_t)(w3_units(4, (kt0i + 1) / 2) + w3_units(n_layers == 3 ? 4 : nto, 2) + (n_layers == 3 ? w3_units(nto, 2) : 0)) * 16 + 3 * 64 * sizeof(float);
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     EMER_RMLP_DISPATCH(rmlp_fwd_kernel, a, lds, "rmlp_fwd");
@@ -845,7 +974,7 @@ extern "C" int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, c
     a.dpre1 = dpre1; a.dpre0 = dpre0; a.dx = dx; a.lddx = lddx;
     const int kt0 = n_feat == 0 ? 4 : (k0 + 15) / 16, nto = n_out <= 16 ? 1 : 4;
     const int kt0i = n_feat == 0 ? 4 : (kt0 <= 2 ? 2 : kt0);
-    const size_t lds = (size_t)(64 * (nto * 16 + 4) + (n_layers == 3 ? 64 * 68 : 0) + kt0i * 16 * 68) * sizeof(float);
+    const size_t lds = (size_t)(w3_units(4, (nto + 1) / 2) + (n_layers == 3 ? w3_units(4, 2) : 0) + w3_units(kt0i, 2)) * 16;
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid((n + 15) / 16, kNThreads);
     EMER_RMLP_DISPATCH(rmlp_bwd_kernel, a, lds, "rmlp_bwd");

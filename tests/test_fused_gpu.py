@@ -268,15 +268,25 @@ def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
     n = len(Ws)
     out = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
     h = r[0].permute(1, 0, 2).reshape(N, K0)
+    # rows with a hidden pre-activation within fp32 rounding of the ReLU kink: any two correct fp32 evaluations may
+    # disagree on that unit's mask, and the row's INPUT gradient then differs by a whole weight column (one such row in
+    # 262144 here).  Their input gradient is excluded; everything else -- including the weight gradients, to which such a
+    # row contributes |pre| ~ 1e-7 -- is compared in full.  (~1e-4 of the rows.)
+    kink = torch.zeros(N, dtype=torch.bool)
     for i in range(n):
         h = torch.nn.functional.linear(h, r[1 + i], r[1 + n + i])
         if i + 1 < n:
+            kink |= (h.detach().abs() < 4e-7 * h.detach().abs().max()).any(dim=1)
             h = torch.relu(h)
+    assert int(kink.sum()) <= 2 + N // 2000, int(kink.sum())
     _close("out", out, h)
     w = torch.randn(N, dims[-1], generator=g)
     (out * w.to(dev)).sum().backward(); (h * w.double()).sum().backward()
     for i, (a, b) in enumerate(zip(t, r)):
-        _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+        ga, gb = a.grad, b.grad
+        if i == 0:
+            ga, gb = ga.cpu()[:, ~kink], gb[:, ~kink]
+        _close(f"grad{i}", ga, gb, rtol=2e-4, scale_atol=5e-5)
 
 
 def test_seq_mlp_routes_to_register_resident_kernels(hip_lib):

@@ -1,10 +1,7 @@
 """Time emer_wgrad_segmented on the shapes of one training step (1M rows)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import emernerf_amd._lib as _L0
-if "--lib" in sys.argv:  # A/B: emernerf_amd/lib/libemernerf_<tag>.so (tools/build_variant.sh)
-    _L0.LIB_PATH = os.path.join(os.path.dirname(_L0.LIB_PATH), f"libemernerf_{sys.argv[sys.argv.index('--lib') + 1]}.so")
-    print("lib", sys.argv[sys.argv.index('--lib') + 1])
+from tools import _libsel
 from emernerf_amd import fused
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); R, S = 8192, 128; N = R * S
@@ -23,3 +20,8 @@ cases = {
 }
 for k, f in cases.items():
     print(f"{k:28s} {timeit(f, iters=8)[0]:8.1f} us (includes workspace alloc + reduce)")
+# accuracy against fp64 (the dW1 case: 1M-row reduction)
+dw, _ = fused.wgrad(dp1, [fused.seg(a1, 0, 64), fused.seg(g, 64, 64)], 128, want_bias=False)
+ref = dp1.double().T @ torch.cat([a1, g], 1).double()
+err = (dw.double() - ref).abs().max().item(); sc = ref.abs().max().item()
+print(f"lib {_libsel.TAG}: dW1 max abs err {err:.3e} / max |dW| {sc:.3e} = {err / sc:.2e}; rms rel {((dw.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item():.2e}")
