@@ -221,7 +221,7 @@ def main():
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
-                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_rgb_head_fwd", "emer_rgb_head_bwd",
+                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd",
                               "emer_rmlp_fwd", "emer_rmlp_bwd", "emer_contract_bwd", "emer_blend_accumulate_fwd", "emer_blend_accumulate_bwd",
                               "emer_prop_loss", "emer_ray_epilogue_fwd", "emer_ray_epilogue_bwd", "emer_pixel_loss_fwd", "emer_pixel_loss_bwd",
                               "emer_trunc_exp_fwd", "emer_trunc_exp_bwd"]

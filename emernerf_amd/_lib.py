@@ -75,6 +75,8 @@ SIGNATURES = {
     "emer_neck_supported": [c_int32, c_int32, c_int32, c_int32],
     "emer_neck_fwd": [_P, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P],
     "emer_neck_bwd": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P],
+    "emer_neck_bwd_fused_supported": [c_int32, c_int32, c_int32, c_int32],
+    "emer_neck_bwd_fused": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
     "emer_rmlp_supported": [c_int32, c_int32, c_int32, c_int32, c_int32],
     "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
@@ -89,6 +91,14 @@ SIGNATURES = {
     "emer_gen_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_int32, _P],
 }
+
+# workspace-size queries (return int64 floats, not an error code)
+INT64_FUNCTIONS = {
+    "emer_linear_bwd_workspace": [c_int64, c_int32, c_int32],
+    "emer_neck_bwd_fused_workspace": [c_int32, c_int32, c_int64, c_int32],
+}
+
+ALLOW_MISSING_SYMBOLS = False  # never set by the product path
 
 _lib = None
 
@@ -106,12 +116,16 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found. Build it with `python -m emernerf_amd._build` (hipcc, gfx950). "
             "emernerf_amd has no CPU/PyTorch fallback by design.")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
-        fn.argtypes = argtypes
-        fn.restype = c_int
-    lib.emer_linear_bwd_workspace.argtypes = [c_int64, c_int32, c_int32]
-    lib.emer_linear_bwd_workspace.restype = c_int64
+    for table, restype in ((SIGNATURES, c_int), (INT64_FUNCTIONS, c_int64)):
+        for name, argtypes in table.items():
+            try:
+                fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            except AttributeError:
+                if ALLOW_MISSING_SYMBOLS:  # tools/_libsel.py only: an older build of the library in a same-session A/B
+                    continue
+                raise
+            fn.argtypes = argtypes
+            fn.restype = restype
     lib.emer_last_error.restype = ctypes.c_char_p
     lib.emer_version.restype = c_int
     _lib = lib

@@ -42,6 +42,10 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // hipGraph (core.hip).
 int reserve_lds(const void *kernel, size_t bytes, const char *what);
 
+// csrc/mlp.hip: dw (+=) and dbias (+=) from per-workgroup partials ([n][k] | [n] at the start of each `stride`-float partial)
+int launch_dw_reduce(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
+                     float *dbias, hipStream_t st);
+
 // Measurement hook (emer_profile_next): a pair of caller-owned HIP events that the NEXT instrumented launch of this thread
 // records immediately before / after its kernel (hipExtLaunchKernelGGL), so bench.py times the kernel itself and not
 // the host's enqueue latency around it.  One-shot; both null when not armed.

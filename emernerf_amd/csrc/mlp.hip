@@ -257,9 +257,11 @@ static inline DwDst dw_dst_identity(int32_t k) {
 }
 
 __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float *__restrict__ partials, int32_t n_blocks, int64_t stride,
-                                                               int64_t nk, float *__restrict__ dw, float *__restrict__ dbias, const DwDst dst) {
+                                                               int64_t nk, float *__restrict__ dw, float *__restrict__ dbias, const DwDst dst,
+                                                               int64_t extent = -1) {
+    // extent: floats of a partial that belong to this (dW | dbias) pair; -1: the whole partial (= stride)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= stride) return;
+    if (i >= (extent < 0 ? stride : extent)) return;
     const int32_t per = (n_blocks + (int32_t)gridDim.y - 1) / (int32_t)gridDim.y;
     const int32_t b0 = (int32_t)blockIdx.y * per;
     const int32_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
@@ -304,6 +306,18 @@ static inline int32_t dw_rows_per_block(int64_t m, int32_t n, int32_t k) {
     if (r < 64) r = 64;
     if (r > cap) r = cap;
     return (int32_t)r;
+}
+
+// Sum `n_blocks` partials (`stride` floats apart, each holding dW [n][k] | dbias [n] at its start) into dw (+=, leading dimension
+// ld_dw) and dbias (+=, may be null).  Used by the fused backward kernels of csrc/mlp_fused.hip.
+int launch_dw_reduce(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
+                     float *dbias, hipStream_t st) {
+    DwDst d = dw_dst_identity(k);
+    d.ld = ld_dw;
+    const int64_t extent = (int64_t)n * k + n;
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(extent, 256), dw_reduce_splits(n_blocks, extent)), dim3(256), 0, st, partials,
+                       n_blocks, stride, (int64_t)n * k, dw, dbias, d, extent);
+    return check_launch("dw_reduce");
 }
 
 static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,
@@ -742,7 +756,8 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &h, unsigned &
 //              instead of T dword loads.  Needs every segment boundary and leading dimension to be a multiple of T.
 // C0 = true: column 0 of dPre is replaced by its own array (sx.col0, VEC layouts; the scalar layout redirects lane 0's pointer).
 // FULL = true: every lane's column exists (N = 32 NT, K = 32 KT): no column masks.
-template <int NT, int KT, bool VEC, bool C0, bool FULL>
+// BIAS = false: no bias-gradient accumulators (the widest tile has no registers to spare for them).
+template <int NT, int KT, bool VEC, bool C0, bool FULL, bool BIAS = true>
 __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restrict__ dpre, int64_t ldd, const SegX sx,
                                                            float *__restrict__ partials, int64_t M, int32_t N, int32_t K,
                                                            int32_t rows_per_block, int want_bias) {
@@ -802,9 +817,12 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < KT; ++b) acc[a][b] = f32x16{0};
-    float bsum[NT];
+    // bias gradient = dPre^T 1: one more B tile, all ones (every column of the result holds the column sums of dPre).  Three
+    // instructions per A tile and block on the pipe that is already there, instead of a per-lane fp32 side sum.
+    f32x16 accb[BIAS ? NT : 1];
 #pragma unroll
-    for (int a = 0; a < NT; ++a) bsum[a] = 0.0f;
+    for (int a = 0; a < (BIAS ? NT : 1); ++a) accb[a] = f32x16{0};
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
     // per-lane pointers to row 8 kg of the current block; the block loop advances them by 16 rows
 #pragma unroll
@@ -869,7 +887,14 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
                 unsigned h, m, l;
                 split3(x0, x1, h, m, l);
                 ah[a][q] = h; am[a][q] = m; al[a][q] = l;
-                bsum[a] += x0 + x1;
+            }
+        }
+        if (BIAS && want_bias) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                accb[a] = EMER_MF32(al[a], ones, accb[a]);
+                accb[a] = EMER_MF32(am[a], ones, accb[a]);
+                accb[a] = EMER_MF32(ah[a], ones, accb[a]);
             }
         }
 #pragma unroll
@@ -942,8 +967,6 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
     }
     // ---- sum the four waves through LDS (wave 0 writes, 1..3 add in turn), then one coalesced store of the partial.
     // red is indexed by ACTUAL (n, k): tile (a, b), element (i, j)  ->  VEC: n = NT i + a, k = KT j + b;  else n = 32 a + i, k = 32 b + j
-#pragma unroll
-    for (int a = 0; a < NT; ++a) bsum[a] += __shfl_down(bsum[a], 32, 64);
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -958,9 +981,13 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
                         *q = (w == 0) ? acc[a][b][v] : *q + acc[a][b][v];
                     }
                 }
-                if (kg == 0) {
-                    float *q = red + NT * 32 * KP + (VEC ? NT * j + a : a * 32 + j);
-                    *q = (w == 0) ? bsum[a] : *q + bsum[a];
+                if (BIAS && j == 0) {   // column 0 of the ones product: dbias[n(a, i)]
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int i = (v & 3) + 8 * (v >> 2) + 4 * kg;
+                        float *q = red + NT * 32 * KP + (VEC ? NT * i + a : a * 32 + i);
+                        *q = (w == 0) ? accb[a][v] : *q + accb[a][v];
+                    }
                 }
             }
         }
@@ -1041,21 +1068,25 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
     const int32_t n_row_blocks = (int32_t)ceil_div(m, rpb);
     bool stream_ok = n <= 64 && k <= 128;
     for (int s = 0; s < n_segs; ++s) stream_ok = stream_ok && (segs[s].mode == 1 || segs[s].row_div == 1);
+    const int NT = n <= 32 ? 1 : 2;
+    int KT = (k + 31) / 32;
+    // vector loads (one per operand per row) when every boundary is a multiple of the vector width
+    const int KTv = KT == 3 ? 4 : KT;
+    bool vec = stream_ok && (n % NT == 0) && (ldd % NT == 0) && ((uintptr_t)dpre % (4 * NT) == 0) && (k % KTv == 0) && (NT * KTv > 1);
+    for (int s = 0; s < n_segs && vec; ++s) {
+        const emer_chain_seg &S = segs[s];
+        vec = (S.col % KTv == 0) && (S.width % KTv == 0) && ((uintptr_t)S.ptr % (4 * KTv) == 0) &&
+              (S.mode == 1 ? (S.f % KTv == 0) : (S.ld % KTv == 0));
+    }
+    if (vec) KT = KTv;
+    const bool full = vec && n == 32 * NT && k == 32 * KT;  // every lane owns real columns: no masks
+    // the widest tile (64 x 128) streams only in its mask-free vector form: the masked / scalar forms of that tile do not fit the
+    // register file (hundreds of spilled registers); such shapes (no shipped head) take the LDS-staged kernel below
+    if (NT * KT >= 8 && !full) stream_ok = false;
     if (stream_ok) {  // no per-ray operand: operands stream straight into the MFMA layout
-        const int NT = n <= 32 ? 1 : 2;
-        int KT = (k + 31) / 32;
         const dim3 sgrid((uint32_t)n_row_blocks);
-        // vector loads (one per operand per row) when every boundary is a multiple of the vector width
-        const int KTv = KT == 3 ? 4 : KT;
-        bool vec = (n % NT == 0) && (ldd % NT == 0) && ((uintptr_t)dpre % (4 * NT) == 0) && (k % KTv == 0) && (NT * KTv > 1);
-        for (int s = 0; s < n_segs && vec; ++s) {
-            const emer_chain_seg &S = segs[s];
-            vec = (S.col % KTv == 0) && (S.width % KTv == 0) && ((uintptr_t)S.ptr % (4 * KTv) == 0) &&
-                  (S.mode == 1 ? (S.f % KTv == 0) : (S.ld % KTv == 0));
-        }
-        if (vec) KT = KTv;
-        const bool full = vec && n == 32 * NT && k == 32 * KT;  // every lane owns real columns: no masks
-#define EMER_WSL(A, B, V, C, F) hipLaunchKernelGGL((wgrad_stream_kernel<A, B, V, C, F>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+#define EMER_WSK(A, B, V, C, F, BI) hipLaunchKernelGGL((wgrad_stream_kernel<A, B, V, C, F, BI>), sgrid, dim3(256), 0, st, dpre, ldd, sx, workspace, m, n, k, rpb, dbias ? 1 : 0)
+#define EMER_WSL(A, B, V, C, F) do { if (A * B >= 8 && !dbias) EMER_WSK(A, B, V, C, F, (A * B < 8)); else EMER_WSK(A, B, V, C, F, true); } while (0)
 #define EMER_WS(A, B) do { if (vec && col0 && full) EMER_WSL(A, B, true, true, true); else if (vec && col0) EMER_WSL(A, B, true, true, false); \
                            else if (vec && full) EMER_WSL(A, B, true, false, true); else if (vec) EMER_WSL(A, B, true, false, false); \
                            else EMER_WSL(A, B, false, false, false); } while (0)
@@ -1065,6 +1096,7 @@ extern "C" int emer_wgrad_segmented(const float *dpre, int64_t ldd, const float 
 #undef EMER_WS
 #undef EMER_WS3
 #undef EMER_WSL
+#undef EMER_WSK
         if (int rc = check_launch("wgrad_stream")) return rc;
         const int64_t stride = (int64_t)n * k + n;
         hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(stride, 256), dw_reduce_splits(n_row_blocks, stride)), dim3(256), 0, st,

@@ -405,6 +405,196 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_bwd_kernel(const NeckBwdArg
     }
 }
 
+// ------------------------------------------------------------------------ neck backward with fused weight gradients
+// [r3]  dW = dPre^T X needs the ROWS on the reduction index of the matrix core, while the transposed chain keeps a row on
+// a lane.  Two facts make the fusion cheap once the matrix pipe is 16x faster than fp32:
+//  * The matrix core is its own transposer.  An operand X in chain layout (lane (m, g): eight features of row m) times a
+//    0/1 selection matrix E_p -- B[k][j] = [feature(k) == 16 p + j] -- gives D[i = row][j] = X[row][16 p + j] in the
+//    accumulator layout: lane (j, g) holds rows 4 g .. 4 g + 3 of feature 16 p + j.  One instruction per bf16 term; the
+//    result is exact (one product per output), so the three terms re-pack into bf16 without another split.
+//  * That layout IS the operand layout of v_mfma_f32_16x16x16_bf16 with the reduction over a tile's 16 rows (lane (i, g)
+//    supplies k = 4 g .. 4 g + 3), for A (dPre: feature i) and B (X: feature j) alike.
+// The 16x16 tiles of dW (64 x 64 and 64 x K0: 24 tiles = 96 registers) stay in the wave's accumulators for the whole
+// launch -- two waves per SIMD instead of four; an LDS copy per workgroup with ds_add_f32 was tried first and is
+// hopeless on this chip (0.37 lane-adds per clock per CU, DESIGN 4.1: 2 ms for this kernel).  The waves of a workgroup are
+// summed through LDS once at the end and the per-workgroup partials by linear_dw_reduce_kernel.  dPre never goes to HBM
+// and h1 / enc / d are read once: the separate weight-gradient pass of the neck (two launches, 0.94 GB) is gone.
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+struct SwT { u32x2 h, m, l; };  // one 16-row x 16-feature tile, rows on the reduction index, three bf16 terms
+
+struct SelE { unsigned a0, a1; };  // the two non-zero registers of the selection fragments (built once per lane)
+__device__ __forceinline__ SelE make_sel(int lane) {
+    const bool on = (lane >> 4) == ((lane & 15) >> 2);
+    const unsigned one = on ? (0x3F80u << (16 * (lane & 1))) : 0u;   // bf16 1.0 in the half this lane's feature sits in
+    return SelE{((lane & 3) >> 1) == 0 ? one : 0u, ((lane & 3) >> 1) == 1 ? one : 0u};
+}
+// feature tile p of the operand `o` (k-step p >> 1, half p & 1) -> swapped layout; colsum += the lane's four rows (fp32)
+template <int KS>
+__device__ __forceinline__ SwT to_rows(const Opd<KS> &o, int p, const SelE e, float *colsum = nullptr) {
+    const u32x4 sel = (p & 1) ? u32x4{0u, 0u, e.a0, e.a1} : u32x4{e.a0, e.a1, 0u, 0u};
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 th = EMER_MF(o.h[p >> 1], sel, z), tm = EMER_MF(o.m[p >> 1], sel, z), tl = EMER_MF(o.l[p >> 1], sel, z);
+    SwT t;
+    t.h = u32x2{pk_bf16(th[0], th[1]), pk_bf16(th[2], th[3])};
+    t.m = u32x2{pk_bf16(tm[0], tm[1]), pk_bf16(tm[2], tm[3])};
+    t.l = u32x2{pk_bf16(tl[0], tl[1]), pk_bf16(tl[2], tl[3])};
+    if (colsum) *colsum += ((tl[0] + tl[1]) + (tl[2] + tl[3])) + ((tm[0] + tm[1]) + (tm[2] + tm[3])) + ((th[0] + th[1]) + (th[2] + th[3]));
+    return t;
+}
+#define EMER_MF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, A), __builtin_bit_cast(s16x4, B), C, 0, 0, 0)
+// acc[p][b] (lane (j, g), register r: dW[16 p + 4 g + r][16 b + j]) += sum over the tile's rows of a[p][row][.] * bt[b][row][.]
+// Products outermost: consecutive instructions hit different accumulators.
+template <int NA, int NB>
+__device__ __forceinline__ void dw_tiles(f32x4 (&acc)[NA][NB], const SwT (&a)[NA], const SwT (&bt)[NB]) {
+#define EMER_DW_PASS(X, Y)                                                                   \
+    _Pragma("unroll") for (int p = 0; p < NA; ++p)                                           \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) acc[p][b] = EMER_MF16(a[p].X, bt[b].Y, acc[p][b]);
+    EMER_DW_PASS(l, h) EMER_DW_PASS(h, l) EMER_DW_PASS(m, m) EMER_DW_PASS(m, h) EMER_DW_PASS(h, m) EMER_DW_PASS(h, h)
+#undef EMER_DW_PASS
+}
+
+constexpr int kWThreads = 256;  // fused backward: 4 waves, two workgroups per CU = 2 waves per SIMD (<= 256 registers)
+
+struct NeckBwdWArgs {
+    const float *d0;     // [n][64] gradient of output features 0..63 (null: zero)
+    const float *ddens;  // [n] gradient of the density (null: none)
+    const float *dens;   // [n] saved density
+    const float *h1;     // [n][64] saved hidden activations
+    const float *enc;    // level-major [L][n][F]: the forward's input (operand of dW0)
+    int64_t n; int32_t n_levels, k0;
+    WSrc w1t, w0t;       // W1^T (64 x 64), W0^T (K0 x 64)
+    float *denc;         // level-major [L][n][F]
+    float *partials;     // [gridDim.x][stride]: dW1 [64][64] | db1 [64] | dW0 [64][k0] | db0 [64]
+    int64_t stride;
+};
+
+template <int KT0, int F>
+__global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int K0P = 16 * KT0;
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2);
+    stage_w3(w0l, KT0, 2, a.w0t);
+    stage_w3(w1l, 4, 2, a.w1t);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2, lane);
+    const SelE sel = make_sel(lane);
+    f32x4 aw1[4][4], aw0[4][KT0];   // dW1 [64][64], dW0 [64][K0P] as 16x16 tiles
+    float ab1[4], ab0[4];           // bias gradients: this lane's rows 4 g .. 4 g + 3 of feature 16 p + m
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        zero<4>(aw1[p]); zero<KT0>(aw0[p]);
+        ab1[p] = 0.0f; ab0[p] = 0.0f;
+    }
+    const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t t0 = c * kNeckChunk;
+        for (int j = 0; j < kNeckChunk && t0 + j < n_tiles; ++j) {
+            const int64_t row = (t0 + j) * 16 + m;
+            const bool ok = row < a.n;
+            float fix = 0.0f;
+            if (a.ddens && ok) fix = a.ddens[row] * fminf(a.dens[row], 3269017.3724721107f);
+            // h1: operand of dW1 (rows on the reduction index) and relu'(h1) as 16 bits (h1 >= 0: positive iff its leading
+            // bf16 term is non-zero)
+            SwT hs[4];
+            unsigned relu_bits = 0u;
+            {
+                f32x4 mk[4];
+                ld_rm<4>(a.h1 + row * 64, ok, g, mk);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) relu_bits |= (mk[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                Opd<2> ho;
+                make_opd<4>(mk, ho);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) hs[p] = to_rows<2>(ho, p, sel);
+            }
+            f32x4 da[4];
+            zero<4>(da);
+            {
+                f32x4 lo[4];
+                if (a.d0) ld_rm<4>(a.d0 + row * 64, ok, g, lo); else zero<4>(lo);
+                if (g == 0) lo[0][0] += fix;
+                Opd<2> dop;
+                make_opd<4>(lo, dop);
+                tgemm<2, 4>(w1p, dop, da);
+                SwT ds[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) ds[p] = to_rows<2>(dop, p, sel, &ab1[p]);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_tiles<4, 4>(aw1, ds, hs);   // dW1 += d^T h1
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) da[p][i] = ((relu_bits >> (4 * p + i)) & 1u) ? da[p][i] : 0.0f;
+            Opd<2> dao;
+            make_opd<4>(da, dao);
+            f32x4 de[KT0];
+            zero<KT0>(de);
+            tgemm<2, KT0>(w0p, dao, de);
+            st_lm<KT0, F>(a.denc, a.n, a.n_levels, row, ok, g, de);
+            {   // dW0 += dPre0^T enc
+                SwT xs[KT0], ds[4];
+                {
+                    f32x4 x[KT0];
+                    ld_lm<KT0, F>(a.enc, a.n, a.n_levels, row, ok, g, x);
+                    Opd<(KT0 + 1) / 2> xo;
+                    make_opd<KT0>(x, xo);
+#pragma unroll
+                    for (int b = 0; b < KT0; ++b) xs[b] = to_rows<(KT0 + 1) / 2>(xo, b, sel);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) ds[p] = to_rows<2>(dao, p, sel, &ab0[p]);
+                dw_tiles<4, KT0>(aw0, ds, xs);
+            }
+        }
+    }
+    // ---- sum the waves through LDS (the weights are dead: the buffer takes their place), one coalesced partial per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);   // dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
+    float *r1 = red, *rb1 = r1 + 64 * 64, *r0 = rb1 + 64, *rb0 = r0 + 64 * K0P;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {   // bias: rows 4 g .. 4 g + 3 of the four lane groups -> every lane holds the column sum
+        ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64);
+        ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64);
+    }
+    for (int w = 0; w < kWThreads / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = r1 + (16 * p + 4 * g + r) * 64 + 16 * b + m;
+                        *q = (w == 0) ? aw1[p][b][r] : *q + aw1[p][b][r];
+                    }
+#pragma unroll
+                for (int b = 0; b < KT0; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = r0 + (16 * p + 4 * g + r) * K0P + 16 * b + m;
+                        *q = (w == 0) ? aw0[p][b][r] : *q + aw0[p][b][r];
+                    }
+                if (g == 0) {
+                    rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
+                    rb0[16 * p + m] = (w == 0) ? ab0[p] : rb0[16 * p + m] + ab0[p];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
+    for (int i = threadIdx.x; i < 64 * 64 + 64; i += (int)blockDim.x) part[i] = red[i];
+    float *part0 = part + 64 * 64 + 64;
+    for (int i = threadIdx.x; i < 64 * a.k0; i += (int)blockDim.x) { const int nn = i / a.k0, kk = i - nn * a.k0; part0[i] = r0[nn * K0P + kk]; }
+    for (int i = threadIdx.x; i < 64; i += (int)blockDim.x) part0[64 * a.k0 + i] = rb0[i];
+}
+
 // ------------------------------------------------------------------------------------------------- rgb forward
 struct RgbFwdArgs {
     const float *geo; int64_t ld_geo;  // [n][>= 64]
@@ -846,6 +1036,66 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
         auto lds = [](int kt0) { return (size_t)(w3_units(kt0, 2) + w3_units(4, 4)) * 16; };
         EMER_NECK_DISPATCH(neck_bwd_kernel, 8, a, lds, "neck_bwd");
     }
+}
+
+// ---- neck backward with the weight gradients fused [r3] --------------------------------------------------------------------
+static inline uint32_t neck_bwdw_grid(int64_t n) {
+    const int64_t chunks = ((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk;
+    int64_t blocks = (chunks + kWThreads / 64 - 1) / (kWThreads / 64);
+    if (blocks > 512) blocks = 512;   // persistent: two 4-wave workgroups per CU
+    return (uint32_t)(blocks < 1 ? 1 : blocks);
+}
+static inline size_t neck_bwdw_lds(int kt0) {
+    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2)) * 16, r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
+    return w > r ? w : r;
+}
+static inline int64_t neck_bwdw_stride(int k0) { return (int64_t)64 * 64 + 64 + 64 * (int64_t)k0 + 64; }
+
+// 1 when emer_neck_bwd_fused covers this neck: 64 outputs (the geometry features; the 128-output neck of the feature
+// configs and the density MLP, n_out == 1, stay on emer_neck_bwd + emer_wgrad_segmented -- their dW would not fit the registers)
+extern "C" int emer_neck_bwd_fused_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out) {
+    return (emer_neck_supported(n_levels, n_feat, hidden, n_out) && n_out == 64) ? 1 : 0;
+}
+// floats of workspace emer_neck_bwd_fused needs (per-workgroup partial weight gradients)
+extern "C" int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out) {
+    if (n <= 0 || !emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out)) return 0;
+    return (int64_t)neck_bwdw_grid(n) * neck_bwdw_stride(n_levels * n_feat);
+}
+// Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
+// [64][ld_dw0 >= L*F], db0 [64], dw1 [64][ld_dw1 >= 64], db1 [64] (torch Linear layouts; what autograd's AccumulateGrad would
+// add).  d0 / ddens as in emer_neck_bwd.  enc_lm: the forward's input.
+extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *h1, const float *enc_lm,
+                                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1, int32_t n_out,
+                                   float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1,
+                                   float *db1, void *stream) {
+    EMER_REQUIRE(n >= 0, "neck_bwd_fused: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out), "neck_bwd_fused: unsupported shape L=%d F=%d n_out=%d", n_levels, n_feat, n_out);
+    EMER_REQUIRE(h1 && enc_lm && w0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1, "neck_bwd_fused: null pointer");
+    EMER_REQUIRE(!ddens || dens, "neck_bwd_fused: ddens needs the saved density");
+    const int k0 = n_levels * n_feat;
+    EMER_REQUIRE(ld_dw0 >= k0 && ld_dw1 >= 64, "neck_bwd_fused: leading dimension smaller than the row");
+    NeckBwdWArgs a;
+    a.d0 = d0; a.ddens = ddens; a.dens = dens; a.h1 = h1; a.enc = enc_lm; a.n = n; a.n_levels = n_levels; a.k0 = k0;
+    a.w0t = WSrc{w0, 1, k0, k0, 64};          // (n = input feature, k = hidden) = w0[k][n]
+    a.w1t = WSrc{w1, 1, 64, 64, 64};          // (n = hidden, k = output) = w1[k][n]
+    a.denc = denc_lm; a.partials = workspace; a.stride = neck_bwdw_stride(k0);
+    hipStream_t st = as_stream(stream);
+    const int kt0 = (k0 + 15) / 16;
+    const uint32_t grid = neck_bwdw_grid(n);
+    const size_t lds = neck_bwdw_lds(kt0);
+    int rc = EMER_E_INVALID;
+    auto go = [&](auto kern) {
+        if (int r = set_lds(kern, lds, "neck_bwd_fused")) return r;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWThreads), lds, st, a);
+        return check_launch("neck_bwd_fused");
+    };
+#define EMER_NBW(FF) (kt0 == 1 ? go(neck_bwdw_kernel<1, FF>) : kt0 == 2 ? go(neck_bwdw_kernel<2, FF>) : kt0 == 3 ? go(neck_bwdw_kernel<3, FF>) : go(neck_bwdw_kernel<4, FF>))
+    if (n_feat == 1) rc = EMER_NBW(1); else if (n_feat == 2) rc = EMER_NBW(2); else if (n_feat == 4) rc = EMER_NBW(4); else rc = EMER_NBW(8);
+#undef EMER_NBW
+    if (rc) return rc;
+    if (int r = launch_dw_reduce(workspace, (int32_t)grid, a.stride, 64, 64, dw1, ld_dw1, db1, st)) return r;
+    return launch_dw_reduce(workspace + 64 * 64 + 64, (int32_t)grid, a.stride, 64, k0, dw0, ld_dw0, db0, st);
 }
 
 // rgb head forward: a1 = relu(geo W0g^T + rb0[ray]); a2 = relu(a1 W1a^T + geo W1g^T + rb1[ray]); out = sigmoid(a2 W2^T + b2).

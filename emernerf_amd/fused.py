@@ -158,6 +158,7 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
     return dw, db
 
 
+FUSED_WGRAD = True   # weight gradients inside the backward kernels where the library has them (emer_neck_bwd_fused); False: separate pass
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
 
 
@@ -314,8 +315,20 @@ class _NeckFn(torch.autograd.Function):
         d0c = None if d0 is None else _c(d0)
         d1c = None if d1 is None else _c(d1)
         fa = None if ddens is None else _c(ddens)
-        dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
         denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+        sw0, sb0, sw1, sb1 = ctx.sinks
+        tw1, rw1 = _target(sw1, (n_out, 64), dev)
+        tb1, rb1 = _target(sb1, (n_out,), dev)
+        tw0, rw0 = _target(sw0, (64, L * F), dev)
+        tb0, rb0 = _target(sb0, (64,), dev)
+        if FUSED_WGRAD and _lib.load().emer_neck_bwd_fused_supported(L, F, 64, n_out):
+            # data gradients AND weight gradients in one kernel: dpre0 never reaches memory, h1 / enc / d are read once
+            ws = torch.empty((int(_lib.load().emer_neck_bwd_fused_workspace(L, F, N, n_out)),), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_neck_bwd_fused", _p(d0c), _p(fa), _p(dens), _p(h1), _p(enc), L, F, N, _p(W0), _p(W1), n_out,
+                          _p(denc), _p(ws), _p(tw0), tw0.stride(0), _p(tb0), _p(tw1), tw1.stride(0), _p(tb1), _stream(enc))
+            return denc, rw0, rb0, rw1, rb1
+        dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
         # column 0 of the output-layer wgrad operand = d0[:, 0] + trunc_exp side gradient, written by the kernel
         col0 = None if fa is None else torch.empty((N,), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
@@ -323,11 +336,6 @@ class _NeckFn(torch.autograd.Function):
                       _p(dpre0), _p(denc), _stream(enc))
         # weight gradients, accumulated straight into the parameters' .grad when the trainer allows it (_sink).
         # Output rows whose gradient is structurally zero (an unused semantic half) cost nothing.
-        sw0, sb0, sw1, sb1 = ctx.sinks
-        tw1, rw1 = _target(sw1, (n_out, 64), dev)
-        tb1, rb1 = _target(sb1, (n_out,), dev)
-        tw0, rw0 = _target(sw0, (64, L * F), dev)
-        tb0, rb0 = _target(sb0, (64,), dev)
         if d0c is None:
             d0c = torch.zeros((N, 64), device=dev, dtype=torch.float32)
         wgrad(d0c, [seg(h1, 0, 64)], 64, col0=col0, out_w=tw1[:64], out_b=tb1[:64])

@@ -45,9 +45,12 @@ def test_base_mlp(hip_lib, L, Fe, NG, N):
 @pytest.mark.parametrize("L,Fe,NG,N,which", [(16, 2, 128, 1000, "all"), (16, 2, 128, 2048, "geo"), (10, 4, 128, 777, "all"),
                                               (4, 2, 64, 16, "all"), (8, 1, 64, 33, "dens"), (3, 8, 64, 100, "all"),
                                               (16, 4, 128, 50, "sem")])
-def test_neck_register_resident(hip_lib, L, Fe, NG, N, which):
-    """emer_neck_fwd / emer_neck_bwd: split outputs, ragged row counts, every combination of live output gradients."""
+@pytest.mark.parametrize("fusedw", [True, False])
+def test_neck_register_resident(hip_lib, monkeypatch, L, Fe, NG, N, which, fusedw):
+    """emer_neck_fwd / emer_neck_bwd (+ emer_wgrad_segmented) and emer_neck_bwd_fused (weight gradients accumulated inside
+    the backward kernel): split outputs, ragged row counts, every combination of live output gradients."""
     from emernerf_amd import fused
+    monkeypatch.setattr(fused, "FUSED_WGRAD", fusedw)
     dev = torch.device("cuda:0")
     assert fused.neck_supported(L, Fe, 64, NG)
     g = torch.Generator().manual_seed(L * 7 + NG + N)
@@ -266,27 +269,31 @@ def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
     t = [v.to(dev).requires_grad_(True) for v in [enc] + Ws + Bs]
     r = [v.double().requires_grad_(True) for v in [enc] + Ws + Bs]
     n = len(Ws)
-    out = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
+    # The reference takes the PRODUCT's ReLU masks (its saved post-ReLU activations): a pre-activation within fp32 rounding of
+    # zero may legitimately get either sign, and one flipped unit moves a whole row of dW by O(1) -- at 262144 rows a handful
+    # of such units exist for any pair of correct fp32 evaluations (same device as tests/test_a_metric_shape_gpu.py).
+    saved = []
+
+    def pack(x):
+        saved.append(x)
+        return x
+    with torch.autograd.graph.saved_tensors_hooks(pack, lambda x: x):
+        out = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
+    acts = [x for x in saved if x.dim() == 2 and tuple(x.shape) == (N, 64) and x.data_ptr() != out.data_ptr()]
+    assert len(acts) == n - 1, [tuple(x.shape) for x in saved]
     h = r[0].permute(1, 0, 2).reshape(N, K0)
-    # rows with a hidden pre-activation within fp32 rounding of the ReLU kink: any two correct fp32 evaluations may
-    # disagree on that unit's mask, and the row's INPUT gradient then differs by a whole weight column (one such row in
-    # 262144 here).  Their input gradient is excluded; everything else -- including the weight gradients, to which such a
-    # row contributes |pre| ~ 1e-7 -- is compared in full.  (~1e-4 of the rows.)
-    kink = torch.zeros(N, dtype=torch.bool)
     for i in range(n):
         h = torch.nn.functional.linear(h, r[1 + i], r[1 + n + i])
         if i + 1 < n:
-            kink |= (h.detach().abs() < 4e-7 * h.detach().abs().max()).any(dim=1)
-            h = torch.relu(h)
-    assert int(kink.sum()) <= 2 + N // 2000, int(kink.sum())
+            mask = (acts[i] > 0).double().cpu()
+            flips = int((mask != (h.detach() > 0).double()).sum())
+            assert flips <= 2 + N // 4000, flips      # masks agree except at the kink
+            h = h * mask
     _close("out", out, h)
     w = torch.randn(N, dims[-1], generator=g)
     (out * w.to(dev)).sum().backward(); (h * w.double()).sum().backward()
     for i, (a, b) in enumerate(zip(t, r)):
-        ga, gb = a.grad, b.grad
-        if i == 0:
-            ga, gb = ga.cpu()[:, ~kink], gb[:, ~kink]
-        _close(f"grad{i}", ga, gb, rtol=2e-4, scale_atol=5e-5)
+        _close(f"grad{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
 def test_seq_mlp_routes_to_register_resident_kernels(hip_lib):

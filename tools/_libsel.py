@@ -15,3 +15,6 @@ if "--lib" in sys.argv:
         _L0.LIB_PATH = os.path.join(os.path.dirname(_L0.LIB_PATH), f"libemernerf_{TAG}.so")
         import emernerf_amd._build as _B
         _B.build = lambda *a, **k: _L0.LIB_PATH
+        _L0.ALLOW_MISSING_SYMBOLS = True   # an older build: entry points added since are absent ...
+        import emernerf_amd.fused as _F
+        _F.FUSED_WGRAD = False             # ... so the paths that need them are switched off

@@ -6,11 +6,11 @@ Prints bench.py's JSON line; alternate the two a few times and compare ms_per_st
 import os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import emernerf_amd._build as B
-import emernerf_amd._lib as L
 tag = sys.argv[1] if len(sys.argv) > 1 else "base"
-if tag != "base":
-    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libemernerf_{tag}.so")
-    B.build = lambda *a, **k: L.LIB_PATH
-sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[2:]
+sys.argv = [sys.argv[0], "--lib", tag] + sys.argv[2:]
+from tools import _libsel  # noqa: E402,F401  (selects the library, tolerates entry points an older build lacks)
+if os.environ.get("EMER_NO_FUSED_WGRAD"):
+    import emernerf_amd.fused as _F
+    _F.FUSED_WGRAD = False
+sys.argv = ["bench.py", "--no-cpu-baseline"] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
