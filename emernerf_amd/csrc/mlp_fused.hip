@@ -253,6 +253,64 @@ __device__ __forceinline__ void st_lm(float *enc, int64_t n_total, int n_levels,
     }
 }
 
+// The same accesses with a wave-uniform base (the tile's first row: enc + row0 * F) and 32-bit per-lane offsets: `mrow` is the
+// lane's row inside the tile.  Requires n_total * n_levels * F < 2^30 (host check).
+template <int KT, int F>
+__device__ __forceinline__ void ld_lm_t(const float *base, unsigned n_total, int n_levels, unsigned mrow, int g, f32x4 (&v)[KT]) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        v[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (F == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lv = 16 * t + 4 * g + i;
+                if (lv < n_levels) v[t][i] = base[(unsigned)lv * n_total + mrow];
+            }
+        } else if (F == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lv = 8 * t + 2 * g + j;
+                if (lv < n_levels) {
+                    const float2 x = *reinterpret_cast<const float2 *>(base + ((unsigned)lv * n_total + mrow) * 2u);
+                    v[t][2 * j] = x.x; v[t][2 * j + 1] = x.y;
+                }
+            }
+        } else if (F == 4) {
+            const int lv = 4 * t + g;
+            if (lv < n_levels) v[t] = *reinterpret_cast<const f32x4 *>(base + ((unsigned)lv * n_total + mrow) * 4u);
+        } else {  // F == 8
+            const int lv = 2 * t + (g >> 1);
+            if (lv < n_levels) v[t] = *reinterpret_cast<const f32x4 *>(base + ((unsigned)lv * n_total + mrow) * 8u + 4u * (g & 1));
+        }
+    }
+}
+template <int KT, int F>
+__device__ __forceinline__ void st_lm_t(float *base, unsigned n_total, int n_levels, unsigned mrow, bool ok, int g, const f32x4 (&v)[KT]) {
+    if (!ok) return;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (F == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lv = 16 * t + 4 * g + i;
+                if (lv < n_levels) base[(unsigned)lv * n_total + mrow] = v[t][i];
+            }
+        } else if (F == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lv = 8 * t + 2 * g + j;
+                if (lv < n_levels) *reinterpret_cast<float2 *>(base + ((unsigned)lv * n_total + mrow) * 2u) = make_float2(v[t][2 * j], v[t][2 * j + 1]);
+            }
+        } else if (F == 4) {
+            const int lv = 4 * t + g;
+            if (lv < n_levels) *reinterpret_cast<f32x4 *>(base + ((unsigned)lv * n_total + mrow) * 4u) = v[t];
+        } else {
+            const int lv = 2 * t + (g >> 1);
+            if (lv < n_levels) *reinterpret_cast<f32x4 *>(base + ((unsigned)lv * n_total + mrow) * 8u + 4u * (g & 1)) = v[t];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ neck forward
 struct NeckFwdArgs {
     const float *enc; int64_t n; int32_t n_levels;
@@ -487,45 +545,90 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
         zero<4>(aw1[p]); zero<KT0>(aw0[p]);
         ab1[p] = 0.0f; ab0[p] = 0.0f;
     }
-    const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
-    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
-        const int64_t t0 = c * kNeckChunk;
-        for (int j = 0; j < kNeckChunk && t0 + j < n_tiles; ++j) {
-            const int64_t row = (t0 + j) * 16 + m;
+    // Each wave owns a contiguous range of 16-row tiles.  With two waves per SIMD nothing else hides the HBM latency, so the
+    // inputs of tile t + 1 are in flight while tile t is in the matrix pipe -- WITHOUT holding them in registers (the
+    // accumulators leave none: a register prefetch was spilled to scratch by the compiler, i.e. loaded, waited for and
+    // stored again): h1 and d0 go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, lane-major, so
+    // each lane reads back its own 16 bytes conflict-free); only the small enc tile and the density scalars ride in
+    // registers.  Loads are unconditional (rows past the end re-read row n - 1 and are zeroed at use).
+    const int64_t n_tiles = (a.n + 15) >> 4, n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const int64_t t_begin = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * per_wave;
+    const int64_t t_end = t_begin + per_wave < n_tiles ? t_begin + per_wave : n_tiles;
+    float *stg = reinterpret_cast<float *>(w1l + w3_units(4, 2)) + wave * 2048;   // per wave: h1 tile [4][64][4] | d0 tile [4][64][4]
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    f32x4 xn[KT0];
+    float ddn = 0.0f, den = 0.0f;
+    auto issue = [&](int64_t tile) {   // addressing: the tile is wave-uniform -> one scalar base per tensor, 32-bit lane offsets
+        const int64_t row0 = tile * 16;
+        const unsigned mrow = row0 + m < a.n ? (unsigned)m : (unsigned)(a.n - 1 - row0);
+        const unsigned o64 = mrow * 64u + 4u * g;
+        const float *h1 = a.h1 + row0 * 64;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(h1 + (o64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
+        if (a.d0) {
+            const float *d0 = a.d0 + row0 * 64;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(d0 + (o64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+        }
+        ld_lm_t<KT0, F>(a.enc + row0 * F, (unsigned)a.n, a.n_levels, mrow, g, xn);
+        ddn = a.ddens ? (a.ddens + row0)[mrow] : 0.0f;
+        den = a.ddens ? (a.dens + row0)[mrow] : 0.0f;
+    };
+    struct Raw { f32x4 h[4], d[4], x[KT0]; float dd, de; };
+    if (t_begin < t_end) issue(t_begin);
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        Raw cur;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs have landed (issued one tile ago)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            cur.h[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
+            cur.d[p] = a.d0 ? *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int b = 0; b < KT0; ++b) cur.x[b] = xn[b];
+        cur.dd = ddn; cur.de = den;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging buffer has been read: it may be overwritten
+        issue(tile + 1 < t_end ? tile + 1 : tile);
+        {
+            const int64_t row = tile * 16 + m;
             const bool ok = row < a.n;
-            float fix = 0.0f;
-            if (a.ddens && ok) fix = a.ddens[row] * fminf(a.dens[row], 3269017.3724721107f);
-            // h1: operand of dW1 (rows on the reduction index) and relu'(h1) as 16 bits (h1 >= 0: positive iff its leading
-            // bf16 term is non-zero)
+            const float fix = ok ? cur.dd * fminf(cur.de, 3269017.3724721107f) : 0.0f;
+            // h1: operand of dW1 (rows on the reduction index) and relu'(h1) as 16 bits
             SwT hs[4];
             unsigned relu_bits = 0u;
             {
-                f32x4 mk[4];
-                ld_rm<4>(a.h1 + row * 64, ok, g, mk);
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) relu_bits |= (mk[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                    for (int i = 0; i < 4; ++i) {
+                        cur.h[p][i] = ok ? cur.h[p][i] : 0.0f;
+                        relu_bits |= (cur.h[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                    }
                 Opd<2> ho;
-                make_opd<4>(mk, ho);
+                make_opd<4>(cur.h, ho);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) hs[p] = to_rows<2>(ho, p, sel);
             }
             f32x4 da[4];
             zero<4>(da);
             {
-                f32x4 lo[4];
-                if (a.d0) ld_rm<4>(a.d0 + row * 64, ok, g, lo); else zero<4>(lo);
-                if (g == 0) lo[0][0] += fix;
-                Opd<2> dop;
-                make_opd<4>(lo, dop);
-                tgemm<2, 4>(w1p, dop, da);
-                SwT ds[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) ds[p] = to_rows<2>(dop, p, sel, &ab1[p]);
-                __builtin_amdgcn_sched_barrier(0);
-                dw_tiles<4, 4>(aw1, ds, hs);   // dW1 += d^T h1
-                __builtin_amdgcn_sched_barrier(0);
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cur.d[p][i] = ok ? cur.d[p][i] : 0.0f;
+                if (g == 0) cur.d[0][0] += fix;
+                Opd<2> dop;
+                make_opd<4>(cur.d, dop);
+                tgemm<2, 4, false>(w1p, dop, da);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {   // dW1 rows 16 p .. += d^T h1, one row block of tiles at a time
+                    SwT ds[1];
+                    ds[0] = to_rows<2>(dop, p, sel, &ab1[p]);
+                    dw_tiles<1, 4>(*reinterpret_cast<f32x4 (*)[1][4]>(&aw1[p]), ds, hs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p)
@@ -535,21 +638,27 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             make_opd<4>(da, dao);
             f32x4 de[KT0];
             zero<KT0>(de);
-            tgemm<2, KT0>(w0p, dao, de);
-            st_lm<KT0, F>(a.denc, a.n, a.n_levels, row, ok, g, de);
+            tgemm<2, KT0, false>(w0p, dao, de);
+            st_lm_t<KT0, F>(a.denc + tile * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, ok, g, de);
             {   // dW0 += dPre0^T enc
-                SwT xs[KT0], ds[4];
+                SwT xs[KT0];
                 {
-                    f32x4 x[KT0];
-                    ld_lm<KT0, F>(a.enc, a.n, a.n_levels, row, ok, g, x);
+#pragma unroll
+                    for (int b = 0; b < KT0; ++b)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cur.x[b][i] = ok ? cur.x[b][i] : 0.0f;
                     Opd<(KT0 + 1) / 2> xo;
-                    make_opd<KT0>(x, xo);
+                    make_opd<KT0>(cur.x, xo);
 #pragma unroll
                     for (int b = 0; b < KT0; ++b) xs[b] = to_rows<(KT0 + 1) / 2>(xo, b, sel);
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p) ds[p] = to_rows<2>(dao, p, sel, &ab0[p]);
-                dw_tiles<4, KT0>(aw0, ds, xs);
+                for (int p = 0; p < 4; ++p) {
+                    SwT ds[1];
+                    ds[0] = to_rows<2>(dao, p, sel, &ab0[p]);
+                    dw_tiles<1, KT0>(*reinterpret_cast<f32x4 (*)[1][KT0]>(&aw0[p]), ds, xs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -1040,13 +1149,14 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
 
 // ---- neck backward with the weight gradients fused [r3] --------------------------------------------------------------------
 static inline uint32_t neck_bwdw_grid(int64_t n) {
-    const int64_t chunks = ((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk;
-    int64_t blocks = (chunks + kWThreads / 64 - 1) / (kWThreads / 64);
+    const int64_t tiles = (n + 15) / 16;
+    int64_t blocks = (tiles + kWThreads / 64 - 1) / (kWThreads / 64);
     if (blocks > 512) blocks = 512;   // persistent: two 4-wave workgroups per CU
     return (uint32_t)(blocks < 1 ? 1 : blocks);
 }
-static inline size_t neck_bwdw_lds(int kt0) {
-    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2)) * 16, r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
+static inline size_t neck_bwdw_lds(int kt0) {   // weights + a staging buffer of 8 KB per wave; the final reduction reuses the front
+    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2)) * 16 + (size_t)(kWThreads / 64) * 2048 * sizeof(float);
+    const size_t r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
     return w > r ? w : r;
 }
 static inline int64_t neck_bwdw_stride(int k0) { return (int64_t)64 * 64 + 64 + 64 * (int64_t)k0 + 64; }
@@ -1056,9 +1166,10 @@ static inline int64_t neck_bwdw_stride(int k0) { return (int64_t)64 * 64 + 64 + 
 extern "C" int emer_neck_bwd_fused_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out) {
     return (emer_neck_supported(n_levels, n_feat, hidden, n_out) && n_out == 64) ? 1 : 0;
 }
+static inline bool neck_bwdw_fits(int32_t n_levels, int32_t n_feat, int64_t n) { return n * n_levels * n_feat < (1ll << 30); }  // 32-bit lane offsets
 // floats of workspace emer_neck_bwd_fused needs (per-workgroup partial weight gradients)
 extern "C" int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out) {
-    if (n <= 0 || !emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out)) return 0;
+    if (n <= 0 || !emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out) || !neck_bwdw_fits(n_levels, n_feat, n)) return 0;
     return (int64_t)neck_bwdw_grid(n) * neck_bwdw_stride(n_levels * n_feat);
 }
 // Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
@@ -1071,6 +1182,7 @@ extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const fl
     EMER_REQUIRE(n >= 0, "neck_bwd_fused: negative n");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out), "neck_bwd_fused: unsupported shape L=%d F=%d n_out=%d", n_levels, n_feat, n_out);
+    EMER_REQUIRE(neck_bwdw_fits(n_levels, n_feat, n), "neck_bwd_fused: n * L * F must stay below 2^30 (32-bit lane offsets); split the batch or use emer_neck_bwd");
     EMER_REQUIRE(h1 && enc_lm && w0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1, "neck_bwd_fused: null pointer");
     EMER_REQUIRE(!ddens || dens, "neck_bwd_fused: ddens needs the saved density");
     const int k0 = n_levels * n_feat;
