@@ -113,6 +113,19 @@ def lm_to_rm(enc_lm: Tensor) -> Tensor:
     return _LmToRmFn.apply(enc_lm)
 
 
+def _table_grad_via_autograd(param, grad):
+    """A table gradient that is handed BACK to autograd (AccumulateGrad will add it onto ``param.grad``).  A trainer that
+    skips zeroing table gradients (``FlatParams.zero_grad`` marks them ``_emer_grad_fresh`` instead: the owner-computes
+    backward overwrites them) leaves last step's values in ``.grad``; every path that does not overwrite must therefore zero
+    the stale buffer first and clear the mark -- otherwise AccumulateGrad adds onto stale data and ``finish_grads`` later zeroes
+    the sum (the row-major / atomic / fp16 fallbacks trained with a zero gradient)."""
+    if grad is not None and param is not None and getattr(param, "_emer_grad_fresh", False):
+        if param.grad is not None:
+            param.grad.zero_()
+        param._emer_grad_fresh = False
+    return grad
+
+
 class _HashGridFn(torch.autograd.Function):
     """tcnn ``_module_function`` (third_party/tcnn_modules.py:115-174) on HIP.
 
@@ -133,6 +146,8 @@ class _HashGridFn(torch.autograd.Function):
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
         out = layout_transpose(lm, L, N, F, to_row_major=True)
         ctx.desc, ctx.grad_dtype = desc, grad_dtype
+        ctx.param_obj = params
+        _count_table_eval(params)
         ctx.save_for_backward(xc, pc, masks)
         return out
 
@@ -142,6 +157,7 @@ class _HashGridFn(torch.autograd.Function):
         desc = ctx.desc
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         dx = dp = None
+        _before_table_grad(ctx.param_obj)
         with torch.cuda.device(xc.device):
             dlm = layout_transpose(_f32c(dout), L, N, F, to_row_major=False)
             st = _stream(xc)
@@ -156,12 +172,30 @@ class _HashGridFn(torch.autograd.Function):
                     grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)
-                dp = grad.to(pc.dtype) if grad.dtype != pc.dtype else grad
+                dp = _table_grad_via_autograd(ctx.param_obj, grad.to(pc.dtype) if grad.dtype != pc.dtype else grad)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xc)
                 _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,
                           N * F, _ptr(dx), N, st)
         return dx, dp, None, None
+
+
+def _count_table_eval(param) -> None:
+    """Data-parallel trainers hang ``_emer_before_table_grad`` on the table whose backward runs LAST in a step.  If that
+    encoder is evaluated more than once per step (warped positions, chunked training), only the backward of its FIRST
+    forward evaluation is the last one to run; the evaluations are counted here so the callback fires exactly then."""
+    if getattr(param, "_emer_before_table_grad", None) is not None:
+        param._emer_pending_evals = getattr(param, "_emer_pending_evals", 0) + 1
+
+
+def _before_table_grad(param) -> None:
+    cb = getattr(param, "_emer_before_table_grad", None)
+    if cb is None:
+        return
+    left = getattr(param, "_emer_pending_evals", 1) - 1
+    param._emer_pending_evals = max(left, 0)
+    if left <= 0:  # the last backward of this table in the step: everything upstream has its gradient enqueued by now
+        cb()
 
 
 class _HashGridLMFn(torch.autograd.Function):
@@ -188,6 +222,7 @@ class _HashGridLMFn(torch.autograd.Function):
         sink = fused._sink(params) if ctx.sliced else None
         ctx.param = params if (sink is not None and sink.is_contiguous() and sink.numel() == pc.numel()) else None
         ctx.param_obj = params
+        _count_table_eval(params)
         ctx.save_for_backward(xc, pc, masks)
         return lm
 
@@ -197,9 +232,7 @@ class _HashGridLMFn(torch.autograd.Function):
         desc = ctx.desc
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         dx = dp = None
-        cb = getattr(ctx.param_obj, "_emer_before_table_grad", None)
-        if cb is not None:  # data-parallel trainer: everything upstream of this table has its gradient enqueued by now
-            cb()
+        _before_table_grad(ctx.param_obj)  # data-parallel trainer: early gradient bucket (fires on the table's last backward)
         with torch.cuda.device(xc.device):
             dlm = _f32c(dlm)
             st = _stream(xc)
@@ -221,7 +254,7 @@ class _HashGridLMFn(torch.autograd.Function):
                     grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)
-                dp = None if grad is None else (grad.to(pc.dtype) if grad.dtype != pc.dtype else grad)
+                dp = None if grad is None else _table_grad_via_autograd(ctx.param_obj, grad.to(pc.dtype) if grad.dtype != pc.dtype else grad)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xc)
                 _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,

@@ -100,21 +100,30 @@ class PixelSource:
     def _next_seed(self) -> None:
         self.seed_word.add_(0x9E3779B9)  # device-side: graph-capturable
 
-    def sample_uniform_rays(self, num_rays: int, img_candidate_indices=None) -> Tuple[Tensor, Tensor, Tensor]:
-        """:622-668 -> (img_id, y, x), int64 [num_rays]."""
+    def sample_uniform_rays(self, num_rays: int, img_candidate_indices=None, advance: bool = True) -> Tuple[Tensor, Tensor, Tensor]:
+        """:622-668 -> (img_id, y, x), int64 [num_rays].  Every call draws fresh pixels (the seed word advances on the device;
+        ``advance=False``: the caller advances it once for a group of draws, as get_train_rays does)."""
         cand, n_c = self._candidates(img_candidate_indices)
         img, y, x = (torch.empty(num_rays, dtype=torch.int64, device=self.device) for _ in range(3))
         with torch.cuda.device(self.device):
             _lib.call("emer_sample_uniform", _ptr(self.seed_word), _SALT_UNIFORM, num_rays, _ptr(cand), n_c, self.HEIGHT, self.WIDTH,
                       _ptr(img), _ptr(y), _ptr(x), _stream(img))
+        if advance:
+            self._next_seed()
         return img, y, x
 
-    def sample_important_rays(self, num_rays: int, img_candidate_indices=None) -> Tuple[Tensor, Tensor, Tensor]:
+    def sample_important_rays(self, num_rays: int, img_candidate_indices=None, advance: bool = True,
+                              check_support: bool = True) -> Tuple[Tensor, Tensor, Tensor]:
         """:564-620: multinomial over the error buffer of the candidate images WITHOUT replacement, then a random pixel of
-        the chosen buffer cell."""
+        the chosen buffer cell.  Like torch.multinomial, asking for more samples than there are cells of positive weight is
+        an error (``check_support``: one device->host read; a captured graph passes False after checking once)."""
         assert self.pixel_error_buffered, "Pixel error buffer not built."
         cand, n_c = self._candidates(img_candidate_indices)
         maps = self.pixel_error_maps if cand is None else self.pixel_error_maps[cand].contiguous()
+        if check_support:
+            n_pos = int((maps > 0).sum())
+            if num_rays > n_pos:
+                raise RuntimeError(f"sample_important_rays: cannot draw {num_rays} cells without replacement from {n_pos} cells of positive weight")
         Hb, Wb = maps.shape[1:]
         flat = torch.empty(num_rays, dtype=torch.int64, device=self.device)
         img, y, x = (torch.empty(num_rays, dtype=torch.int64, device=self.device) for _ in range(3))
@@ -123,6 +132,8 @@ class PixelSource:
             _lib.call("emer_sample_importance", _ptr(maps), maps.numel(), _ptr(self.seed_word), _SALT_RACE, num_rays, _ptr(self._ws), _ptr(flat), st)
             _lib.call("emer_buffer_to_pixels", _ptr(flat), num_rays, Hb, Wb, self.buffer_downscale, _ptr(cand), self.HEIGHT, self.WIDTH,
                       _ptr(self.seed_word), _SALT_CELL, _ptr(img), _ptr(y), _ptr(x), st)
+        if advance:
+            self._next_seed()
         return img, y, x
 
     # ---------------------------------------------------------------------------------------------------- rays
@@ -152,11 +163,11 @@ class PixelSource:
         """:670-731: ``buffer_ratio`` of the batch from the error buffer (once it exists), the rest uniform."""
         if self.buffer_ratio > 0 and self.pixel_error_buffered:
             n_roi = int(num_rays * self.buffer_ratio)
-            ri, ry, rx = self.sample_uniform_rays(num_rays - n_roi, candidate_indices)
-            bi, by, bx = self.sample_important_rays(n_roi, candidate_indices)
+            ri, ry, rx = self.sample_uniform_rays(num_rays - n_roi, candidate_indices, advance=False)
+            bi, by, bx = self.sample_important_rays(n_roi, candidate_indices, advance=False)
             img_idx, y, x = torch.cat([ri, bi]), torch.cat([ry, by]), torch.cat([rx, bx])
         else:
-            img_idx, y, x = self.sample_uniform_rays(num_rays, candidate_indices)
+            img_idx, y, x = self.sample_uniform_rays(num_rays, candidate_indices, advance=False)
         self._next_seed()
         return self._gather(img_idx, y, x)
 

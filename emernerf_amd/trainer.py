@@ -255,6 +255,9 @@ class Trainer:
         self.use_graph, self._graphs, self._static_data = use_graph, {}, None
         self.requires_grad_fn = get_proposal_requires_grad_fn()
         self.step_count = 0
+        # LR-scheduler ticks: the reference calls scheduler.step() after the pixel optimizer step AND after the lidar one
+        # (train_emernerf.py:745, :826), so with lidar supervision the warm-up and the milestones advance twice per iteration
+        self.sched_ticks = 0
         # early all-reduce bucket: the dense (non-table) parameters of the main model
         a, b = self.flat.ranges["main"]
         self._early_ranges = [(lo, hi) for lo, hi in self.flat._dense_ranges if a <= lo and hi <= b]
@@ -315,10 +318,11 @@ class Trainer:
             (loss * self.loss_scale).backward()
         fused.join_side_stream()
         self._exchange_grads(prop_grad)
-        lr = self.lr * lr_factor(step, self.num_iters)
+        lr = self.lr * lr_factor(self.sched_ticks, self.num_iters)
         if prop_grad:
             self._adam("prop", lr)
         self._adam("main", lr)
+        self.sched_ticks += 1
         return {"loss": loss.detach(), "prop_grad": prop_grad}
 
     # ------------------------------------------------------------------------------------------- data parallel
@@ -328,6 +332,7 @@ class Trainer:
         (small) all-reduce starts here and runs on RCCL's stream while the grid backward -- the longest kernel of the
         step -- computes the table gradient.  Only the table bucket is exposed at the end of the backward."""
         if self.world_size > 1 and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
+            fused.join_side_stream()  # weight gradients written on the side stream (off by default) must be complete
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
             self._early_done = True
 
@@ -363,6 +368,8 @@ class Trainer:
             if self._prop_work is not None:
                 self._prop_work.wait()
         self._early_done, self._early_work, self._prop_work = False, [], None
+        if self.world_size > 1:
+            self.model.xyz_encoder.tcnn_encoding.params._emer_pending_evals = 0
 
     def _adam(self, group: str, lr: float):
         a, b = self.flat.ranges[group]
@@ -429,9 +436,10 @@ class Trainer:
         else:
             loss = self._forward_backward(data, prop_grad)
         self._exchange_grads(prop_grad)
-        lr = self.lr * lr_factor(step, self.num_iters)
+        lr = self.lr * lr_factor(self.sched_ticks, self.num_iters)
         if prop_grad:
             self._adam("prop", lr)
         self._adam("main", lr)
         self.step_count += 1
+        self.sched_ticks += 1
         return {"loss": loss, "prop_grad": prop_grad}

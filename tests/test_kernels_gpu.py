@@ -606,6 +606,14 @@ def test_importance_sampling_without_replacement(hip_lib):
     assert b["origins"].shape == (400, 3)
     roi = b["img_idx"].cpu()[320:]  # the last fifth (80 rays) comes from the buffer: only images 2 and 4 (97 cells) carry error
     assert set(roi.tolist()) <= {2, 4}
+    # the public sampling methods draw fresh pixels on every call (the seed only advanced in get_train_rays) ...
+    u1, u2 = src.sample_uniform_rays(256), src.sample_uniform_rays(256)
+    assert not all(torch.equal(a, b_) for a, b_ in zip(u1, u2))
+    i1, i2 = src.sample_important_rays(40), src.sample_important_rays(40)
+    assert not all(torch.equal(a, b_) for a, b_ in zip(i1, i2))
+    # ... and, like torch.multinomial, refuse to draw more cells without replacement than carry weight (97 here)
+    with pytest.raises(RuntimeError, match="positive weight"):
+        src.sample_important_rays(98)
 
 
 # ---------------------------------------------------------------------------------------------- lidar losses
