@@ -26,7 +26,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32-input matrix peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (MI355X_MICROARCH.md); the heads run exact 3-term bf16 splits on it
+FP32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input matrix peak, for reference (round 2 ran the heads on it)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 N_BATCHES = 8  # seeded ray batches rotated through the steps (a new batch every step)
 
@@ -95,11 +96,25 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
                       f"threads + OpenMP; {dt:.1f} s"}
 
 
+def source_hash() -> str:
+    """sha256[:16] of the kernel sources (csrc/*.hip, *.h, include/*.h): what a recorded measurement is valid for.  The GPU
+    box has no .git, so a commit id cannot be checked there; the sources of the library that ran can."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "emernerf_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if fn.endswith((".hip", ".h")) and "_variant_" not in fn:
+            h.update(os.path.basename(fn).encode())
+            h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(dominant: str, D: int, F: int, args):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
     (profiles/r*_hbm_traffic.json).  FETCH_SIZE and WRITE_SIZE need separate profiler passes of this command
     (tools/profile_round.sh), so they cannot be collected inside this process; the file name is reported next to the
-    number.  Only valid for the default workload the summary was recorded on; null otherwise."""
+    number.  Only valid for the default workload AND the kernel sources the summary was recorded on: the summary carries
+    `source_sha16` (tools/profile_round.sh stamps it) and a summary of other sources gives null, with the reason."""
     import glob
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     files = sorted(glob.glob(os.path.join(root, "r*_hbm_traffic.json")))
@@ -108,6 +123,9 @@ def pmc_traffic(dominant: str, D: int, F: int, args):
     path = files[-1]
     try:
         j = json.load(open(path))
+        if j.get("source_sha16") != source_hash():
+            return None, (f"profiles/{os.path.basename(path)} was recorded on kernel sources {j.get('source_sha16')}, this run has "
+                          f"{source_hash()}: not reported (re-run tools/profile_round.sh)")
         kern = {"emer_hashgrid_bwd_params_sliced": f"hashgrid_bwd_params_sliced_kernel<{D}, {F}>",
                 "emer_hashgrid_fwd": f"hashgrid_fwd_kernel<{D}, {F}, float>"}[dominant]
         return j["kernels"][kern]["hbm_bytes"], (f"profiles/{os.path.basename(path)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
@@ -133,6 +151,52 @@ def rccl_summary(path, world):
     return {"world_size": world, "backend": "nccl (RCCL)", "log_lines_total": n, "log_excerpt": keep}
 
 
+def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: int, init_steps: int, start_step: int = 1000):
+    """A short run of another BASELINE config on this GPU (rank 0, single GPU): ms/step, rays/s and the roofline of its xyzt
+    encoders, with the same step definition as the headline (full optimizer step, a new seeded batch every step)."""
+    from emernerf_amd import _lib
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    tr = Trainer(kind=kind, device=dev, num_samples=samples, world_size=1)
+    tr.step_count = start_step
+    for s_ in range(start_step):
+        tr.requires_grad_fn(s_)
+    kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
+    batches = [synthetic_rays(rays, dev, seed=3000 + i, **kw) for i in range(4)]
+    for i in range(init_steps + warmup):
+        tr.train_step(batches[i % 4])
+    timer = _lib.KernelTimer(["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input"])
+    _lib.TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(batches[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    _lib.TIMER = None
+    us, tags = timer.elapsed_us(), timer.tags
+    N = rays * samples
+    out = {"kind": kind, "rays": rays, "samples": samples, "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": rays / dt}
+    dyn = tr.cfg.dynamic_xyz_encoder
+    D4, L4, F4 = dyn.n_input_dims, dyn.n_levels, dyn.n_features_per_level
+    f4 = [u for u, tg in zip(us["emer_hashgrid_fwd"], tags["emer_hashgrid_fwd"]) if tg == (D4, L4, F4)]
+    b4 = [u for u, tg in zip(us["emer_hashgrid_bwd_params_sliced"], tags["emer_hashgrid_bwd_params_sliced"]) if tg == (D4, L4, F4)]
+    i4 = [u for u, tg in zip(us["emer_hashgrid_bwd_input"], tags["emer_hashgrid_bwd_input"]) if tg == (D4, L4, F4)]
+    if f4 and b4:
+        fb4, bb4 = grid_alg_bytes(D4, L4, F4)
+        # samples per launch differ once evaluations are batched: bytes are counted per SAMPLE EVALUATION of the step
+        evals = {"dynamic": 1, "flow": 6, "feature": 6}[kind]   # xyzt evaluations per sample: current (+ both warps), dynamic and flow grids
+        out["roofline_xyzt"] = {
+            "grid": f"D{D4}/L{L4}/F{F4}/T2^{dyn.log2_hashmap_size}", "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "launches_per_step": {"fwd": len(f4) / steps, "bwd": len(b4) / steps, "bwd_input": len(i4) / steps},
+            "ms_per_step": {"fwd": sum(f4) / 1e3 / steps, "bwd": sum(b4) / 1e3 / steps, "bwd_input": sum(i4) / 1e3 / steps},
+            "sample_evaluations_per_step": evals * N, "algorithmic_bytes_per_sample": {"fwd": fb4, "bwd": bb4},
+            "frac_fwd": fb4 * evals * N / (sum(f4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS,
+            "frac_bwd": bb4 * evals * N / (sum(b4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +214,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the lidar-step and eval-render measurements")
     ap.add_argument("--no-second-state", action="store_true", help="skip the trained-like (table_init 0.3) roofline pass")
     ap.add_argument("--graph", action="store_true", help="replay the forward+backward of a step as a captured hipGraph")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2..3] (dynamic, flow, flow at "
+                    "the 2048-ray per-rank shard of configs[3])")
+    ap.add_argument("--secondary-steps", type=int, default=0, help="timed steps of each secondary run (0: min(--steps, 12))")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before the HIP runtime starts
@@ -314,6 +381,18 @@ def main():
         torch.cuda.synchronize()
         _lib.TIMER = None
         del t2
+    # BASELINE configs[2..3] on the same code path, short runs (parity-test configurations, reported next to the headline so
+    # that the driver's line carries them): dynamic and flow at 8192 x 128, and flow at 2048 x 128 -- the per-rank shard of
+    # configs[3] ("16384 rays over 8 GPUs")
+    secondary = None
+    if rank == 0 and world == 1 and args.kind == "static" and not args.no_secondary:
+        ss = args.secondary_steps or min(args.steps, 12)
+        secondary = []
+        for kind_, rays_ in (("dynamic", args.rays), ("flow", args.rays), ("flow", max(args.rays // 4, 256))):
+            try:
+                secondary.append(measure_config(kind_, rays_, args.samples, dev, steps=ss, warmup=4, init_steps=14))
+            except Exception as e:  # reporting only
+                secondary.append({"kind": kind_, "rays": rays_, "error": repr(e)})
     if world > 1:
         dist.barrier()
 
@@ -373,22 +452,31 @@ def main():
                     "(8192 rays per GPU; the config names 16384 rays over 8 GPUs)",
             "feature": "BASELINE.json configs[4]: flow model + feature head (E=64) + learnable PE, 3 cameras (8192 rays per GPU)",
         }
-        # fp32-MFMA rooflines of the head kernels (static configuration only: hidden 64, geo 64): algorithmic flops of
-        # one launch / its average duration in the instrumented pass, vs the dense fp32 matrix peak
+        # Matrix-pipe rooflines of the head kernels (static configuration only: hidden 64, geo 64).  `achieved` = algorithmic
+        # (fp32-equivalent) flops of one launch / its average duration in the instrumented pass; the kernels execute SIX
+        # bf16 partial products per fp32 product (exact 3-term splits, csrc/mlp_fused.hip), so the bf16 pipe does 6x that
+        # (`executed`; the fused backward additionally transposes through the matrix core and fills only half the K of its
+        # weight-gradient instructions: x 2 on those) and `frac` = executed / 2.5 PFLOP/s dense bf16.
         mfma = {}
         if args.kind == "static":
             k0 = L * F
             n_out = trainer.model.base_mlp[2].out_features
-            flops = {"emer_neck_fwd": 2.0 * N * (k0 * 64 + 64 * n_out), "emer_neck_bwd": 2.0 * N * (64 * 64 + 64 * k0),
-                     "emer_rgb_head_fwd": 2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), "emer_rgb_head_bwd": 2.0 * N * (3 * 64 + 3 * 64 * 64)}
-            for kn, fl in flops.items():
+            dgrad_neck, wgrad_neck = 2.0 * N * (64 * 64 + 64 * k0), 2.0 * N * (64 * n_out + 64 * k0)
+            flops = {"emer_neck_fwd": (2.0 * N * (k0 * 64 + 64 * n_out), 6.0),
+                     "emer_neck_bwd": (dgrad_neck, 6.0),
+                     "emer_neck_bwd_fused": (dgrad_neck + wgrad_neck, None),
+                     "emer_rgb_head_fwd": (2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),
+                     "emer_rgb_head_bwd": (2.0 * N * (3 * 64 + 3 * 64 * 64), 6.0)}
+            for kn, (fl, mult) in flops.items():
                 v = [u for u in breakdown.elapsed_us().get(kn, [])]
                 if kn.startswith("emer_neck"):  # main-field launches only (the proposal nets are the short ones)
                     v = sorted(v)[-max(1, breakdown_steps):]
                 if v:
                     t = sum(v) / len(v)
-                    mfma[kn] = {"avg_us": t, "achieved": fl / (t * 1e-6) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                    ex = fl * mult if mult is not None else 6.0 * dgrad_neck + 12.0 * wgrad_neck + 3.0 * 2.0 * N * 16 * (3 * 64 + k0)
+                    mfma[kn] = {"avg_us": t, "achieved": fl / (t * 1e-6) / 1e12, "executed": ex / (t * 1e-6) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": ex / (t * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                "vs_fp32_matrix_peak": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         out = {
             "metric": "train rays/sec (8192-ray batch, 128 samples)",
             "value": world * args.rays * args.steps / elapsed,
@@ -401,6 +489,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": "fp32 parameters, activations, gradients and accumulation; the 64-wide head GEMMs evaluate each fp32 product as six "
+                          "bf16 partial products of an exact three-term split (error of the order of fp32 rounding; parity tests at the "
+                          "fp32 kernels' tolerances)",
             "data": "synthetic",
             "config": {"workload": f"{workloads[args.kind]}, xyz hash grid D{D}/L{L}/F{F}/T2^{c.log2_hashmap_size} "
                                    f"(fp32 tables, the reference's precision) + base MLP {L * F}->64->64 + rgb head 113->64->[177]->64->3 "
@@ -420,6 +511,8 @@ def main():
             "lidar_step": extra.get("lidar_step"),
             "eval_render": extra.get("eval_render"),
             "roofline_mfma": mfma,
+            "secondary": secondary,
+            "source_sha16": source_hash(),
             "kernels": per_kernel,
             "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "
                             "timed region; the roofline kernels are timed with HIP events inside the timed region itself",

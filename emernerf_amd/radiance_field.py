@@ -107,6 +107,9 @@ class MLP(nn.Module):
         return x
 
 
+BATCH_XYZT = True  # flow configs: evaluate each xyzt table once per dependency level (RadianceField._flow_branch_batched)
+
+
 class RadianceField(nn.Module):
     """radiance_fields/radiance_field.py:20-785."""
 
@@ -367,6 +370,61 @@ class RadianceField(nn.Module):
             "backward_dynamic_hash_encodings": bwd_enc,
         }
 
+    def _flow_branch_batched(self, positions: Tensor, normed_positions: Tensor, normed_timestamps: Tensor,
+                             want_hash: bool) -> Optional[Dict[str, Tensor]]:
+        """The flow branch of ``forward`` (:434-459 + temporal_aggregation :553-620) with every xyzt table evaluated in as few
+        launches as the data flow allows: the flow grid at the current positions (N samples) -> flow MLP -> warped positions ->
+        the dynamic grid ONCE at [current | forward-warped | backward-warped] (3N samples, one encode, one neck, one owner-
+        computes backward) and the flow grid ONCE at both warped sets (2N).  Six encodes / six table backwards / four input-
+        gradient launches of the call-by-call order become 3 / 3 / 2, and each table's slices are scanned, accumulated and
+        flushed once per step instead of three times (no 40 MB temporaries merged with add_).  Same arithmetic per sample.
+        Returns None when a stack is not covered by the fused kernels (the caller then takes the call-by-call path)."""
+        enc_d, enc_f = self.dynamic_xyz_encoder.tcnn_encoding, self.flow_xyz_encoder.tcnn_encoding
+        mlp = self.dynamic_base_mlp
+        n_out = mlp[2].out_features
+        lins = [m for m in self.flow_mlp if isinstance(m, nn.Linear)]
+        if not (normed_positions.is_cuda and positions is not None and self.geometry_feature_dim == 64
+                and n_out == 64 + self.semantic_feature_dim
+                and fused.neck_supported(enc_d.desc.n_levels, enc_d.desc.n_features, mlp[0].out_features, n_out)
+                and len(lins) == 3 and all(l.bias is not None for l in lins)
+                and fused.rmlp_supported([l.weight for l in lins], enc_f.desc.n_levels * enc_f.desc.n_features, enc_f.desc.n_features)):
+            return None
+        if normed_timestamps.shape[-1] != 1:
+            normed_timestamps = normed_timestamps.unsqueeze(-1)
+        lead = normed_positions.shape[:-1]
+        D4 = self.num_dims + 1
+        ts = normed_timestamps.to(normed_positions.dtype)
+        x_cur = torch.cat([normed_positions, ts], dim=-1).reshape(-1, D4)
+        N = x_cur.shape[0]
+        fw, fb = [l.weight for l in lins], [l.bias for l in lins]
+        # (1) flow at the current positions
+        flow = fused.seq_mlp_lm(enc_f.forward_level_major(x_cur), fw, fb).view(*lead, 6)
+        forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
+        # (2) warped positions and times (:567-580)
+        noise = self._noise(forward_flow)
+        fwd_pos = self.contract_points(positions + forward_flow * noise)
+        bwd_pos = self.contract_points(positions + backward_flow * noise)
+        fwd_t = torch.clamp(ts + self.time_diff * noise, 0, 1.0)
+        bwd_t = torch.clamp(ts - self.time_diff * noise, 0, 1.0)
+        x_fwd = torch.cat([fwd_pos, fwd_t.to(fwd_pos.dtype)], dim=-1).reshape(-1, D4)
+        x_bwd = torch.cat([bwd_pos, bwd_t.to(bwd_pos.dtype)], dim=-1).reshape(-1, D4)
+        # (3) dynamic table: one evaluation of 3N samples, one neck
+        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0))
+        geo3, sem3, _ = fused.neck(enc3, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+        feats3 = geo3 if sem3 is None else torch.cat([geo3, sem3], dim=-1)
+        cur_f, fwd_f, bwd_f = (t.view(*lead, -1) for t in feats3.split(N, dim=0))
+        # (4) flow table at both warped sets: one evaluation of 2N samples
+        flow2 = fused.seq_mlp_lm(enc_f.forward_level_major(torch.cat([x_fwd, x_bwd], dim=0)), fw, fb)
+        fwd_pred, bwd_pred = (t.view(*lead, 6) for t in flow2.split(N, dim=0))
+        out = {"forward_flow": forward_flow, "backward_flow": backward_flow,
+               "dynamic_feats": (cur_f + 0.5 * fwd_f + 0.5 * bwd_f) / 2.0,
+               "forward_pred_backward_flow": fwd_pred[..., 3:], "backward_pred_forward_flow": bwd_pred[..., :3]}
+        if want_hash:  # row-major copies of the encodings: part of forward()'s contract (:453-459, 615-617), consumed by nobody
+            cur_h, fwd_h, bwd_h = (t.view(*lead, -1) for t in ops.lm_to_rm(enc3).split(N, dim=0))
+            out.update({"forward_dynamic_hash_encodings": fwd_h, "backward_dynamic_hash_encodings": bwd_h,
+                        "current_dynamic_hash_encodings": cur_h})
+        return out
+
     @staticmethod
     def _per_ray(t: Tensor) -> bool:
         """True for a (R, S[, C]) tensor that is a stride-0 broadcast of per-ray values along S (what
@@ -467,9 +525,11 @@ class RadianceField(nn.Module):
     def forward(self, positions: Tensor, directions: Tensor = None, data_dict: Dict[str, Tensor] = {},
                 return_density_only: bool = False, combine_static_dynamic: bool = False,
                 query_feature_head: bool = True, query_pe_head: bool = True,
-                normed_positions: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                normed_positions: Optional[Tensor] = None, hash_encodings: bool = True) -> Dict[str, Tensor]:
         """``normed_positions`` (extension): the contracted positions when the caller already has them (render_rays
-        gets them from the ray-point kernel); ``positions`` may then be None unless the flow branch is on."""
+        gets them from the ray-point kernel); ``positions`` may then be None unless the flow branch is on.
+        ``hash_encodings`` (extension): False drops the three row-major ``*_dynamic_hash_encodings`` outputs of the flow
+        branch ("to be studied" in the reference, consumed by nothing): render_rays never reads them."""
         results_dict = {}
         if normed_positions is None:
             normed_positions = self.contract_points(positions)
@@ -481,9 +541,16 @@ class RadianceField(nn.Module):
             normed_timestamps = data_dict["normed_timestamps"] if "normed_timestamps" in data_dict \
                 else data_dict["lidar_normed_timestamps"]
             use_flow = self.flow_xyz_encoder is not None
-            dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
-                normed_positions, normed_timestamps, want_density=not use_flow, want_hash=use_flow)
-            if use_flow:
+            batched = self._flow_branch_batched(positions, normed_positions, normed_timestamps, hash_encodings) \
+                if (use_flow and BATCH_XYZT) else None
+            if batched is not None:
+                dynamic_feats = batched["dynamic_feats"]
+                results_dict.update(batched)
+                dynamic_density = ops.trunc_exp_column(dynamic_feats, 0)
+            else:
+                dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
+                    normed_positions, normed_timestamps, want_density=not use_flow, want_hash=use_flow)
+            if use_flow and batched is None:
                 flow = self.forward_flow_hash(normed_positions, normed_timestamps)
                 forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
                 results_dict["forward_flow"] = forward_flow

@@ -157,7 +157,7 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         normed, positions = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
                                            radiance_field.aabb, radiance_field.unbounded, want_positions=want_pos)
         results_dict = radiance_field(positions, t_dirs, sub_dict, return_density_only=(prefix == "lidar_"),
-                                      normed_positions=normed)
+                                      normed_positions=normed, hash_encodings=False)  # rendering() reads none of them
         results_dict["density"] = results_dict["density"].squeeze(-1)
         return results_dict
 

@@ -25,6 +25,7 @@ GRIDS = {
     "cfg2_static": (3, 16, 16, 2048, 19, 2),       # HashEncoder defaults, encodings.py:110-118 (BASELINE configs[1])
     "default_static": (3, 10, 16, 8192, 20, 4),    # default_config.yaml:62-69  (256 LDS slices -> shared bitmaps)
     "dynamic_xyzt": (4, 10, 32, 8192, 18, 4),      # default_config.yaml:70-77
+    "flow_xyzt": (4, 10, 16, 4096, 18, 4),         # radiance_field.py:916-923 (has a DENSE level 0; the dynamic grid has none)
     "prop1": (3, 8, 16, 2048, 20, 1),              # default_config.yaml:51-58 (second proposal net)
 }
 
@@ -231,6 +232,8 @@ def _ref_from_trainer(oracle, tr):
         d = c.dynamic_xyz_encoder
         grids["model/dynamic_xyz_encoder"] = oracle.grid_meta_from_encoder_args(4, d.n_levels, d.base_resolution, d.max_resolution,
                                                                                 d.log2_hashmap_size, d.n_features_per_level)
+    if tr.model.flow_xyz_encoder is not None:
+        grids["model/flow_xyz_encoder"] = oracle.grid_meta_from_encoder_args(*GRIDS["flow_xyzt"][:1], *GRIDS["flow_xyzt"][1:])  # radiance_field.py:916-923
     for i, kw in enumerate(PROP_KW):
         grids[f"prop{i}/xyz_encoder"] = oracle.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
                                                                            kw["log2_hashmap_size"], kw["n_features_per_level"])
@@ -239,20 +242,22 @@ def _ref_from_trainer(oracle, tr):
     return RefPath(ms, ps, grids, AABB, time_diff=1 / c.num_train_timesteps)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "flow"])
 def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
-    """One optimizer step's gradients at 2048 rays x 128 samples (proposal rounds 128 + 64, proposal nets training):
-    every parameter's gradient in Trainer.flat.grads vs oracle/ref_path.py (torch-CPU autograd on the C oracle) with
-    the stratified jitter replayed on both sides.  Same losses as Trainer.losses."""
+    """One optimizer step's gradients at 2048 rays x 128 samples (flow: 1024 x 128 -- seven xyzt evaluations per sample on
+    the CPU oracle; proposal rounds 128 + 64, proposal nets training): every parameter's gradient in Trainer.flat.grads vs
+    oracle/ref_path.py (torch-CPU autograd on the C oracle) with the stratified jitter -- and, for the flow model, the
+    temporal-aggregation noise -- replayed on both sides.  Same losses as Trainer.losses.  The flow case runs the batched
+    xyzt evaluations (3N dynamic, N + 2N flow) with input gradients through both grids."""
     import torch.nn.functional as Fn
     from oracle.ref_path import prop_loss
     from emernerf_amd.trainer import Trainer, synthetic_rays
     dev = _dev()
-    R, S = 2048, 128
+    R, S = (1024 if kind == "flow" else 2048), 128
     tr = Trainer(kind=kind, device=dev, num_samples=S, prop_samples=(128, 64), table_init=0.3, seed=7)
     ref = _ref_from_trainer(oracle, tr)
     data = synthetic_rays(R, dev, seed=77)
-    if kind == "dynamic":
+    if kind in ("dynamic", "flow"):
         # static + dynamic density saturates every ray (opacity rounds to exactly 1), where the sky term -log(1 - opacity)
         # and its gradient 1 / (1 - opacity) are decided by the last bit of a sum: covered by the static case; here the
         # dynamic / shadow branches are what is being compared
@@ -262,10 +267,12 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
     jit = [torch.rand(R, generator=g) for _ in range(3)]
     it = iter([j.to(dev) for j in jit])
     tr.estimator.jitter_fn = lambda n, d: next(it)
+    noise = torch.rand(R, S, 1, generator=g)
+    tr.model._noise = lambda like: noise.to(like.device)
     loss_hip = tr._forward_backward(data, prop_grad=True)
     torch.cuda.synchronize()
 
-    res = ref.render_rays(cpu, S, [128, 64], jitters=jit, requires_grad=True)
+    res = ref.render_rays(cpu, S, [128, 64], jitters=jit, requires_grad=True, noise_fn=lambda like: noise)
     pl = prop_loss(ref.cache, res["extras"]["trans"], 1024.0)
     pl.backward()
     loss = Fn.mse_loss(res["rgb"], cpu["pixels"]) + 0.001 * Fn.binary_cross_entropy(res["opacity"].squeeze(-1), 1 - cpu["sky_masks"].float())
@@ -273,6 +280,10 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
         loss = loss + 0.01 * res["extras"]["dynamic_density"].mean()
     if "shadow_ratio" in res:
         loss = loss + 0.01 * res["shadow_ratio"].mean()
+    if "forward_flow" in res["extras"]:  # flow cycle consistency, as Trainer.losses (train_emernerf.py:700-716)
+        ex = res["extras"]
+        loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
+                                    + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
     (loss * 1024.0).backward()
     np.testing.assert_allclose(float(loss_hip), float(loss), rtol=1e-4)
 

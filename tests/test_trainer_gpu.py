@@ -164,3 +164,31 @@ def test_lr_schedule_ticks_twice_with_lidar_supervision(hip_lib):
     tr.estimator.jitter_fn = lambda n, d: torch.rand(n, device=d)
     tr.lidar_step(synthetic_lidar_rays(256, torch.device("cuda:0"), seed=2))
     assert tr.sched_ticks == 2 and tr.step_count == 1
+
+
+@pytest.mark.parametrize("kind", ["flow", "feature"])
+def test_batched_xyzt_evaluations_equal_call_by_call(hip_lib, monkeypatch, kind):
+    """RadianceField._flow_branch_batched (one 3N-sample evaluation of the dynamic table, N + 2N of the flow table) gives the
+    gradients of the call-by-call order of the reference (six evaluations, radiance_field.py:434-459,553-620)."""
+    from emernerf_amd import radiance_field as RF
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = torch.device("cuda:0")
+    R, S = 384, 32
+    kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
+    data = synthetic_rays(R, dev, seed=8, **kw)
+    g = torch.Generator().manual_seed(4)
+    noise = torch.rand(R, S, 1, generator=g).to(dev)
+    jit = [torch.rand(R, generator=g).to(dev) for _ in range(3)]
+    grads = []
+    for batched in (True, False):
+        monkeypatch.setattr(RF, "BATCH_XYZT", batched)
+        tr = Trainer(kind=kind, device=dev, num_samples=S, prop_samples=(32, 16), table_init=0.3, seed=6)
+        it = iter(jit)
+        tr.estimator.jitter_fn = lambda n, d: next(it)
+        tr.model._noise = lambda like: noise
+        loss = tr._forward_backward(data, prop_grad=True)
+        tr._exchange_grads(True)
+        grads.append((float(loss), tr.flat.grads.clone()))
+    (la, ga), (lb, gb) = grads
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max())

@@ -34,7 +34,10 @@ for k, (v, n) in cal_w.items():
 tr = [c for k, c in cal.items() if "layout_transpose" in k]
 rf = (1.0 / tr[0]["FETCH_SIZE_GiB"]) if tr and tr[0].get("FETCH_SIZE_GiB") else 2.0
 wf = (1.0 / tr[0]["WRITE_SIZE_GiB"]) if tr and tr[0].get("WRITE_SIZE_GiB") else 1.0
-out = {"unit": "bytes per launch", "read_correction": rf, "write_correction": wf,
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (what the summary is valid for; bench.py refuses a summary of other sources)
+out = {"unit": "bytes per launch", "source_sha16": source_hash(), "read_correction": rf, "write_correction": wf,
        "correction_note": "factors = known bytes / counter on tools/pmc_calibrate.py's layout_transpose dispatch (same 8 B/lane "
                           "access width as the grid kernels); MI355X_MICROARCH.md documents the x2 on reads for gfx950",
        "calibration": cal, "kernels": {}}
