@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the lidar-step and eval-render measurements")
     ap.add_argument("--no-second-state", action="store_true", help="skip the trained-like (table_init 0.3) roofline pass")
     ap.add_argument("--graph", action="store_true", help="replay the forward+backward of a step as a captured hipGraph")
+    ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"], help="hash-table precision: f32 (the reference's; the headline) or "
+                    "f16 (tcnn half-precision tables: fp32 master cast per call, fp32 gradient accumulation; BASELINE.md 2.2)")
+    ap.add_argument("--no-fp16-state", action="store_true", help="skip the short fp16-table run behind roofline_fp16_tables")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2..3] (dynamic, flow, flow at "
                     "the 2048-ray per-rank shard of configs[3])")
     ap.add_argument("--secondary-steps", type=int, default=0, help="timed steps of each secondary run (0: min(--steps, 12))")
@@ -256,7 +259,7 @@ def main():
     from emernerf_amd.trainer import Trainer, synthetic_rays
 
     trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
-                      use_graph=args.graph)
+                      use_graph=args.graph, table_dtype=args.table_dtype)
     trainer.step_count = args.start_step
     # advance the proposal schedule to its state at start_step
     fn = trainer.requires_grad_fn
@@ -381,6 +384,27 @@ def main():
         torch.cuda.synchronize()
         _lib.TIMER = None
         del t2
+    # BASELINE configs[1] names fp16 tables; the headline runs the reference's fp32.  A third short run with half-precision tables
+    # (fp32 master cast per call, fp32 gradient accumulation) reports the grid pair of THAT mode next to it.
+    fp16_state = None
+    if rank == 0 and world == 1 and args.table_dtype == "f32" and args.kind == "static" and not args.no_fp16_state:
+        t3 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_dtype="f16")
+        t3.step_count = args.start_step
+        for s_ in range(args.start_step):
+            t3.requires_grad_fn(s_)
+        for _ in range(18):
+            t3.train_step(next_batch())
+        fp16_timer = _lib.KernelTimer(grid_names)
+        _lib.TIMER = fp16_timer
+        torch.cuda.synchronize()
+        t16 = time.perf_counter()
+        for _ in range(12):
+            t3.train_step(next_batch())
+        torch.cuda.synchronize()
+        fp16_state = {"timer": fp16_timer, "ms_per_step": (time.perf_counter() - t16) / 12 * 1e3}
+        _lib.TIMER = None
+        del t3
+        torch.cuda.empty_cache()
     # BASELINE configs[2..3] on the same code path, short runs (parity-test configurations, reported next to the headline so
     # that the driver's line carries them): dynamic and flow at 8192 x 128, and flow at 2048 x 128 -- the per-rank shard of
     # configs[3] ("16384 rays over 8 GPUs")
@@ -430,6 +454,21 @@ def main():
                          "frac": bwd_b * N / (ba * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "grid_encode_plus_bwd": {"fwd_avg_us": fa, "bwd_avg_us": ba,
                                                   "frac": (fwd_b + bwd_b) * N / ((fa + ba) * 1e-6) / 1e9 / HBM_PEAK_GBPS}}
+        roof16 = None
+        if fp16_state is not None:
+            us3, tg3 = fp16_state["timer"].elapsed_us(), fp16_state["timer"].tags
+            f3 = [u for u, tg in zip(us3["emer_hashgrid_fwd"], tg3["emer_hashgrid_fwd"]) if tg == (D, L, F)]
+            b3 = [u for u, tg in zip(us3["emer_hashgrid_bwd_params_sliced"], tg3["emer_hashgrid_bwd_params_sliced"]) if tg == (D, L, F)]
+            if f3 and b3:
+                fa3, ba3 = sum(f3) / len(f3), sum(b3) / len(b3)
+                fwd16, bwd16 = grid_alg_bytes(D, L, F, sp=2, so=4, sg=4)   # fp16 gathers, fp32 encodings and gradient accumulation
+                roof16 = {"tables": "fp16 copy of the fp32 master per call (emer_cast_f32_f16), fp32 encodings, fp32 gradient accumulation "
+                                    "(owner-computes backward, never reads the table)", "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "fwd_avg_us": fa3, "bwd_avg_us": ba3, "algorithmic_bytes_per_sample": {"fwd": fwd16, "bwd": bwd16},
+                          "frac_encode_plus_bwd": (fwd16 + bwd16) * N / ((fa3 + ba3) * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                          "baseline_md_target_us": 711, "pair_us": fa3 + ba3, "ms_per_step": fp16_state["ms_per_step"],
+                          "note": "BASELINE.md 2.3 counts 2712 B/sample for this mode (fp16 encodings: 588 + 2124); this path keeps the "
+                                  "encodings fp32 (the fused heads consume fp32): 652 + 2188 B"}
         # xyzt grids of the dynamic / flow configs (dynamic and flow encoders share one shape): their own roofline block
         roof_xyzt = None
         dyn = getattr(trainer.cfg, "dynamic_xyz_encoder", None)
@@ -488,25 +527,26 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.table_dtype == "f32" else "f32 (fp16 hash tables)",
             "dtype_note": "fp32 parameters, activations, gradients and accumulation; the 64-wide head GEMMs evaluate each fp32 product as six "
                           "bf16 partial products of an exact three-term split (error of the order of fp32 rounding; parity tests at the "
                           "fp32 kernels' tolerances)",
             "data": "synthetic",
             "config": {"workload": f"{workloads[args.kind]}, xyz hash grid D{D}/L{L}/F{F}/T2^{c.log2_hashmap_size} "
-                                   f"(fp32 tables, the reference's precision) + base MLP {L * F}->64->64 + rgb head 113->64->[177]->64->3 "
+                                   f"({'fp32 tables, the reference precision' if args.table_dtype == 'f32' else 'fp16 tables from an fp32 master, fp32 gradient accumulation'}) + base MLP {L * F}->64->64 + rgb head 113->64->[177]->64->3 "
                                    f"+ sky head, 2 proposal nets (L8/F1/T2^20), {args.rays} rays x {args.samples} samples per GPU, "
                                    "proposal rounds 128+64, full optimizer step (Adam)",
                        "kind": args.kind, "rays_per_gpu": args.rays, "samples": args.samples,
                        "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
                        "init_steps": args.init_steps, "ray_batches_rotated": N_BATCHES,
-                       "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4",
+                       "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4", "table_dtype": args.table_dtype,
                        "launch_mode": "hipGraph replay of forward+backward" if args.graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
             "roofline_trained_like": roof2,
+            "roofline_fp16_tables": roof16,
             "roofline_xyzt": roof_xyzt,
             "lidar_step": extra.get("lidar_step"),
             "eval_render": extra.get("eval_render"),

@@ -56,6 +56,7 @@ SIGNATURES = {
     "emer_prop_loss": [_P, _P, c_int32, _P, _P, c_int32, c_float, c_int, c_int64, c_float, _P, _P, c_int, _P, _P],
     "emer_reduce_sum": [_P, c_int64, c_int, _P, _P],
     "emer_scale": [_P, _P, c_float, _P, c_int64, _P],
+    "emer_cast_f32_f16": [_P, _P, c_int64, _P],
     "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
     "emer_blend_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P],

@@ -302,3 +302,30 @@ extern "C" int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, in
     hipLaunchKernelGGL(trunc_exp_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), dy, y, dx, dx_stride, n);
     return check_launch("trunc_exp_bwd");
 }
+
+// fp32 master table -> the fp16 copy the encoders read in half-precision mode (tcnn casts its fp32 master parameters to the
+// parameter precision on every call: third_party/tcnn_modules.py:223-233,257-260).  Eight entries per lane: 32 B in, 16 B out.
+namespace emer {
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float *__restrict__ src, __half *__restrict__ dst, int64_t n) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4 *>(src + i0), b = *reinterpret_cast<const float4 *>(src + i0 + 4);
+        union { __half2 h[4]; uint4 u; } o;
+        o.h[0] = __floats2half2_rn(a.x, a.y); o.h[1] = __floats2half2_rn(a.z, a.w);
+        o.h[2] = __floats2half2_rn(b.x, b.y); o.h[3] = __floats2half2_rn(b.z, b.w);
+        *reinterpret_cast<uint4 *>(dst + i0) = o.u;
+    } else {
+        for (int64_t i = i0; i < n; ++i) dst[i] = __float2half_rn(src[i]);
+    }
+}
+}  // namespace emer
+
+extern "C" int emer_cast_f32_f16(const float *src, void *dst_f16, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0, "cast_f32_f16: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(src && dst_f16 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_f16 % 16) == 0, "cast_f32_f16: null or unaligned pointer");
+    hipLaunchKernelGGL(emer::cast_f32_f16_kernel, dim3((uint32_t)emer::ceil_div(n, 256 * 8)), dim3(256), 0, emer::as_stream(stream), src,
+                       reinterpret_cast<__half *>(dst_f16), n);
+    return emer::check_launch("cast_f32_f16");
+}
+

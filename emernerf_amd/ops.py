@@ -206,11 +206,22 @@ class _HashGridLMFn(torch.autograd.Function):
     every table entry exactly once, so it can write STRAIGHT into the parameter's ``.grad`` -- no 49 MB temporary, no
     AccumulateGrad add, and the trainer does not zero the table's gradient beforehand (``params._emer_grad_fresh`` is set
     by the trainer's zero_grad: the first backward of a step overwrites, later ones of the same step -- the flow
-    configs evaluate an encoder three times -- add)."""
+    configs evaluate an encoder three times -- add).
+
+    ``table_dtype=torch.float16`` with an fp32 ``params``: half-precision tables the way BASELINE.md 2.2 / tcnn run them --
+    the fp32 MASTER is cast to fp16 for this call (emer_cast_f32_f16), the encode and the input gradient read the fp16 copy
+    (half the gather bytes), and the gradient is accumulated in fp32 by the owner-computes backward (which never reads the
+    table) straight into the master's ``.grad``.  ``skip_dx_rows``: leading rows of ``x`` that carry no gradient (the current
+    positions in a batched [current | warped | warped] evaluation): the input-gradient kernel skips them."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype):
+    def forward(ctx, x: Tensor, params: Tensor, desc: GridDesc, grad_dtype, table_dtype=None, skip_dx_rows: int = 0):
         xc, pc = _f32c(x), params.detach().contiguous()
+        if table_dtype == torch.float16 and pc.dtype == torch.float32:
+            ph = torch.empty(pc.shape, device=pc.device, dtype=torch.float16)
+            with torch.cuda.device(pc.device):
+                _lib.call("emer_cast_f32_f16", _ptr(pc), _ptr(ph), pc.numel(), _stream(pc))
+            pc = ph  # what the kernels read; `params` stays the fp32 master (gradient sink)
         gdt = grad_dtype or torch.float32
         ctx.sliced = bool(ctx.needs_input_grad[1] and gdt == torch.float32 and sliced_supported(desc))
         if ctx.sliced:
@@ -218,6 +229,8 @@ class _HashGridLMFn(torch.autograd.Function):
         else:
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
         ctx.desc, ctx.grad_dtype = desc, grad_dtype
+        ctx.skip_dx_rows = int(skip_dx_rows)
+        ctx.master_dtype = params.dtype
         from . import fused
         sink = fused._sink(params) if ctx.sliced else None
         ctx.param = params if (sink is not None and sink.is_contiguous() and sink.numel() == pc.numel()) else None
@@ -254,17 +267,22 @@ class _HashGridLMFn(torch.autograd.Function):
                     grad = torch.zeros(pc.numel(), device=xc.device, dtype=gdt)
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)
-                dp = None if grad is None else _table_grad_via_autograd(ctx.param_obj, grad.to(pc.dtype) if grad.dtype != pc.dtype else grad)
+                dp = None if grad is None else _table_grad_via_autograd(ctx.param_obj, grad.to(ctx.master_dtype) if grad.dtype != ctx.master_dtype else grad)
             if ctx.needs_input_grad[0]:
+                k, D = min(ctx.skip_dx_rows, N), desc.n_dims
                 dx = torch.empty_like(xc)
-                _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), _ptr(xc), _ptr(pc), _dtype_tag(pc), _ptr(dlm), F,
-                          N * F, _ptr(dx), N, st)
-        return dx, dp, None, None
+                if k > 0:
+                    dx[:k].zero_()  # rows without a consumer (torch.cat's backward slices them away)
+                if N > k:  # level-major dlm [L][N][F]: row k of every level is k*F floats in, the level stride stays N*F
+                    _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), xc.data_ptr() + 4 * k * D, _ptr(pc), _dtype_tag(pc),
+                              dlm.data_ptr() + 4 * k * F, F, N * F, dx.data_ptr() + 4 * k * D, N - k, st)
+        return dx, dp, None, None, None, None
 
 
-def hashgrid_encode_lm(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:
-    """x [N,D] in [0,1] -> level-major [L, N, F] fp32, differentiable w.r.t. params and x."""
-    return _HashGridLMFn.apply(x, params, desc, grad_dtype)
+def hashgrid_encode_lm(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None, table_dtype=None, skip_dx_rows: int = 0) -> Tensor:
+    """x [N,D] in [0,1] -> level-major [L, N, F] fp32, differentiable w.r.t. params and x (see _HashGridLMFn for
+    ``table_dtype`` / ``skip_dx_rows``)."""
+    return _HashGridLMFn.apply(x, params, desc, grad_dtype, table_dtype, skip_dx_rows)
 
 
 def hashgrid_encode(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:

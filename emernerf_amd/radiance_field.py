@@ -409,7 +409,7 @@ class RadianceField(nn.Module):
         x_fwd = torch.cat([fwd_pos, fwd_t.to(fwd_pos.dtype)], dim=-1).reshape(-1, D4)
         x_bwd = torch.cat([bwd_pos, bwd_t.to(bwd_pos.dtype)], dim=-1).reshape(-1, D4)
         # (3) dynamic table: one evaluation of 3N samples, one neck
-        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0))
+        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0), skip_dx_rows=N)  # the current positions carry no gradient
         geo3, sem3, _ = fused.neck(enc3, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
         feats3 = geo3 if sem3 is None else torch.cat([geo3, sem3], dim=-1)
         cur_f, fwd_f, bwd_f = (t.view(*lead, -1) for t in feats3.split(N, dim=0))

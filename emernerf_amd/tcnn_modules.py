@@ -74,13 +74,19 @@ class Encoding(torch.nn.Module):
                                   grad_dtype=None if self.dtype == torch.float32 else torch.float16)
         return out.view(*lead, self.n_output_dims)
 
-    def forward_level_major(self, x: Tensor) -> Tensor:
-        """[N, D] -> [L, N, F]: the grid kernels' native layout, consumed directly by the fused MLP chains."""
+    def forward_level_major(self, x: Tensor, skip_dx_rows: int = 0) -> Tensor:
+        """[N, D] -> [L, N, F]: the grid kernels' native layout, consumed directly by the fused MLP chains.
+        dtype float16: the fp32 master is cast to fp16 for the call, the kernels gather from the fp16 copy, gradients are
+        accumulated in fp32 into the master (ops._HashGridLMFn; BASELINE.md 2.2 "fp16 tables, fp32 grad accumulation")
+        when the owner-computes backward covers the grid; otherwise tcnn's all-fp16 path (fp16 atomics)."""
         if not x.is_cuda:
             raise _lib.EmerError("Encoding.forward needs a GPU tensor (no CPU fallback)")
-        params = self.params if self.dtype == torch.float32 else self.params.to(torch.float16)
-        return ops.hashgrid_encode_lm(x.reshape(-1, self.n_input_dims), params, self.desc,
-                                      grad_dtype=None if self.dtype == torch.float32 else torch.float16)
+        x2 = x.reshape(-1, self.n_input_dims)
+        if self.dtype == torch.float32:
+            return ops.hashgrid_encode_lm(x2, self.params, self.desc, skip_dx_rows=skip_dx_rows)
+        if ops.sliced_supported(self.desc):
+            return ops.hashgrid_encode_lm(x2, self.params, self.desc, table_dtype=torch.float16, skip_dx_rows=skip_dx_rows)
+        return ops.hashgrid_encode_lm(x2, self.params.to(torch.float16), self.desc, grad_dtype=torch.float16, skip_dx_rows=skip_dx_rows)
 
     def extra_repr(self):
         return f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, dtype={self.dtype}, {self.encoding_config}"

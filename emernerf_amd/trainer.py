@@ -215,7 +215,7 @@ class Trainer:
 
     def __init__(self, kind: str = "static", device="cuda:0", num_samples: int = 128, prop_samples=(128, 64), lr: float = 0.01,
                  weight_decay: float = 1e-5, num_iters: int = 25000, loss_scale: float = 1024.0, seed: int = 0,
-                 world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False):
+                 world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False, table_dtype: str = "f32"):
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial parameters on every rank
         self.cfg = model_config(kind, num_cams=3 if kind == "feature" else 1)
@@ -233,6 +233,15 @@ class Trainer:
                     for n, p in m.named_parameters():
                         if n.endswith("tcnn_encoding.params"):
                             p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * table_init)
+        # table precision: "f32" is what the reference runs; "f16" = tcnn's half-precision tables -- fp32 master
+        # parameters cast to fp16 per call, fp32 gradient accumulation through the owner-computes backward
+        assert table_dtype in ("f32", "f16")
+        self.table_dtype = table_dtype
+        if table_dtype == "f16":
+            for mod in [self.model] + self.props:
+                for sub in mod.modules():
+                    if hasattr(sub, "desc") and hasattr(sub, "params") and hasattr(sub, "dtype"):
+                        sub.dtype = torch.float16
         self.model.to(self.device)
         for p in self.props:
             p.to(self.device)

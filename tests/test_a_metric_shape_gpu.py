@@ -374,3 +374,56 @@ def test_stot_all_transforms(hip_lib, oracle, typ):
         np.testing.assert_allclose(got, want, rtol=5e-7)
     else:
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------- half-precision tables (BASELINE configs[1])
+def test_fp16_table_mode_metric_shape(hip_lib, oracle):
+    """tcnn's half-precision tables as BASELINE.md 2.2 states them: the fp32 MASTER is cast to fp16 per call, the encode gathers
+    fp16 entries and accumulates in fp32, the gradient is accumulated in fp32 by the owner-computes backward straight into the
+    master's .grad.  At N = 1 048 576 on the cfg-2 grid: forward vs the oracle on the fp16-ROUNDED table (2e-6 abs, the fp32
+    tolerance), table gradient vs the oracle (it does not depend on the table: 2e-5 x max)."""
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, "cfg2_static")
+    D, L, F = meta.n_dims, meta.n_levels, meta.n_features
+    x = _positions("training", D, seed=31)
+    g = torch.Generator().manual_seed(32)
+    p = torch.rand(meta.n_params, generator=g) - 0.5
+    dout = torch.randn(N_METRIC, L * F, generator=g)
+    dev = _dev()
+    pd = p.to(dev).requires_grad_(True)
+    lm = ops.hashgrid_encode_lm(x.to(dev), pd, desc, table_dtype=torch.float16)
+    assert lm.dtype == torch.float32
+    dlm = dout.view(N_METRIC, L, F).permute(1, 0, 2).contiguous().to(dev)
+    lm.backward(dlm)
+    torch.cuda.synchronize()
+    got = lm.detach().permute(1, 0, 2).reshape(N_METRIC, L * F).cpu().numpy()
+    ref = oracle.hashgrid_fwd(meta, x, p.half().float())
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+    assert pd.grad.dtype == torch.float32
+    ref_dp = oracle.hashgrid_bwd_params(meta, x, dout)
+    assert np.abs(pd.grad.cpu().numpy() - ref_dp).max() <= 2e-5 * np.abs(ref_dp).max()
+
+
+def test_fp16_table_trainer_step(hip_lib):
+    """Trainer(table_dtype="f16"): every encoder reads fp16 copies, the flat fp32 buffers stay the masters; the step trains
+    (finite, decreasing loss) and its first-step gradients agree with the fp32-table trainer to fp16 table rounding."""
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = _dev()
+    data = synthetic_rays(1024, dev, seed=5)
+    jit = torch.full((1024,), 0.41, device=dev)
+    gs = {}
+    for td in ("f32", "f16"):
+        tr = Trainer(kind="static", device=dev, num_samples=64, prop_samples=(64, 32), table_init=0.3, seed=2, table_dtype=td)
+        tr.estimator.jitter_fn = lambda n, d: jit
+        tr._forward_backward(data, prop_grad=False)
+        tr._exchange_grads(False)
+        a, b = tr.flat.ranges["main"]
+        gs[td] = tr.flat.grads[a:b].clone()
+        if td == "f16":
+            assert tr.flat.params.dtype == torch.float32
+            l0 = float(tr.train_step(data)["loss"])
+            for _ in range(6):
+                l1 = float(tr.train_step(data)["loss"])
+            assert np.isfinite([l0, l1]).all() and l1 < l0
+    rel = float((gs["f16"] - gs["f32"]).abs().max() / gs["f32"].abs().max())
+    assert rel < 2e-2, rel   # tables differ by fp16 rounding (2^-11 relative): gradients follow to that order
