@@ -7,8 +7,8 @@
 
 A "step" is one full optimizer step on one synthetic ray batch per rank (BASELINE.json configs[1]: static-only
 RadianceField, HashEncoder defaults D3/L16/F2/T2^19, 8192 rays x 128 samples, proposal rounds of 128 and 64):
-proposal sampling -> field -> compositing -> losses -> backward -> (one RCCL all-reduce of the flat grad
-buffer) -> fused Adam.  Inputs (rays, parameters) are resident in HBM before the timed region.  Weak scaling:
+proposal sampling -> field -> compositing -> losses -> backward -> (gradient exchange over RCCL: up to three buckets
+of the flat gradient buffer, two of them hidden behind the backward) -> fused Adam.  Inputs (rays, parameters) are resident in HBM before the timed region.  Weak scaling:
 every rank draws its own 8192 rays; value = world * rays * steps / max-over-ranks(time).
 
 Prints ONE JSON line on rank 0 (fields per the driver contract + "roofline" + "cpu_baseline").
@@ -302,6 +302,8 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if rank == 0:
+            trainer.comm_events = []   # HIP events around the exposed part of every step's gradient exchange
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -311,6 +313,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
+    exposed_comm = None
+    if world > 1 and rank == 0 and trainer.comm_events:
+        ev = [a.elapsed_time(b) for a, b in trainer.comm_events]
+        exposed_comm = {"exposed_comm_ms": sum(ev) / len(ev), "max_ms": max(ev), "steps": len(ev), "dp_mode": trainer.dp_mode,
+                        "note": "device time between the end of the backward and the optimizer step: the late (table) bucket plus the waits "
+                                "for the early buckets (allreduce mode), or the reduce-scatter (rs_ag; its all-gather follows Adam and is "
+                                "inside ms_per_step only)"}
+    trainer.comm_events = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -537,7 +547,7 @@ def main():
                                    f"+ sky head, 2 proposal nets (L8/F1/T2^20), {args.rays} rays x {args.samples} samples per GPU, "
                                    "proposal rounds 128+64, full optimizer step (Adam)",
                        "kind": args.kind, "rays_per_gpu": args.rays, "samples": args.samples,
-                       "global_rays": world * args.rays, "parallelism": f"dp{world}", "start_step": args.start_step,
+                       "global_rays": world * args.rays, "parallelism": f"dp{world}", "dp_mode": trainer.dp_mode, "start_step": args.start_step,
                        "init_steps": args.init_steps, "ray_batches_rotated": N_BATCHES,
                        "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4", "table_dtype": args.table_dtype,
                        "launch_mode": "hipGraph replay of forward+backward" if args.graph else "eager"},
@@ -559,6 +569,8 @@ def main():
         }
         if world > 1:
             out["rccl"] = rccl_summary(os.environ.get("NCCL_DEBUG_FILE", rccl_log), world)
+            out["rccl"].update({"env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "EMER_DP_MODE", "NCCL_MIN_NCHANNELS") if k in os.environ}})
+            out["gradient_exchange"] = exposed_comm
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
         print(json.dumps(out))

@@ -5,14 +5,17 @@ Shape of a step (train_emernerf.py:634-745, pixel rays): proposal_requires_grad 
 backward -> optimizer step.  What is new relative to the reference (which is single-GPU):
 
   * every trainable tensor (hash tables, MLPs, embeddings; main model AND proposal nets) is a view into
-    ONE contiguous fp32 buffer, and so is every gradient, so data parallelism costs exactly one RCCL
-    all-reduce of one flat buffer per step (``torch.distributed`` backend "nccl" = RCCL over xGMI);
+    ONE contiguous fp32 buffer, and so is every gradient.  Data parallelism exchanges that buffer's gradients over
+    ``torch.distributed`` (backend "nccl" = RCCL over xGMI) in up to THREE buckets per step, two of them hidden:
+    the trained proposal net's range right after ITS backward (1 step in 6, while the whole main backward is still
+    ahead), the dense MLP / embedding ranges of the main model when the last table backward starts, and -- the only
+    exposed one -- the main model's hash tables after the backward.  ``dp_mode="rs_ag"`` (env EMER_DP_MODE) replaces the
+    exchange by reduce-scatter -> Adam on this rank's 1/W shard of (params, m, v) -> all-gather of the parameters;
   * Adam runs as one fused HIP kernel per optimizer group over that buffer (torch.optim.Adam semantics of
     builders.py:50-60,114-120, including the reference's never-unscaled GradScaler(2**10) quirk,
     train_emernerf.py:475-476,742-745: gradients enter Adam multiplied by 1024);
-  * the proposal-net update and the main update are applied after the single all-reduce; neither backward
-    depends on the other's updated weights (samples are detached, nerfacc_prop_net.py:89), so this is
-    numerically the reference's order.
+  * the proposal-net update and the main update are applied after the exchange; neither backward depends on the
+    other's updated weights (samples are detached, nerfacc_prop_net.py:89), so this is numerically the reference's order.
 """
 from __future__ import annotations
 
@@ -113,7 +116,9 @@ class FlatParams:
     groups: {name: [modules]} -> contiguous [start, end) ranges, e.g. "main" and "prop".
     """
 
-    def __init__(self, groups: Dict[str, List[torch.nn.Module]], device):
+    def __init__(self, groups: Dict[str, List[torch.nn.Module]], device, align: int = 1):
+        """``align``: every group's length is padded up to a multiple of it (zero parameters with zero gradients), so a group
+        splits into equal shards for reduce-scatter / all-gather (align = 4 * world_size keeps shards 16-byte aligned)."""
         plist, self.ranges = [], {}
         off = 0
         for gname, mods in groups.items():
@@ -122,9 +127,10 @@ class FlatParams:
                 for p in m.parameters():
                     plist.append((p, off))
                     off += p.numel()
+            off = start + -(-(off - start) // align) * align
             self.ranges[gname] = (start, off)
         self.numel = off
-        self.params = torch.empty(off, device=device, dtype=torch.float32)
+        self.params = torch.zeros(off, device=device, dtype=torch.float32)
         self.grads = torch.zeros(off, device=device, dtype=torch.float32)
         for p, o in plist:
             n = p.numel()
@@ -215,7 +221,8 @@ class Trainer:
 
     def __init__(self, kind: str = "static", device="cuda:0", num_samples: int = 128, prop_samples=(128, 64), lr: float = 0.01,
                  weight_decay: float = 1e-5, num_iters: int = 25000, loss_scale: float = 1024.0, seed: int = 0,
-                 world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False, table_dtype: str = "f32"):
+                 world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False, table_dtype: str = "f32",
+                 dp_mode: Optional[str] = None):
         self.device = torch.device(device)
         torch.manual_seed(seed)  # identical initial parameters on every rank
         self.cfg = model_config(kind, num_cams=3 if kind == "feature" else 1)
@@ -249,7 +256,13 @@ class Trainer:
         # The reference's late-binding closures make every proposal level query the LAST proposal network
         # (render_utils.py:356-358); the earlier ones never receive a gradient, their .grad stays None and torch's Adam
         # skips them (no weight decay, no moment update).  They live in their own range so the fused Adam skips them too.
-        self.flat = FlatParams({"main": [self.model], "prop": self.props[-1:], "prop_idle": self.props[:-1]}, self.device)
+        import os as _os
+        self.dp_mode = dp_mode or _os.environ.get("EMER_DP_MODE", "allreduce")
+        assert self.dp_mode in ("allreduce", "rs_ag"), self.dp_mode
+        self.dp_debug = _os.environ.get("EMER_DP_DEBUG") == "1"   # check the ordering assumption of the early bucket (no overlap then)
+        self.comm_events = None    # bench.py: list of (start, end) HIP events around the EXPOSED part of the exchange
+        self.flat = FlatParams({"main": [self.model], "prop": self.props[-1:], "prop_idle": self.props[:-1]}, self.device,
+                               align=4 * max(world_size, 1) if self.dp_mode == "rs_ag" else 1)
         # this trainer owns every gradient buffer (views of flat.grads, zeroed each step, no parameter hooks), so the
         # fused heads may accumulate weight gradients straight into .grad: enabled around ITS forward+backward only
         # (fused.grad_sinks), never process-wide
@@ -340,6 +353,12 @@ class Trainer:
         encoder of the forward pass): every MLP / embedding gradient of the main model is enqueued by now, so their
         (small) all-reduce starts here and runs on RCCL's stream while the grid backward -- the longest kernel of the
         step -- computes the table gradient.  Only the table bucket is exposed at the end of the backward."""
+        if self.world_size > 1 and self.dp_mode == "rs_ag":
+            return  # one reduce-scatter per group after the backward
+        if self.world_size > 1 and self.dp_debug and not self._early_done and not self._hold_buckets:
+            # debug: record what the early ranges hold NOW instead of reducing them; _exchange_grads checks nothing wrote later
+            self._early_snapshot = [self.flat.grads[a:b].clone() for a, b in self._early_ranges]
+            return
         if self.world_size > 1 and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()  # weight gradients written on the side stream (off by default) must be complete
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
@@ -349,6 +368,8 @@ class Trainer:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
         is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
         starts here and is hidden completely.  Eager launches only (a collective cannot be captured into the step's graph)."""
+        if self.world_size > 1 and self.dp_mode == "rs_ag":
+            return
         if self.world_size > 1 and self._prop_work is None and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()
             self.flat.finish_grads("prop")
@@ -362,7 +383,29 @@ class Trainer:
         self.flat.finish_grads("main")
         if prop_grad:
             self.flat.finish_grads("prop")
-        if self.world_size > 1:
+        snap = getattr(self, "_early_snapshot", None)
+        if snap is not None:  # EMER_DP_DEBUG=1: the early ranges must be final when the last table backward starts
+            for (lo, hi), old in zip(self._early_ranges, snap):
+                assert torch.equal(self.flat.grads[lo:hi], old), \
+                    f"gradient range [{lo}, {hi}) was written after the early bucket would have been launched"
+            self._early_snapshot = None
+        ev0 = ev1 = None
+        if self.world_size > 1 and self.comm_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if self.world_size > 1 and self.dp_mode == "rs_ag":
+            self._rs_shards = {}
+            for grp in (["main", "prop"] if prop_grad else ["main"]):
+                a, b = self.flat.ranges[grp]
+                n = (b - a) // self.world_size
+                r = dist.get_rank()
+                shard = self.flat.grads[a + r * n: a + (r + 1) * n]
+                try:
+                    dist.reduce_scatter_tensor(shard, self.flat.grads[a:b])
+                except (RuntimeError, NotImplementedError):  # gloo (CPU-side tests): no reduce-scatter; same result, more bytes
+                    dist.all_reduce(self.flat.grads[a:b])
+                self._rs_shards[grp] = (a + r * n, a + (r + 1) * n)
+        elif self.world_size > 1:
             a, b = self.flat.ranges["main"]
             if prop_grad and self._prop_work is None:
                 b = self.flat.ranges["prop"][1]  # main and the trained proposal net are adjacent in the flat buffer
@@ -376,6 +419,9 @@ class Trainer:
                 dist.all_reduce(self.flat.grads[a:b])
             if self._prop_work is not None:
                 self._prop_work.wait()
+        if ev0 is not None:
+            ev1.record()
+            self.comm_events.append((ev0, ev1))
         self._early_done, self._early_work, self._prop_work = False, [], None
         if self.world_size > 1:
             self.model.xyz_encoder.tcnn_encoding.params._emer_pending_evals = 0
@@ -383,6 +429,14 @@ class Trainer:
     def _adam(self, group: str, lr: float):
         a, b = self.flat.ranges[group]
         self.opt_steps[group] += 1
+        if self.world_size > 1 and self.dp_mode == "rs_ag":
+            # this rank owns 1/W of the group: update its shard (the only part of m / v it ever touches), then everyone
+            # gathers the updated parameters
+            lo, hi = self._rs_shards[group]
+            ops.adam_step(self.flat.params[lo:hi], self.flat.grads[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, 0.9, 0.99, 1e-15, self.wd,
+                          1.0 / self.world_size, self.opt_steps[group])
+            dist.all_gather_into_tensor(self.flat.params[a:b], self.flat.params[lo:hi])
+            return
         ops.adam_step(self.flat.params[a:b], self.flat.grads[a:b], self.m[a:b], self.v[a:b], lr, 0.9, 0.99, 1e-15, self.wd,
                       1.0 / self.world_size, self.opt_steps[group])
 
