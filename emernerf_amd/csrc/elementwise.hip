@@ -308,8 +308,14 @@ extern "C" int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, in
 namespace emer {
 __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float *__restrict__ src, __half *__restrict__ dst, int64_t n) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;   // a table inside a flat parameter buffer may sit at any float
     if (i0 + 8 <= n) {
-        const float4 a = *reinterpret_cast<const float4 *>(src + i0), b = *reinterpret_cast<const float4 *>(src + i0 + 4);
+        float4 a, b;
+        if (aligned) {
+            a = *reinterpret_cast<const float4 *>(src + i0); b = *reinterpret_cast<const float4 *>(src + i0 + 4);
+        } else {
+            a = make_float4(src[i0], src[i0 + 1], src[i0 + 2], src[i0 + 3]); b = make_float4(src[i0 + 4], src[i0 + 5], src[i0 + 6], src[i0 + 7]);
+        }
         union { __half2 h[4]; uint4 u; } o;
         o.h[0] = __floats2half2_rn(a.x, a.y); o.h[1] = __floats2half2_rn(a.z, a.w);
         o.h[2] = __floats2half2_rn(b.x, b.y); o.h[3] = __floats2half2_rn(b.z, b.w);
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float *__restri
 extern "C" int emer_cast_f32_f16(const float *src, void *dst_f16, int64_t n, void *stream) {
     EMER_REQUIRE(n >= 0, "cast_f32_f16: negative n");
     if (n == 0) return EMER_OK;
-    EMER_REQUIRE(src && dst_f16 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_f16 % 16) == 0, "cast_f32_f16: null or unaligned pointer");
+    EMER_REQUIRE(src && dst_f16 && ((uintptr_t)dst_f16 % 16) == 0, "cast_f32_f16: null pointer or unaligned destination");
     hipLaunchKernelGGL(emer::cast_f32_f16_kernel, dim3((uint32_t)emer::ceil_div(n, 256 * 8)), dim3(256), 0, emer::as_stream(stream), src,
                        reinterpret_cast<__half *>(dst_f16), n);
     return emer::check_launch("cast_f32_f16");

@@ -1490,11 +1490,11 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
                                      (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
         } else {
             if (wide)
-                hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                   (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, __half, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
             else
-                hipLaunchKernelGGL((hashgrid_fwd_kernel<D, F, __half, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                   (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, __half, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
+                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
         }
         return check_launch("hashgrid_fwd");
     });

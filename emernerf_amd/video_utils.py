@@ -61,9 +61,15 @@ def render_pixels(cfg, model: RadianceField, proposal_estimator: PropNetEstimato
 
 def render(dataset, render_func: Callable, model: Optional[RadianceField] = None, compute_metrics: bool = False,
            vis_indices: Optional[List[int]] = None) -> Dict[str, list]:
-    """video_utils.py:109-468 (rgb / depth / opacity / decomposition / flow outputs; feature visualisation omitted)."""
+    """video_utils.py:109-468: the reference's result dictionary key for key -- the nine lists it always returns (possibly
+    empty), the conditional ones (gt_rgbs, gt_sky_masks, shadow_*, forward_flows / backward_flows, median_depths), the
+    scalars (psnr; ssim and the feature / masked metrics are -1: SSIM and the DINO-feature PCA colouring are out of scope,
+    SURVEY section 2).  ``forward_flows`` / ``backward_flows`` hold the rendered flow (the reference stores its colour-wheel
+    visualisation).  Checked against a recording of the reference's own loop: tests/golden/render_pixels_*.npz."""
+    always = ["rgbs", "static_rgbs", "dynamic_rgbs", "depths", "opacities", "static_depths", "static_opacities", "dynamic_depths",
+              "dynamic_opacities"]
     out: Dict[str, list] = {v: [] for v in _COLLECT.values()}
-    out.update({"gt_rgbs": [], "dynamic_rgbs": [], "median_depths": [], "sky_masks": []})
+    out.update({"gt_rgbs": [], "dynamic_rgbs": [], "median_depths": [], "gt_sky_masks": []})
     psnrs: List[float] = []
     n_rays, t0 = 0, time.perf_counter()
     green = None
@@ -86,15 +92,16 @@ def render(dataset, render_func: Callable, model: Optional[RadianceField] = None
             if "pixels" in data:
                 keep["gt_rgbs"] = data["pixels"]
             if "sky_masks" in data:
-                keep["sky_masks"] = data["sky_masks"]
+                keep["gt_sky_masks"] = data["sky_masks"]
             if compute_metrics and "pixels" in data:
                 psnrs.append(compute_psnr(res["rgb"], data["pixels"]))
             for name, t in keep.items():  # one squeeze + device->host copy per key, after the image is complete
                 out[name].append(t.squeeze().cpu().numpy())
     torch.cuda.synchronize()
-    out = {k: v for k, v in out.items() if len(v) > 0}
+    out = {k: v for k, v in out.items() if len(v) > 0 or k in always}
     dt = time.perf_counter() - t0
     out["render_rays_per_s"] = n_rays / dt if dt > 0 else float("nan")
-    if compute_metrics:
-        out["psnr"] = float(np.mean(psnrs)) if psnrs else -1.0
+    out["psnr"] = (float(np.mean(psnrs)) if psnrs else -1.0) if compute_metrics else -1
+    for k in ("ssim", "feat_psnr", "masked_psnr", "masked_ssim", "masked_feat_psnr"):
+        out[k] = -1
     return out

@@ -186,8 +186,8 @@ int emer_reduce_sum(const float *x, int64_t n, int accumulate, float *out, void 
  * without a host round trip. */
 int emer_scale(const float *x, const float *dev_scalar, float host_scale, float *y, int64_t n, void *stream);
 /* dst_f16[i] = (half) src[i], round to nearest even: the fp16 copy of an fp32 master table that the encoders read in
- * half-precision mode (tcnn casts the master parameters per call, third_party/tcnn_modules.py:223-233,257-260).  16-byte
- * aligned pointers. */
+ * half-precision mode (tcnn casts the master parameters per call, third_party/tcnn_modules.py:223-233,257-260).  dst 16-byte
+ * aligned; src may sit at any float (a table inside a flat parameter buffer). */
 int emer_cast_f32_f16(const float *src, void *dst_f16, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

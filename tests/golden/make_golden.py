@@ -254,8 +254,116 @@ CASES = {
 }
 
 
+# ---------------------------------------------------------------------------------------- N3: the evaluation render loop
+def _install_video_utils_shims():
+    """radiance_fields/video_utils.py imports packages that are absent here and have nothing to do with the path: imageio,
+    scikit-image (SSIM), and -- through utils.visualization_tools and datasets -- matplotlib, plotly, PIL and the dataset
+    readers.  They are replaced by stubs; ``render_pixels`` / ``render`` themselves run UNMODIFIED.  The stubs' only influence
+    on the recorded values: ``ssim`` is 0 (SSIM is out of scope), and the flow visualiser (a colour wheel) is the identity,
+    so ``forward_flows`` / ``backward_flows`` hold the rendered flow itself."""
+    import importlib.util
+    import types
+    from oracle import ref_shims
+    ref_shims.install()
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.metrics")
+    skm.structural_similarity = lambda a, b, **k: 0.0
+    sk.metrics = skm
+    sys.modules["skimage"], sys.modules["skimage.metrics"] = sk, skm
+    ds, dsb = types.ModuleType("datasets"), types.ModuleType("datasets.base")
+    dsb.SplitWrapper = type("SplitWrapper", (), {})
+    ds.base, ds.__path__ = dsb, []
+    sys.modules["datasets"], sys.modules["datasets.base"] = ds, dsb
+    spec = importlib.util.spec_from_file_location("datasets.metrics", os.path.join(ref_shims.REFERENCE_ROOT, "datasets", "metrics.py"))
+    dm = importlib.util.module_from_spec(spec)
+    sys.modules["datasets.metrics"] = dm
+    spec.loader.exec_module(dm)          # the reference's own compute_psnr
+    ds.metrics = dm
+    import utils  # the reference's package
+    vt = types.ModuleType("utils.visualization_tools")
+    vt.resize_five_views = lambda imgs: imgs
+    vt.to8b = lambda x: x
+    vt.visualize_depth = lambda *a, **k: a[0]
+    vt.scene_flow_to_rgb = lambda frame, **k: frame
+    sys.modules["utils.visualization_tools"] = vt
+    utils.visualization_tools = vt
+
+
+class GoldenSplit:
+    """What render() needs from a SplitWrapper (datasets/base/split_wrapper.py): ``split``, len, image-shaped ray dicts."""
+    split = "test"
+
+    def __init__(self, images):
+        self.images = images
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        return dict(self.images[i])
+
+
+def run_render_pixels_case(kind: str, seed: int, n_images: int = 3, hw=(6, 10), prop_samples=(24, 16), num_samples=16, chunk=25):
+    """radiance_fields/video_utils.py:50-468 on a stub split: every list the loop returns, plus the psnr it computes."""
+    _install_video_utils_shims()
+    import radiance_fields as ref_rf
+    from radiance_fields import video_utils as ref_video
+    from third_party import nerfacc_prop_net as ref_prop
+    torch.manual_seed(seed)
+    cfg = model_cfg(kind)
+    model = ref_rf.build_radiance_field_from_cfg(cfg, verbose=False)
+    model.set_aabb(AABB)
+    if kind != "static":
+        model.register_normalized_training_timesteps(torch.linspace(0, 1, cfg.num_train_timesteps), time_diff=1 / cfg.num_train_timesteps)
+    props = [ref_rf.build_density_field(aabb=AABB, unbounded=True, **kw) for kw in PROP_KW]
+    randomize_tables({"model/": model, **{f"prop{i}/": p for i, p in enumerate(props)}}, seed + 1)
+    est = ref_prop.PropNetEstimator(None, None)
+    rcfg = render_cfg(list(prop_samples), num_samples, chunk=chunk)
+    H, W = hw
+    images = []
+    for i in range(n_images):
+        d = make_rays(H * W, seed + 10 + i, cfg.num_train_timesteps, cfg.num_cams, (H, W))
+        d.pop("features")
+        images.append(d)
+    out, state = {}, {}
+    _flat("model/", dict(model.state_dict()), state)
+    for i, p in enumerate(props):
+        _flat(f"prop{i}/", dict(p.state_dict()), state)
+    out.update({"state/" + k: v for k, v in state.items() if not k.endswith("tcnn_encoding.params")})
+    out["table_seed"] = np.array(seed + 1)
+    for i, d in enumerate(images):
+        _flat(f"image{i}/", d, out)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self      # render() moves every tensor with .cuda(): the build container has no GPU
+    try:
+        res = ref_video.render_pixels(rcfg, model, est, GoldenSplit(images), proposal_networks=props, compute_metrics=True,
+                                      vis_indices=[0, 2], return_decomposition=True)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    for k, v in res.items():
+        if isinstance(v, list):
+            for j, a in enumerate(v):
+                out[f"res/{k}/{j}"] = np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+        else:
+            out[f"scalar/{k}"] = np.asarray(float(v))
+    return out
+
+
+RENDER_PIXELS_CASES = {
+    "render_pixels_static": dict(kind="static", seed=800),
+    "render_pixels_flow": dict(kind="flow", seed=900),
+}
+
+
 def main():
     only = sys.argv[1:]
+    for name, kw in RENDER_PIXELS_CASES.items():
+        if only and name not in only:
+            continue
+        out = run_render_pixels_case(**kw)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB; keys {sorted({k.split('/')[1] for k in out if k.startswith('res/')})}")
     for name, kw in CASES.items():
         if only and name not in only:
             continue

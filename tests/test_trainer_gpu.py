@@ -45,7 +45,7 @@ def test_render_pixels_loop(hip_lib):
     cfg = render_config(32, (32, 16), chunk=256)  # 960 rays per image -> 4 chunks
     out = render_pixels(cfg, tr.model, tr.estimator, src, proposal_networks=tr.props, compute_metrics=True, vis_indices=[0, 2])
     for k in ("rgbs", "gt_rgbs", "depths", "opacities", "static_rgbs", "dynamic_rgbs", "static_depths", "dynamic_depths",
-              "static_opacities", "dynamic_opacities", "shadow_reduced_static_rgbs", "shadow_only_static_rgbs", "sky_masks"):
+              "static_opacities", "dynamic_opacities", "shadow_reduced_static_rgbs", "shadow_only_static_rgbs", "gt_sky_masks"):
         assert k in out and len(out[k]) == 2, k
     assert out["rgbs"][0].shape == (24, 40, 3) and out["depths"][0].shape == (24, 40) and np.isfinite(out["psnr"])
     assert out["render_rays_per_s"] > 0
