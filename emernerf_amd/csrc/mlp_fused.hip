@@ -512,16 +512,17 @@ __device__ __forceinline__ void dw_tiles(f32x4 (&acc)[NA][NB], const SwT (&a)[NA
 #undef EMER_DW_PASS
 }
 
-constexpr int kWThreads = 256;  // fused backward: 4 waves, two workgroups per CU = 2 waves per SIMD (<= 256 registers)
+constexpr int kWThreads = 512;  // fused backward: 8 waves, ONE workgroup per CU = 2 waves per SIMD (<= 256 registers); the weights (48-72 KB) are
+                                // staged once per CU and leave room for 7-10 KB of per-wave staging
 
 struct NeckBwdWArgs {
     const float *d0;     // [n][64] gradient of output features 0..63 (null: zero)
     const float *ddens;  // [n] gradient of the density (null: none)
     const float *dens;   // [n] saved density
-    const float *h1;     // [n][64] saved hidden activations
-    const float *enc;    // level-major [L][n][F]: the forward's input (operand of dW0)
+    const float *enc;    // level-major [L][n][F]: the forward's input (operand of dW0; the hidden layer is recomputed from it)
+    const float *b0;     // [64] bias of the first layer
     int64_t n; int32_t n_levels, k0;
-    WSrc w1t, w0t;       // W1^T (64 x 64), W0^T (K0 x 64)
+    WSrc w1t, w0t, w0;   // W1^T (64 x 64), W0^T (K0 x 64), W0 (64 x K0, for the recomputation)
     float *denc;         // level-major [L][n][F]
     float *partials;     // [gridDim.x][stride]: dW1 [64][64] | db1 [64] | dW0 [64][k0] | db0 [64]
     int64_t stride;
@@ -530,13 +531,16 @@ struct NeckBwdWArgs {
 template <int KT0, int F>
 __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-    constexpr int K0P = 16 * KT0;
-    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2);
+    constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2;
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2), *w0fl = w1l + w3_units(4, 2);
+    float *b0l = reinterpret_cast<float *>(w0fl + w3_units(4, KS0));
     stage_w3(w0l, KT0, 2, a.w0t);
     stage_w3(w1l, 4, 2, a.w1t);
+    stage_w3(w0fl, 4, KS0, a.w0);
+    stage_b(b0l, 64, a.b0, 64);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2, lane);
+    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2, lane), w0fp = w3_at(w0fl, 4, KS0, lane);
     const SelE sel = make_sel(lane);
     f32x4 aw1[4][4], aw0[4][KT0];   // dW1 [64][64], dW0 [64][K0P] as 16x16 tiles
     float ab1[4], ab0[4];           // bias gradients: this lane's rows 4 g .. 4 g + 3 of feature 16 p + m
@@ -548,14 +552,18 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
     // Each wave owns a contiguous range of 16-row tiles.  With two waves per SIMD nothing else hides the HBM latency, so the
     // inputs of tile t + 1 are in flight while tile t is in the matrix pipe -- WITHOUT holding them in registers (the
     // accumulators leave none: a register prefetch was spilled to scratch by the compiler, i.e. loaded, waited for and
-    // stored again): h1 and d0 go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, lane-major, so
+    // stored again): d0 goes global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, lane-major, so
     // each lane reads back its own 16 bytes conflict-free); only the small enc tile and the density scalars ride in
     // registers.  Loads are unconditional (rows past the end re-read row n - 1 and are zeroed at use).
+    // The hidden layer is NOT read back: h1 = relu(W0 x + b0) is recomputed from the enc tile this kernel needs anyway
+    // (24-48 instructions on the matrix pipe instead of 268 MB written by the forward and read here; bitwise the forward's
+    // values -- same fragments, same order).
     const int64_t n_tiles = (a.n + 15) >> 4, n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
     const int64_t t_begin = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * per_wave;
     const int64_t t_end = t_begin + per_wave < n_tiles ? t_begin + per_wave : n_tiles;
-    float *stg = reinterpret_cast<float *>(w1l + w3_units(4, 2)) + wave * 2048;   // per wave: h1 tile [4][64][4] | d0 tile [4][64][4]
+    float *stg = b0l + 64 + wave * (1024 + 384 * KT0);   // per wave: d0 tile [4][64][4] | parked enc operand tiles [KT0][3][64][2]
+    u32x2 *park = reinterpret_cast<u32x2 *>(stg + 1024) + lane;
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
     f32x4 xn[KT0];
@@ -564,28 +572,23 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
         const int64_t row0 = tile * 16;
         const unsigned mrow = row0 + m < a.n ? (unsigned)m : (unsigned)(a.n - 1 - row0);
         const unsigned o64 = mrow * 64u + 4u * g;
-        const float *h1 = a.h1 + row0 * 64;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(h1 + (o64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
         if (a.d0) {
             const float *d0 = a.d0 + row0 * 64;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(d0 + (o64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+            for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(d0 + (o64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
         }
         ld_lm_t<KT0, F>(a.enc + row0 * F, (unsigned)a.n, a.n_levels, mrow, g, xn);
         ddn = a.ddens ? (a.ddens + row0)[mrow] : 0.0f;
         den = a.ddens ? (a.dens + row0)[mrow] : 0.0f;
     };
-    struct Raw { f32x4 h[4], d[4], x[KT0]; float dd, de; };
+    struct Raw { f32x4 d[4], x[KT0]; float dd, de; };
     if (t_begin < t_end) issue(t_begin);
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         Raw cur;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs have landed (issued one tile ago)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            cur.h[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
-            cur.d[p] = a.d0 ? *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
+        for (int p = 0; p < 4; ++p)
+            cur.d[p] = a.d0 ? *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int b = 0; b < KT0; ++b) cur.x[b] = xn[b];
         cur.dd = ddn; cur.de = den;
@@ -595,19 +598,33 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             const int64_t row = tile * 16 + m;
             const bool ok = row < a.n;
             const float fix = ok ? cur.dd * fminf(cur.de, 3269017.3724721107f) : 0.0f;
-            // h1: operand of dW1 (rows on the reduction index) and relu'(h1) as 16 bits
+            // enc tile -> operand of dW0 (xs) and, through the first layer, h1: operand of dW1 (hs) and relu'(h1) as 16 bits
             SwT hs[4];
             unsigned relu_bits = 0u;
             {
 #pragma unroll
+                for (int b = 0; b < KT0; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cur.x[b][i] = ok ? cur.x[b][i] : 0.0f;
+                Opd<KS0> xo;
+                make_opd<KT0>(cur.x, xo);
+                f32x4 h[4];
+                init_bias<4>(b0l, g, h);
+                tgemm<KS0, 4, false>(w0fp, xo, h);
+#pragma unroll
+                for (int b = 0; b < KT0; ++b) {   // operand of dW0, needed at the end of the tile: parked in LDS, not in 6 KT0 registers
+                    const SwT t = to_rows<KS0>(xo, b, sel);
+                    park[(3 * b + 0) * 64] = t.h; park[(3 * b + 1) * 64] = t.m; park[(3 * b + 2) * 64] = t.l;
+                }
+#pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        cur.h[p][i] = ok ? cur.h[p][i] : 0.0f;
-                        relu_bits |= (cur.h[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                        h[p][i] = (ok && h[p][i] > 0.0f) ? h[p][i] : 0.0f;   // relu; rows past the end contribute nothing
+                        relu_bits |= (h[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
                     }
                 Opd<2> ho;
-                make_opd<4>(cur.h, ho);
+                make_opd<4>(h, ho);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) hs[p] = to_rows<2>(ho, p, sel);
             }
@@ -642,16 +659,8 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             st_lm_t<KT0, F>(a.denc + tile * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, ok, g, de);
             {   // dW0 += dPre0^T enc
                 SwT xs[KT0];
-                {
 #pragma unroll
-                    for (int b = 0; b < KT0; ++b)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) cur.x[b][i] = ok ? cur.x[b][i] : 0.0f;
-                    Opd<(KT0 + 1) / 2> xo;
-                    make_opd<KT0>(cur.x, xo);
-#pragma unroll
-                    for (int b = 0; b < KT0; ++b) xs[b] = to_rows<(KT0 + 1) / 2>(xo, b, sel);
-                }
+                for (int b = 0; b < KT0; ++b) { xs[b].h = park[(3 * b + 0) * 64]; xs[b].m = park[(3 * b + 1) * 64]; xs[b].l = park[(3 * b + 2) * 64]; }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     SwT ds[1];
@@ -1151,11 +1160,11 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
 static inline uint32_t neck_bwdw_grid(int64_t n) {
     const int64_t tiles = (n + 15) / 16;
     int64_t blocks = (tiles + kWThreads / 64 - 1) / (kWThreads / 64);
-    if (blocks > 512) blocks = 512;   // persistent: two 4-wave workgroups per CU
+    if (blocks > 256) blocks = 256;   // persistent: one 8-wave workgroup per CU
     return (uint32_t)(blocks < 1 ? 1 : blocks);
 }
-static inline size_t neck_bwdw_lds(int kt0) {   // weights + a staging buffer of 8 KB per wave; the final reduction reuses the front
-    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2)) * 16 + (size_t)(kWThreads / 64) * 2048 * sizeof(float);
+static inline size_t neck_bwdw_lds(int kt0) {   // weights + bias + a staging buffer of 4 KB per wave; the final reduction reuses the front
+    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2) + w3_units(4, (kt0 + 1) / 2)) * 16 + (size_t)(64 + (kWThreads / 64) * (1024 + 384 * kt0)) * sizeof(float);
     const size_t r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
     return w > r ? w : r;
 }
@@ -1174,21 +1183,23 @@ extern "C" int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_fea
 }
 // Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
 // [64][ld_dw0 >= L*F], db0 [64], dw1 [64][ld_dw1 >= 64], db1 [64] (torch Linear layouts; what autograd's AccumulateGrad would
-// add).  d0 / ddens as in emer_neck_bwd.  enc_lm: the forward's input.
-extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *h1, const float *enc_lm,
-                                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1, int32_t n_out,
+// add).  d0 / ddens as in emer_neck_bwd.  enc_lm: the forward's input; the hidden activations are recomputed from it (the
+// forward need not store them: pass h1 = NULL to emer_neck_fwd).
+extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *enc_lm,
+                                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *b0, const float *w1, int32_t n_out,
                                    float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1,
                                    float *db1, void *stream) {
     EMER_REQUIRE(n >= 0, "neck_bwd_fused: negative n");
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out), "neck_bwd_fused: unsupported shape L=%d F=%d n_out=%d", n_levels, n_feat, n_out);
     EMER_REQUIRE(neck_bwdw_fits(n_levels, n_feat, n), "neck_bwd_fused: n * L * F must stay below 2^30 (32-bit lane offsets); split the batch or use emer_neck_bwd");
-    EMER_REQUIRE(h1 && enc_lm && w0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1, "neck_bwd_fused: null pointer");
+    EMER_REQUIRE(enc_lm && w0 && b0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1, "neck_bwd_fused: null pointer");
     EMER_REQUIRE(!ddens || dens, "neck_bwd_fused: ddens needs the saved density");
     const int k0 = n_levels * n_feat;
     EMER_REQUIRE(ld_dw0 >= k0 && ld_dw1 >= 64, "neck_bwd_fused: leading dimension smaller than the row");
     NeckBwdWArgs a;
-    a.d0 = d0; a.ddens = ddens; a.dens = dens; a.h1 = h1; a.enc = enc_lm; a.n = n; a.n_levels = n_levels; a.k0 = k0;
+    a.d0 = d0; a.ddens = ddens; a.dens = dens; a.enc = enc_lm; a.b0 = b0; a.n = n; a.n_levels = n_levels; a.k0 = k0;
+    a.w0 = WSrc{w0, k0, 1, 64, k0};
     a.w0t = WSrc{w0, 1, k0, k0, 64};          // (n = input feature, k = hidden) = w0[k][n]
     a.w1t = WSrc{w1, 1, 64, 64, 64};          // (n = hidden, k = output) = w1[k][n]
     a.denc = denc_lm; a.partials = workspace; a.stride = neck_bwdw_stride(k0);

@@ -295,8 +295,11 @@ class _NeckFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         enc, W0, B0, W1, B1 = _c(enc_lm), _c(w0), _c(b0), _c(w1), _c(b1)
         n_out = W1.shape[0]
-        h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, any(ctx.needs_input_grad))
-        ctx.save_for_backward(enc, W0, W1, h1, dens)
+        L, N, F = enc.shape
+        # the fused backward recomputes the hidden layer from enc: the forward then does not store it (268 MB at 1 M rows)
+        ctx.fused_bwd = bool(FUSED_WGRAD and any(ctx.needs_input_grad) and _lib.load().emer_neck_bwd_fused_workspace(L, F, N, n_out) > 0)
+        h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, any(ctx.needs_input_grad) and not ctx.fused_bwd)
+        ctx.save_for_backward(enc, W0, W1, h1, dens, B0)
         ctx.n_out = n_out
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1))
         if out1 is None:
@@ -305,7 +308,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        enc, W0, W1, h1, dens = ctx.saved_tensors
+        enc, W0, W1, h1, dens, B0 = ctx.saved_tensors
         n_out = ctx.n_out
         d0, d1, ddens = (grads[0], None, grads[1]) if n_out == 64 else grads
         if d0 is None and d1 is None and ddens is None:
@@ -321,11 +324,11 @@ class _NeckFn(torch.autograd.Function):
         tb1, rb1 = _target(sb1, (n_out,), dev)
         tw0, rw0 = _target(sw0, (64, L * F), dev)
         tb0, rb0 = _target(sb0, (64,), dev)
-        if FUSED_WGRAD and _lib.load().emer_neck_bwd_fused_supported(L, F, 64, n_out):
-            # data gradients AND weight gradients in one kernel: dpre0 never reaches memory, h1 / enc / d are read once
+        if ctx.fused_bwd:
+            # data gradients AND weight gradients in one kernel: neither h1 nor dpre0 reaches memory, enc / d are read once
             ws = torch.empty((int(_lib.load().emer_neck_bwd_fused_workspace(L, F, N, n_out)),), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.call("emer_neck_bwd_fused", _p(d0c), _p(fa), _p(dens), _p(h1), _p(enc), L, F, N, _p(W0), _p(W1), n_out,
+                _lib.call("emer_neck_bwd_fused", _p(d0c), _p(fa), _p(dens), _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), n_out,
                           _p(denc), _p(ws), _p(tw0), tw0.stride(0), _p(tb0), _p(tw1), tw1.stride(0), _p(tb1), _stream(enc))
             return denc, rw0, rb0, rw1, rb1
         dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)

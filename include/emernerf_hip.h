@@ -378,15 +378,16 @@ int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const fl
                   int32_t n_out, float *dpre1, float *dcol0, float *dpre0, float *denc_lm, void *stream);
 
 /* Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients (autograd of radiance_field.py:74-80,89-96): one
- * kernel reads d0 / ddens, h1 and the forward's input enc_lm once, writes denc_lm [L][n][F] and keeps dW1 = d^T h1, db1,
- * dW0 = dpre0^T enc, db0 in the waves' accumulators (the pre-activation gradient dpre0 never goes to memory); per-workgroup
- * partials are summed into dw1 [64][ld_dw1 >= 64], db1 [64], dw0 [64][ld_dw0 >= L*F], db0 [64] with += semantics (what
- * AccumulateGrad does; the targets may be a parameter's .grad).  workspace: emer_neck_bwd_fused_workspace(...) floats.
+ * kernel reads d0 / ddens and the forward's input enc_lm once, RECOMPUTES the hidden layer from enc_lm (the forward need not
+ * store it: h1 = NULL there), writes denc_lm [L][n][F] and keeps dW1 = d^T h1, db1, dW0 = dpre0^T enc, db0 in the waves'
+ * accumulators (neither h1 nor the pre-activation gradient dpre0 ever goes to memory); per-workgroup partials are summed
+ * into dw1 [64][ld_dw1 >= 64], db1 [64], dw0 [64][ld_dw0 >= L*F], db0 [64] with += semantics (what AccumulateGrad does; the
+ * targets may be a parameter's .grad).  workspace: emer_neck_bwd_fused_workspace(...) floats; n * L * F < 2^30.
  * emer_neck_bwd_fused_supported == 0 (128 outputs, density MLP): emer_neck_bwd + emer_wgrad_segmented. */
 int emer_neck_bwd_fused_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out);
 int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out);
-int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *h1, const float *enc_lm,
-                        int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1, int32_t n_out,
+int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *enc_lm, int32_t n_levels,
+                        int32_t n_feat, int64_t n, const float *w0, const float *b0, const float *w1, int32_t n_out,
                         float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1,
                         float *db1, void *stream);
 
