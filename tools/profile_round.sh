@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace stats + PMC HBM traffic (separate passes) + the bench line.
 # Usage (through gpurun): bash tools/profile_round.sh r01_b
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --no-cpu-baseline --no-extras --no-second-state --steps 24 --warmup 8"
+CMD="python $R/bench.py --no-cpu-baseline --no-extras --no-second-state --no-secondary --no-fp16-state --steps 24 --warmup 8"
 
 rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- $CMD > $OUT/bench_under_rocprof.log 2>&1
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_bench_kernel_stats.csv 2>/dev/null
