@@ -213,7 +213,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the lidar-step and eval-render measurements")
     ap.add_argument("--no-second-state", action="store_true", help="skip the trained-like (table_init 0.3) roofline pass")
-    ap.add_argument("--graph", action="store_true", help="replay the forward+backward of a step as a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="(default at N = 1) replay the forward+backward of a step as a captured hipGraph")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel of the timed steps from Python (the default at N > 1, where "
+                    "the gradient buckets are launched from inside the backward)")
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"], help="hash-table precision: f32 (the reference's; the headline) or "
                     "f16 (tcnn half-precision tables: fp32 master cast per call, fp32 gradient accumulation; BASELINE.md 2.2)")
     ap.add_argument("--no-fp16-state", action="store_true", help="skip the short fp16-table run behind roofline_fp16_tables")
@@ -257,6 +259,10 @@ def main():
     if world > 1:
         dist.barrier()
     from emernerf_amd.trainer import Trainer, synthetic_rays
+    # Launch mode.  One step is 86 kernel launches in 3.0 ms: the host has to enqueue one every 35 us, and boxes of this pool
+    # differ (the same library: 3.02 ms on most, 3.58 ms on one with a slow host).  At N = 1 the forward + backward are
+    # therefore replayed as a captured hipGraph (tested equal to eager launches); the exchange and Adam stay eager.
+    args.graph = (args.graph or world == 1) and not args.eager
 
     trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
                       use_graph=args.graph, table_dtype=args.table_dtype)
@@ -326,6 +332,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the other launch mode over the same number of steps (single GPU only), so that the line shows both
+    other_mode = None
+    if rank == 0 and world == 1:
+        was = trainer.use_graph
+        trainer.use_graph = not was
+        for _ in range(min(args.warmup, 6) + (8 if not was else 2)):   # (a first graph replay captures: warm it up)
+            trainer.train_step(next_batch())
+        torch.cuda.synchronize()
+        if was:  # the eager loop is where the roofline kernels can be bracketed: same events as an eager timed region
+            timer = _lib.KernelTimer(grid_names)
+            _lib.TIMER = timer
+        t_o = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(next_batch())
+        torch.cuda.synchronize()
+        _lib.TIMER = None
+        other_mode = {"mode": "hipGraph replay of forward+backward" if trainer.use_graph else "eager",
+                      "ms_per_step": (time.perf_counter() - t_o) / args.steps * 1e3}
+        trainer.use_graph = was
     # untimed: per-kernel breakdown with every entry point instrumented.  EVERY rank takes these steps (a step contains the
     # gradient collectives: rank 0 alone would wait for its peers forever); only rank 0 records events.
     breakdown, breakdown_steps = None, min(args.steps, 12)
@@ -550,9 +575,13 @@ def main():
                        "global_rays": world * args.rays, "parallelism": f"dp{world}", "dp_mode": trainer.dp_mode, "start_step": args.start_step,
                        "init_steps": args.init_steps, "ray_batches_rotated": N_BATCHES,
                        "table_init": args.table_init if args.table_init is not None else "tcnn +-1e-4", "table_dtype": args.table_dtype,
-                       "launch_mode": "hipGraph replay of forward+backward" if args.graph else "eager"},
+                       "launch_mode": "hipGraph replay of forward+backward (exchange + Adam eager)" if args.graph else "eager",
+                       "other_launch_mode": other_mode},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
+                         "timed_in": (f"HIP events on the dispatch packets of the eager loop of {args.steps} steps that follows the hipGraph-timed "
+                                      "region (config.other_launch_mode; a graph replay launches nothing from the host to bracket)")
+                         if (args.graph and world == 1) else "HIP events on the dispatch packets inside the timed region",
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
             "roofline_trained_like": roof2,

@@ -9,8 +9,9 @@ PropNetEstimator.sampling / compute_loss (third_party/nerfacc_prop_net.py:89-238
 Why it exists: /root/reference cannot travel to the GPU box, so the reference's Python cannot be the
 run-time checker there.  This file is PINNED against the reference itself: tests/test_oracle_cpu.py replays
 the golden vectors recorded from the reference's own code (tests/golden/make_golden.py) through it.
-Supported: static / dynamic (+shadow) / flow (+temporal aggregation) / sky head / appearance embedding.
-The feature head + learnable PE map (BASELINE config 5) is covered by the goldens only.
+Supported: static / dynamic (+shadow) / flow (+temporal aggregation) / sky head / appearance embedding (per image or per
+camera) / feature head + learnable PE map + feature sky head (BASELINE config 5; radiance_field.py:192-217,509-537,
+render_utils.py:228-267).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -110,13 +111,14 @@ def density_field(p: Params, positions: Tensor, aabb: Tensor, unbounded: bool = 
 
 def radiance_field(p: Params, positions: Tensor, directions: Optional[Tensor], data: Dict[str, Tensor], aabb: Tensor,
                    geo_dim: int = 64, time_diff: float = 0.0, training: bool = True, return_density_only: bool = False,
-                   noise_fn: Optional[Callable] = None) -> Dict[str, Tensor]:
-    """RadianceField.forward (radiance_field.py:391-551) without the feature head."""
+                   noise_fn: Optional[Callable] = None, cam_embedding: bool = False) -> Dict[str, Tensor]:
+    """RadianceField.forward (radiance_field.py:391-551)."""
     out = {}
     lead = positions.shape[:-1]
     normed = contract_points(positions, aabb, True)
     feats = mlp_seq(p, "base_mlp", p.grid("xyz_encoder", normed), 2).view(*lead, -1)
     geo = feats[..., :geo_dim]
+    emb_key = "cam_idx" if cam_embedding else "img_idx"   # :637-643
     static_density = density_act(geo[..., 0])
     has_t = "normed_timestamps" in data or "lidar_normed_timestamps" in data
     dynamic = p.has("dynamic_xyz_encoder.tcnn_encoding.params") and has_t
@@ -161,7 +163,7 @@ def radiance_field(p: Params, positions: Tensor, directions: Optional[Tensor], d
     if directions is not None:
         h = dir_encode((directions + 1.0) / 2.0)  # query_rgb, :622-658
         if p.has("appearance_embedding.weight"):
-            h = torch.cat([h, F.embedding(data["img_idx"], p["appearance_embedding.weight"])], -1)
+            h = torch.cat([h, F.embedding(data[emb_key], p["appearance_embedding.weight"])], -1)
         rgb = torch.sigmoid(mlp_skip(p, "rgb_head", torch.cat([h, geo], -1)))
         if dynamic:
             out["static_rgb"] = rgb
@@ -173,8 +175,20 @@ def radiance_field(p: Params, positions: Tensor, directions: Optional[Tensor], d
     if p.has("sky_head.layers.0.weight") and directions is not None:  # query_sky on dirs[:, 0], :540-549,660-686
         dd = dir_encode(directions[:, 0])
         if p.has("appearance_embedding.weight"):
-            dd = torch.cat([dd, F.embedding(data["img_idx"][:, 0], p["appearance_embedding.weight"])], -1)
+            dd = torch.cat([dd, F.embedding(data[emb_key][:, 0], p["appearance_embedding.weight"])], -1)
         out["rgb_sky"] = torch.sigmoid(mlp_skip(p, "sky_head", dd))
+        if p.has("dino_sky_head.0.weight"):
+            out["dino_sky_feat"] = mlp_seq(p, "dino_sky_head", dd, 3)
+    if p.has("dino_head.0.weight"):  # feature head, :509-537
+        if p.has("learnable_pe_map") and "pixel_coords" in data:
+            pe = F.grid_sample(p["learnable_pe_map"], data["pixel_coords"].reshape(1, 1, -1, 2) * 2 - 1, align_corners=False,
+                               mode="bilinear").squeeze(2).squeeze(0).permute(1, 0)
+            out["dino_pe"] = p.lin("pe_head.0", pe)
+        dino = mlp_seq(p, "dino_head", feats[..., geo_dim:], 3)
+        if dynamic:
+            out["static_dino_feat"], out["dynamic_dino_feat"] = dino, mlp_seq(p, "dino_head", dyn_feats[..., geo_dim:], 3)
+        else:
+            out["dino_feat"] = dino
     return out
 
 
@@ -285,6 +299,19 @@ def render(field_out: Dict[str, Tensor], t_starts: Tensor, t_ends: Tensor) -> Di
         res["rgb"] = acc(sr[..., None] * field_out["static_rgb"] * (1 - shadow) + dr[..., None] * field_out["dynamic_rgb"])
     if "rgb_sky" in field_out and "rgb" in res:
         res["rgb"] = res["rgb"] + field_out["rgb_sky"] * (1.0 - opacity)
+    dino = None  # features, render_utils.py:228-267
+    if "dino_feat" in field_out:
+        dino = acc(field_out["dino_feat"])
+    elif "static_dino_feat" in field_out:
+        dino = acc(sr[..., None] * field_out["static_dino_feat"] + dr[..., None] * field_out["dynamic_dino_feat"])
+    if dino is not None:
+        if "dino_sky_feat" in field_out:
+            dino = dino + field_out["dino_sky_feat"] * (1.0 - opacity)
+        if "dino_pe" in field_out:
+            res["dino_pe_free"] = dino.clone()
+            res["dino_pe"] = field_out["dino_pe"]
+            dino = dino + field_out["dino_pe"]
+        res["dino_feat"] = dino
     res["extras"] = extras
     return res
 
@@ -294,10 +321,12 @@ class RefPath:
     """Holds parameters (reference names) and evaluates render_rays / one training step on CPU."""
 
     def __init__(self, model_state: Dict[str, Tensor], prop_states: List[Dict[str, Tensor]], grids: Dict[str, O.GridMeta],
-                 aabb, geo_dim: int = 64, time_diff: float = 0.0):
+                 aabb, geo_dim: int = 64, time_diff: float = 0.0, cam_embedding: bool = False):
+        self.cam_embedding = cam_embedding
         self.t: Dict[str, Tensor] = {}
         for k, v in model_state.items():
-            self.t["model/" + k] = v.clone().float().requires_grad_(v.is_floating_point() and k not in ("aabb", "training_timesteps"))
+            self.t["model/" + k] = v.clone().float().requires_grad_(v.is_floating_point() and k not in (
+                "aabb", "training_timesteps", "feats_reduction_mat", "feat_color_min", "feat_color_max"))
         for i, st in enumerate(prop_states):
             for k, v in st.items():
                 self.t[f"prop{i}/" + k] = v.clone().float().requires_grad_(k != "aabb")
@@ -328,8 +357,10 @@ class RefPath:
         S = t0.shape[-1]
         pos = o[:, None, :] + d[:, None, :].expand(-1, S, -1) * (t0 + t1)[..., None] / 2.0
         sub = {k: v[..., None].expand(*v.shape, S) for k, v in data.items() if v.dim() == 1}
+        if "pixel_coords" in data:
+            sub["pixel_coords"] = data["pixel_coords"]   # per ray (render_utils.py:339-340)
         fo = radiance_field(self.model, pos, d[:, None, :].expand(-1, S, -1), sub, self.aabb, self.geo_dim, self.time_diff,
-                            training, return_density_only=(prefix == "lidar_"), noise_fn=noise_fn)
+                            training, return_density_only=(prefix == "lidar_"), noise_fn=noise_fn, cam_embedding=self.cam_embedding)
         return render(fo, t0, t1)
 
     def train_step(self, data, opt_main, opt_prop, num_samples, prop_samples, jitters=None, loss_scale=1024.0, prop_grad=True):

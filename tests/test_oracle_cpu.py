@@ -150,7 +150,7 @@ def _grids(oracle, kind):
     return grids
 
 
-@pytest.mark.parametrize("case", ["static_train", "dynamic_train", "flow_train", "flow_lidar_train"])
+@pytest.mark.parametrize("case", ["static_train", "dynamic_train", "flow_train", "flow_lidar_train", "feature_train"])
 def test_ref_path_reproduces_reference_goldens(oracle, case):
     from oracle.ref_path import RefPath, prop_loss
     z = np.load(os.path.join(HERE, "golden", case + ".npz"))
@@ -167,11 +167,12 @@ def test_ref_path_reproduces_reference_goldens(oracle, case):
         for enc in ("xyz_encoder", "dynamic_xyz_encoder", "flow_xyz_encoder"):
             gk = pre + enc
             needed = gk in grids and (pre != "model/" or enc == "xyz_encoder" or (enc == "dynamic_xyz_encoder" and kw["kind"] != "static")
-                                      or (enc == "flow_xyz_encoder" and kw["kind"] == "flow"))
+                                      or (enc == "flow_xyz_encoder" and kw["kind"] in ("flow", "feature")))
             if needed:
                 name = enc + ".tcnn_encoding.params"
                 st[name] = G.table_values(pre + name, grids[gk].n_params, seed)
-    ref = RefPath(states["model/"], [states["prop0/"], states["prop1/"]], grids, G.AABB, time_diff=0.1)
+    ref = RefPath(states["model/"], [states["prop0/"], states["prop1/"]], grids, G.AABB, time_diff=0.1,
+                  cam_embedding=kw["kind"] == "feature")
     prefix = "lidar_" if kw.get("lidar") else ""
     data = {k[len("data/"):]: torch.from_numpy(v) for k, v in gold.items() if k.startswith("data/")}
     jit = [torch.from_numpy(gold[f"jitter/{i}"]) for i in range(sum(k.startswith("jitter/") for k in gold))]
@@ -188,7 +189,8 @@ def test_ref_path_reproduces_reference_goldens(oracle, case):
     loss = G.golden_loss(res, data, prefix)
     np.testing.assert_allclose(float(loss), float(gold["loss"]), rtol=1e-5)
     loss.backward()
-    for k in ("base_mlp.0.weight", "rgb_head.layers.1.weight", "appearance_embedding.weight"):
+    for k in ("base_mlp.0.weight", "rgb_head.layers.1.weight", "appearance_embedding.weight", "dino_head.4.weight", "learnable_pe_map",
+              "pe_head.0.weight"):
         if "grad/" + k in gold:
             np.testing.assert_allclose(ref.t["model/" + k].grad.numpy(), gold["grad/" + k], rtol=1e-4,
                                        atol=1e-6 * np.abs(gold["grad/" + k]).max(), err_msg=k)
