@@ -242,22 +242,23 @@ def _ref_from_trainer(oracle, tr):
     return RefPath(ms, ps, grids, AABB, time_diff=1 / c.num_train_timesteps)
 
 
-@pytest.mark.parametrize("kind", ["static", "dynamic", "flow"])
+@pytest.mark.parametrize("kind", ["static", "dynamic", "flow", "feature"])
 def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
     """One optimizer step's gradients at 2048 rays x 128 samples (flow: 1024 x 128 -- seven xyzt evaluations per sample on
     the CPU oracle; proposal rounds 128 + 64, proposal nets training): every parameter's gradient in Trainer.flat.grads vs
     oracle/ref_path.py (torch-CPU autograd on the C oracle) with the stratified jitter -- and, for the flow model, the
-    temporal-aggregation noise -- replayed on both sides.  Same losses as Trainer.losses.  The flow case runs the batched
+    temporal-aggregation noise -- replayed on both sides (feature model: + semantic features, feature heads, learnable PE map,
+    feature sky head, three cameras).  Same losses as Trainer.losses.  The flow case runs the batched
     xyzt evaluations (3N dynamic, N + 2N flow) with input gradients through both grids."""
     import torch.nn.functional as Fn
     from oracle.ref_path import prop_loss
     from emernerf_amd.trainer import Trainer, synthetic_rays
     dev = _dev()
-    R, S = (1024 if kind == "flow" else 2048), 128
+    R, S = (1024 if kind in ("flow", "feature") else 2048), 128
     tr = Trainer(kind=kind, device=dev, num_samples=S, prop_samples=(128, 64), table_init=0.3, seed=7)
     ref = _ref_from_trainer(oracle, tr)
-    data = synthetic_rays(R, dev, seed=77)
-    if kind in ("dynamic", "flow"):
+    data = synthetic_rays(R, dev, seed=77, **(dict(num_cams=3, feature_dim=64) if kind == "feature" else {}))
+    if kind in ("dynamic", "flow", "feature"):
         # static + dynamic density saturates every ray (opacity rounds to exactly 1), where the sky term -log(1 - opacity)
         # and its gradient 1 / (1 - opacity) are decided by the last bit of a sum: covered by the static case; here the
         # dynamic / shadow branches are what is being compared
@@ -280,6 +281,8 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
         loss = loss + 0.01 * res["extras"]["dynamic_density"].mean()
     if "shadow_ratio" in res:
         loss = loss + 0.01 * res["shadow_ratio"].mean()
+    if "dino_feat" in res and "features" in cpu:  # feature supervision: l2, coefficient 0.5 (default_config.yaml:141-143)
+        loss = loss + 0.5 * Fn.mse_loss(res["dino_feat"], cpu["features"])
     if "forward_flow" in res["extras"]:  # flow cycle consistency, as Trainer.losses (train_emernerf.py:700-716)
         ex = res["extras"]
         loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
