@@ -327,14 +327,23 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArg
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     constexpr int KS0 = (KT0 + 1) / 2;
     u32x4 *w0l = smem, *w1l = w0l + w3_units(4, KS0);
-    float *b0l = reinterpret_cast<float *>(w1l + w3_units(NT1, 2)), *b1l = b0l + 64;
+    float *b0l = reinterpret_cast<float *>(w1l + w3_units(NT1, 2)), *b1l = b0l + 64, *w1v = b1l + NT1 * 16;
     stage_w3(w0l, 4, KS0, a.w0);
-    stage_w3(w1l, NT1, 2, a.w1);
+    if constexpr (NT1 == 1) {   // density MLP: the single output row stays fp32 (a 64-term dot product per row on the VALU)
+        for (int i = threadIdx.x; i < 64; i += (int)blockDim.x) w1v[i] = a.w1.w[i * a.w1.sk];
+    } else {
+        stage_w3(w1l, NT1, 2, a.w1);
+    }
     stage_b(b0l, 64, a.b0, a.w0.n);
     stage_b(b1l, NT1 * 16, a.b1, a.w1.n);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const W3 w0p = w3_at(w0l, 4, KS0, lane), w1p = w3_at(w1l, NT1, 2, lane);
+    f32x4 w1r[NT1 == 1 ? 4 : 1];   // density MLP: this lane's 16 weights of the output row (features 16 p + 4 g + i)
+    if constexpr (NT1 == 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) w1r[p] = *reinterpret_cast<const f32x4 *>(w1v + 16 * p + 4 * g);
+    }
     const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
     for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int64_t t0 = c * kNeckChunk;
@@ -354,14 +363,20 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArg
             tgemm<KS0, 4>(w0p, xo, h);
             relu<4>(h);
             if (a.h1) st_rm<4>(a.h1 + row * 64, ok, g, h);
-            Opd<2> ho;
-            make_opd<4>(h, ho);
             if constexpr (NT1 == 1) {
-                f32x4 o[1];
-                init_bias<1>(b1l, g, o);
-                tgemm<2, 1>(w1p, ho, o);
-                if (ok && g == 0) a.dens[row] = expf(o[0][0] - 1.0f);
+                // 64 -> 1: sixteen fp32 FMAs per lane and a reduction over the four lane groups of the row -- no split, no
+                // matrix instruction (the bf16x3 form spent 88 VALU on the split and 12 instructions on a 1-row output)
+                float dot = 0.0f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dot = fmaf(w1r[p][i], h[p][i], dot);
+                dot += __shfl_xor(dot, 16, 64);
+                dot += __shfl_xor(dot, 32, 64);
+                if (ok && g == 0) a.dens[row] = expf(dot + b1l[0] - 1.0f);
             } else {
+                Opd<2> ho;
+                make_opd<4>(h, ho);
                 // 64 output features at a time (16 live accumulators instead of 32)
                 f32x4 o[4];
                 init_bias<4>(b1l, g, o);
@@ -1111,13 +1126,13 @@ extern "C" int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_fe
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
     if (n_out == 1) {
-        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(1, 2)) * 16 + (64 + 16) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(1, 2)) * 16 + (64 + 16 + 64) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 1, a, lds, "neck_fwd");
     } else if (n_out == 64) {
-        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, 2)) * 16 + (64 + 64) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, 2)) * 16 + (64 + 64 + 64) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 4, a, lds, "neck_fwd");
     } else {
-        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(8, 2)) * 16 + (64 + 128) * sizeof(float); };
+        auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(8, 2)) * 16 + (64 + 128 + 64) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 8, a, lds, "neck_fwd");
     }
 }

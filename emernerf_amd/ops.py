@@ -5,6 +5,7 @@ module computes on the CPU or through torch math, so a missing extension fails l
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -111,6 +112,22 @@ class _LmToRmFn(torch.autograd.Function):
 
 def lm_to_rm(enc_lm: Tensor) -> Tensor:
     return _LmToRmFn.apply(enc_lm)
+
+
+CHECK_FINITE = os.environ.get("EMER_CHECK_FINITE") == "1"
+
+
+def _check_finite_grid_grad(dlm: Tensor, desc: GridDesc) -> None:
+    """Debug aid (EMER_CHECK_FINITE=1, the analogue of the reference's optim.check_nan, loss/base.py:77-79).  The owner-computes
+    backward reduces runs of equal cells with 0/1-masked multiply-adds, so ONE non-finite entry of the incoming gradient
+    contaminates other table entries of its wave (0 x inf = NaN; upstream's atomics keep it in the sample's own cells): looking
+    at the table gradient afterwards points at the wrong entries.  This check names the offending (level, sample) pairs BEFORE
+    the scatter; it costs one reduction over the gradient and a host read, so it is off by default."""
+    bad = ~torch.isfinite(dlm)
+    if bool(bad.any()):
+        idx = torch.nonzero(bad.any(dim=-1))[:8].tolist()
+        raise FloatingPointError(f"non-finite gradient entering the D{desc.n_dims}/L{desc.n_levels}/F{desc.n_features} hash-grid backward at "
+                                 f"(level, sample) {idx}{' ...' if int(bad.any(dim=-1).sum()) > 8 else ''}")
 
 
 def _table_grad_via_autograd(param, grad):
@@ -248,6 +265,8 @@ class _HashGridLMFn(torch.autograd.Function):
         _before_table_grad(ctx.param_obj)  # data-parallel trainer: early gradient bucket (fires on the table's last backward)
         with torch.cuda.device(xc.device):
             dlm = _f32c(dlm)
+            if CHECK_FINITE:
+                _check_finite_grid_grad(dlm, desc)
             st = _stream(xc)
             if ctx.needs_input_grad[1]:
                 gdt = ctx.grad_dtype or torch.float32

@@ -39,8 +39,10 @@ class PropNetEstimator(AbstractEstimator):
         self.pulse_width = anti_aliasing_pulse_width
         # Stratified jitter: one U(0,1) per ray per resampling round.  Upstream draws it inside the CUDA kernel from
         # torch's Philox state (irreproducible); here it is an explicit tensor, so the sampler stays bit-exact testable.
-        # Tests replace this hook to replay the oracle's draws.
-        self.jitter_fn: Callable[[int, torch.device], Tensor] = lambda n, dev: torch.rand(n, device=dev)
+        # Tests replace this hook to replay the oracle's draws.  None (default): ONE torch.rand call per sampling() for all of
+        # its resampling rounds.
+        self.jitter_fn: Optional[Callable[[int, torch.device], Tensor]] = None
+        self._unit = None  # cached [n_rays, 2] edges (0, 1) of the trivial level-0 histogram
 
     # ------------------------------------------------------------------------------------------ sampling (:89-179)
     @torch.no_grad()
@@ -53,9 +55,15 @@ class PropNetEstimator(AbstractEstimator):
         dev = self.device
         planes = (float(near_plane), float(far_plane), sampling_type)
         # level 0 resamples the trivial histogram on [0, 1]
-        edges = cdfs = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()  # (device-side: graph-capturable)
+        if self._unit is None or self._unit.shape[0] != n_rays or self._unit.device != dev:
+            self._unit = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()
+        edges = cdfs = self._unit  # read-only constant: no launch per call
+        jitters = None
+        if stratified and self.jitter_fn is None:
+            jitters = iter(torch.rand((len(prop_samples) + 1, n_rays), device=dev).unbind(0))
+        draw = (lambda: next(jitters)) if jitters is not None else (lambda: self.jitter_fn(n_rays, dev))
         for level, (sigma_fn, n_level) in enumerate(zip(prop_sigma_fns, prop_samples)):
-            u = self.jitter_fn(n_rays, dev) if stratified else None
+            u = draw() if stratified else None
             edges, t0, t1 = ops.importance_sample(edges, cdfs, n_level, u, stot=planes, intervals=True)
             with torch.set_grad_enabled(requires_grad):
                 sigma = sigma_fn(t0, t1)["density"].squeeze(-1)
@@ -65,7 +73,7 @@ class PropNetEstimator(AbstractEstimator):
                 self.prop_cache.append((RayIntervals(vals=edges), cdfs, level))
             else:
                 cdfs = cdfs.detach()
-        u = self.jitter_fn(n_rays, dev) if stratified else None
+        u = draw() if stratified else None
         edges, t0, t1 = ops.importance_sample(edges, cdfs.detach(), num_samples, u, stot=planes, intervals=True)
         if requires_grad:
             self.prop_cache.append((RayIntervals(vals=edges), None, None))

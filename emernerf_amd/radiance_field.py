@@ -75,6 +75,22 @@ class _EmbedFn(torch.autograd.Function):
         return dw, None
 
 
+_EMBED_CACHE: Dict[tuple, Tensor] = {}
+
+
+def _embed_per_ray(weight: Tensor, idx: Tensor) -> Tensor:
+    """The rgb head and the sky head of one forward pass look up the SAME per-ray indices (radiance_field.py:637-643,668-674):
+    the second lookup reuses the first (one gather, one scatter in the backward; autograd sums the two consumers' gradients).
+    The cache holds one entry and is keyed by the index storage, its version and the weight's, so it can never serve a stale
+    lookup; RadianceField.forward clears it on entry."""
+    key = (weight.data_ptr(), weight._version, idx.data_ptr(), idx._version, tuple(idx.shape), idx.stride(0), torch.is_grad_enabled())
+    hit = _EMBED_CACHE.get(key)
+    if hit is None:
+        _EMBED_CACHE.clear()
+        hit = _EMBED_CACHE[key] = _EmbedFn.apply(weight, idx)
+    return hit
+
+
 class MLP(nn.Module):
     """radiance_fields/mlp.py:7-46 (skip-connection MLP of the rgb / sky heads)."""
 
@@ -433,7 +449,9 @@ class RadianceField(nn.Module):
 
     def _embed(self, idx: Tensor) -> Tensor:
         if self._per_ray(idx):  # look up once per ray, broadcast along the samples (same values, 1/S of the work)
-            return _EmbedFn.apply(self.appearance_embedding.weight, idx[:, 0])[:, None, :].expand(-1, idx.shape[1], -1)
+            return _embed_per_ray(self.appearance_embedding.weight, idx[:, 0])[:, None, :].expand(-1, idx.shape[1], -1)
+        if idx.dim() == 1:  # the sky head's per-ray indices: the same storage the rgb head just looked up
+            return _embed_per_ray(self.appearance_embedding.weight, idx)
         return _EmbedFn.apply(self.appearance_embedding.weight, idx)
 
     def _encode_dirs(self, directions: Tensor, remap: bool) -> Tensor:
@@ -469,7 +487,7 @@ class RadianceField(nn.Module):
             if key is None:
                 emb = self.appearance_embedding.weight.mean(dim=0)[None, :].expand(R, -1)
             elif self._per_ray(data_dict[key]):
-                emb = _EmbedFn.apply(self.appearance_embedding.weight, data_dict[key][:, 0])
+                emb = _embed_per_ray(self.appearance_embedding.weight, data_dict[key][:, 0])
             else:
                 return None
         pe = self.direction_encoding(directions[:, 0].contiguous(), remap=True)
@@ -531,6 +549,7 @@ class RadianceField(nn.Module):
         ``hash_encodings`` (extension): False drops the three row-major ``*_dynamic_hash_encodings`` outputs of the flow
         branch ("to be studied" in the reference, consumed by nothing): render_rays never reads them."""
         results_dict = {}
+        _EMBED_CACHE.clear()
         if normed_positions is None:
             normed_positions = self.contract_points(positions)
         geo_feats, semantic_feats, static_density = self._static_split(normed_positions)

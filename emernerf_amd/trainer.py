@@ -157,8 +157,7 @@ class FlatParams:
         their gradient is overwritten by the owner-computes grid backward (``ops._HashGridLMFn``), which writes every
         entry exactly once, so zeroing 90 MB per step would be wasted HBM traffic.  A table whose backward did not run
         this step is zeroed lazily by ``finish_grads`` before anything reads it."""
-        for a, b in self._dense_ranges:
-            self.grads[a:b].zero_()
+        torch._foreach_zero_([self.grads[a:b] for a, b in self._dense_ranges])  # one multi-tensor launch
         for p, o in self._plist:  # autograd may have replaced .grad; re-pin the views
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)

@@ -690,3 +690,34 @@ def test_blend_accumulate_matches_torch(hip_lib, R, S, with_shadow):
     for k in names:
         ref_g = d64[k].grad
         np.testing.assert_allclose(dv[k].grad.cpu().numpy(), ref_g.numpy(), rtol=1e-4, atol=2e-6 * float(ref_g.abs().max()), err_msg=k)
+
+
+def test_nonfinite_gradient_is_reported_before_the_scatter(hip_lib, oracle, monkeypatch):
+    """DESIGN 4.1 "Determinism and numerics": the run reduction of the owner-computes backward multiplies neighbours by 0/1 masks,
+    so one inf in the incoming gradient turns OTHER table entries of its wave into NaN (upstream's atomics keep it local).  That
+    behaviour is pinned here, and so is the debug check (EMER_CHECK_FINITE=1 / ops.CHECK_FINITE) that names the offending
+    (level, sample) before the scatter -- the table gradient alone would point at the wrong entries."""
+    from emernerf_amd import _lib, ops
+    meta = oracle.grid_meta_from_encoder_args(3, 16, 16, 2048, 19, 2)
+    desc = _lib.make_grid_desc(3, 16, 2, 19, 16, meta.per_level_scale)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    N = 4096
+    x = torch.rand(N, 3, generator=g).to(dev)
+    p = (torch.rand(meta.n_params, generator=g) - 0.5).to(dev).requires_grad_(True)
+    dlm = torch.randn(16, N, 2, generator=g).to(dev)
+    clean = dlm.clone()
+    dlm[5, 1234, 1] = float("inf")
+    lm = ops.hashgrid_encode_lm(x, p, desc)
+    lm.backward(dlm)
+    bad = ~torch.isfinite(p.grad)
+    lo, hi = int(meta.offset[5]) * 2, (int(meta.offset[5]) + int(meta.size[5])) * 2
+    assert bool(bad.any()) and not bool(bad[:lo].any()) and not bool(bad[hi:].any()), "contamination must stay inside the level"
+    p.grad = None
+    monkeypatch.setattr(ops, "CHECK_FINITE", True)
+    lm = ops.hashgrid_encode_lm(x, p, desc)
+    with pytest.raises(FloatingPointError, match=r"\[5, 1234\]"):
+        lm.backward(dlm)
+    lm = ops.hashgrid_encode_lm(x, p, desc)
+    lm.backward(clean)   # finite gradients pass the check
+    assert bool(torch.isfinite(p.grad).all())
