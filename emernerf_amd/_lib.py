@@ -86,6 +86,12 @@ SIGNATURES = {
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
+    "emer_ray_inputs_fwd": [_P, c_int64, _P, c_int64, _P, c_int32, c_int32, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
+    "emer_embed_grad": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P],
+    "emer_ray_pre_fwd": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P],
+    "emer_ray_pre_bwd": [_P, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, c_int64, _P],
+    "emer_ray_head_fwd": [_P, c_int64, c_int64, _P, c_int64, _P, _P, c_int32, c_int, _P, _P, _P, _P],
+    "emer_ray_head_bwd": [_P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int32, c_int, _P, _P, _P, _P],
     "emer_sample_uniform": [_P, c_uint64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P],
     "emer_sample_importance": [_P, c_int64, _P, c_uint64, c_int64, _P, _P, _P],
     "emer_buffer_to_pixels": [_P, c_int64, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, c_uint64, _P, _P, _P, _P],

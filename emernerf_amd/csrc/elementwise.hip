@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ray_points_kernel(const float *__restrict
 //   out = [x (3), sin(2^i x_d) (i-major, 3 per degree), sin(2^i x_d + pi/2)]
 __global__ __launch_bounds__(256) void dir_encode_kernel(const float *__restrict__ dirs, float *__restrict__ out, int64_t n,
                                                          int32_t max_deg, int remap) {
-    const int32_t n_deg = max_deg + 1, width = 3 * (1 + 2 * n_deg);
+    const int32_t n_deg = max_deg + 1, width = max_deg == 0 ? 3 : 3 * (1 + 2 * n_deg);  // identity rows are 3 wide
     const float half_pi = 0.5f * 3.14159265358979323846f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float x[3];

@@ -441,14 +441,14 @@ class _RgbHeadFn(torch.autograd.Function):
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
         ctx.S = S
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
-        ctx.fast = (H == 64 and NG == 64 and C == 3 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
+        ctx.fast = (H == 64 and NG == 64 and C == 3 and Kh <= 64 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
         if ctx.fast:
-            # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row GEMM instead of two 1M-row ones)
-            wcat = torch.cat([W0[:, :Kh], W1[:, H:H + Kh]], 0)
+            # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row launch instead of two 1M-row GEMMs),
+            # reading the two column blocks of W0 / W1 in place
             rb = torch.empty((R, 2 * H), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.call("emer_linear_fwd", _p(hr), hr.stride(0), _p(wcat), _p(torch.cat([B0, B1])), _p(rb), 2 * H, R, 2 * H, Kh,
-                          ACT_NONE, None, _stream(g))
+                _lib.call("emer_ray_pre_fwd", _p(hr), hr.stride(0), R, Kh, H, _p(W0), W0.stride(0), _p(B0), _p(W1[:, H:]), W1.stride(0),
+                          _p(B1), _p(rb), 2 * H, _stream(g))
             rb0, rb1 = rb[:, :H], rb[:, H:]
             with torch.cuda.device(dev):
                 _lib.call("emer_rgb_head_fwd", _p(g), g.stride(0), _p(rb0), _p(rb1), rb.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(B2),
@@ -503,7 +503,10 @@ class _RgbHeadFn(torch.autograd.Function):
             # (8192-row GEMMs; colsum(s) is the bias gradient)
             wgrad(s1, [seg(hr, 0, Kh, dst_col=H)], Kh, out_w=tw1, out_b=tb1)
             wgrad(s0, [seg(hr, 0, Kh, dst_col=0)], Kh, out_w=tw0, out_b=tb0)
-            dhray = torch.addmm(s1 @ W1[:, H:H + Kh], s0, W0[:, :Kh])
+            dhray = torch.empty((R, Kh), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_ray_pre_bwd", _p(s0), _p(s1), H, R, Kh, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dhray), Kh,
+                          _stream(g))
             return dhray, dgeo, None, rw0, rb0, rw1, rb1, rw2, rb2
         dpre2 = (_c(dout) * out * (1.0 - out)).contiguous()            # sigmoid'
         dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
@@ -531,6 +534,58 @@ def rgb_head(hray: Tensor, geo: Tensor, samples_per_ray: int, w0, b0, w1, b1, w2
     return _RgbHeadFn.apply(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2)
 
 
+# ------------------------------------------------------------------------------------------ per-ray inputs
+class _RayInputsFn(torch.autograd.Function):
+    """Input rows of the rgb head ([PE((d+1)/2) | emb[idx]]) and of the sky head ([PE(d) | emb[idx]]) in ONE launch
+    (radiance_field.py:622-643,660-674; replaces two encoder launches, the gather and two cats), and the embedding
+    table's gradient as one deterministic segment sum over both consumers' input gradients (replaces autograd's add,
+    a zero fill and an atomic index_add)."""
+
+    @staticmethod
+    def forward(ctx, weight: Tensor, idx: Tensor, dirs: Tensor, max_deg: int):
+        ctx.set_materialize_grads(False)
+        w = _c(weight)
+        assert idx.dtype == torch.int64 and idx.dim() == 1 and dirs.dim() == 2 and dirs.dtype == torch.float32 and dirs.stride(1) == 1
+        R, E = dirs.shape[0], w.shape[1]
+        P = 3 if max_deg == 0 else 3 * (1 + 2 * (max_deg + 1))
+        dev = dirs.device
+        with torch.cuda.device(dev):
+            out_rgb = torch.empty((R, P + E), device=dev, dtype=torch.float32)
+            out_sky = torch.empty((R, P + E), device=dev, dtype=torch.float32)
+            _lib.call("emer_ray_inputs_fwd", _p(dirs), dirs.stride(0), _p(idx), idx.stride(0), _p(w), w.shape[0], E, max_deg, R,
+                      _p(out_rgb), P + E, _p(out_sky), P + E, _stream(dirs))
+        ctx.save_for_backward(idx)
+        ctx.sink, ctx.shape, ctx.P = _sink(weight), tuple(w.shape), P
+        return out_rgb, out_sky
+
+    @staticmethod
+    def backward(ctx, g_rgb: Optional[Tensor], g_sky: Optional[Tensor]):
+        if g_rgb is None and g_sky is None:
+            return None, None, None, None
+        (idx,) = ctx.saved_tensors
+        dev = idx.device
+        P = ctx.P
+
+        def cols(g):
+            if g is None:
+                return None, 0
+            g = g if (g.dtype == torch.float32 and g.stride(1) == 1) else g.to(torch.float32).contiguous()
+            return g[:, P:], g.stride(0)
+
+        (ga, lda), (gb, ldb) = cols(g_rgb), cols(g_sky)
+        tw, rw = _target(ctx.sink, ctx.shape, dev)
+        with torch.cuda.device(dev):
+            _lib.call("emer_embed_grad", _p(ga), lda, _p(gb), ldb, _p(idx), idx.stride(0), idx.shape[0], ctx.shape[0], ctx.shape[1],
+                      _p(tw), _stream(idx))
+        return rw, None, None, None
+
+
+
+def ray_inputs(emb_weight: Tensor, idx: Tensor, dirs: Tensor, max_deg: int):
+    """(rgb-head rows, sky-head rows), each [R, PE + emb_dim], for per-ray directions [R, 3] and embedding indices [R]."""
+    return _RayInputsFn.apply(emb_weight, idx, dirs, max_deg)
+
+
 # ------------------------------------------------------------------------- 3-layer skip MLP on row-major input
 class _SkipMLP3Fn(torch.autograd.Function):
     """act(MLP(x)) for mlp.MLP(num_layers=3, skip_connections=[1]) (mlp.py:20-46) on a plain row-major input -- the
@@ -548,13 +603,24 @@ class _SkipMLP3Fn(torch.autograd.Function):
         a1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
-        c_x = H                     # [A1 | x] laid out exactly like torch.cat([x_hidden, input]) of mlp.py:42
-        c_o = c_x + _r4(K0)
-        run_chain([seg(X, c_x, K0)],
-                  [layer(W0, B0, c_x, 0, ACT_RELU, store=a1),
-                   layer(W1, B1, 0, 0, ACT_RELU, store=a2),     # A2 overwrites A1 in place (one column group)
-                   layer(W2, B2, 0, c_o, final_act, store=out)],
-                  c_o + _r4(C), N, X)
+        ctx.fast = H == 64 and K0 <= 64 and C <= 16
+        if ctx.fast:
+            # a few thousand rows: two small launches (the input's share of layers 0 and 1, then the rest of the MLP)
+            # instead of the general chain kernel, whose set-up dominates at this size
+            rb = torch.empty((N, 2 * H), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_ray_pre_fwd", _p(X), X.stride(0), N, K0, H, _p(W0), W0.stride(0), _p(B0), _p(W1[:, H:]), W1.stride(0), _p(B1),
+                          _p(rb), 2 * H, _stream(X))
+                _lib.call("emer_ray_head_fwd", _p(rb), 2 * H, N, _p(W1), W1.stride(0), _p(W2), _p(B2), C, final_act, _p(a1), _p(a2), _p(out),
+                          _stream(X))
+        else:
+            c_x = H                     # [A1 | x] laid out exactly like torch.cat([x_hidden, input]) of mlp.py:42
+            c_o = c_x + _r4(K0)
+            run_chain([seg(X, c_x, K0)],
+                      [layer(W0, B0, c_x, 0, ACT_RELU, store=a1),
+                       layer(W1, B1, 0, 0, ACT_RELU, store=a2),     # A2 overwrites A1 in place (one column group)
+                       layer(W2, B2, 0, c_o, final_act, store=out)],
+                      c_o + _r4(C), N, X)
         ctx.save_for_backward(X, W0, W1, W2, a1, a2, out)
         ctx.final_act = final_act
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
@@ -569,18 +635,26 @@ class _SkipMLP3Fn(torch.autograd.Function):
         H, C = W0.shape[0], W2.shape[0]
         dev = X.device
         d = _c(dout)
-        dpre2 = (d * out * (1.0 - out)).contiguous() if ctx.final_act == ACT_SIGMOID else d  # sigmoid' / identity
         dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
         dx = torch.empty((N, K0), device=dev, dtype=torch.float32)
-        c1 = _r4(C)                 # dA2 -> dPre1
-        cx = c1 + H                 # d[A1 | x]; dA1 -> dPre0 in place
-        run_chain([seg(dpre2, 0, C)],
-                  [layer(W2, None, 0, c1, transposed=True, mask=a2, store=dpre1),
-                   layer(W1, None, c1, cx, transposed=True, n_slice=(0, H), mask=a1, store=dpre0),
-                   layer(W1, None, c1, cx + H, transposed=True, n_slice=(H, H + K0)),
-                   layer(W0, None, cx, cx + H, transposed=True, accumulate=True, store=dx)],
-                  cx + H + _r4(K0), N, X)
+        if ctx.fast:
+            dpre2 = torch.empty((N, C), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_ray_head_bwd", _p(d), _p(out), _p(a1), _p(a2), N, _p(W1), W1.stride(0), _p(W2), C, ctx.final_act, _p(dpre2),
+                          _p(dpre1), _p(dpre0), _stream(X))
+                _lib.call("emer_ray_pre_bwd", _p(dpre0), _p(dpre1), H, N, K0, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dx), K0,
+                          _stream(X))
+        else:
+            dpre2 = torch.ops.aten.sigmoid_backward(d, out) if ctx.final_act == ACT_SIGMOID else d  # sigmoid' (one launch) / identity
+            c1 = _r4(C)                 # dA2 -> dPre1
+            cx = c1 + H                 # d[A1 | x]; dA1 -> dPre0 in place
+            run_chain([seg(dpre2, 0, C)],
+                      [layer(W2, None, 0, c1, transposed=True, mask=a2, store=dpre1),
+                       layer(W1, None, c1, cx, transposed=True, n_slice=(0, H), mask=a1, store=dpre0),
+                       layer(W1, None, c1, cx + H, transposed=True, n_slice=(H, H + K0)),
+                       layer(W0, None, cx, cx + H, transposed=True, accumulate=True, store=dx)],
+                      cx + H + _r4(K0), N, X)
         sw0, sb0, sw1, sb1, sw2, sb2 = ctx.sinks
         tw2, rw2 = _target(sw2, (C, H), dev)
         tb2, rb2 = _target(sb2, (C,), dev)

@@ -565,7 +565,8 @@ class _PixelLossFn(torch.autograd.Function):
     """w_rgb * mse(rgb, pixels) + w_sky * bce(opacity, 1 - sky_mask) (loss/base.py:83-185), one launch each way."""
 
     @staticmethod
-    def forward(ctx, rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask: Optional[Tensor], w_rgb: float, w_sky: float):
+    def forward(ctx, rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask: Optional[Tensor], w_rgb: float, w_sky: float,
+                grad_scale: float = 1.0):
         r, px = _f32c(rgb).view(-1, 3), _f32c(pixels).view(-1, 3)
         R = r.shape[0]
         op = None if opacity is None else _f32c(opacity).view(-1)
@@ -576,7 +577,7 @@ class _PixelLossFn(torch.autograd.Function):
             _lib.call("emer_pixel_loss_fwd", _ptr(r), _ptr(px), _ptr(op), _ptr(sm), R, float(w_rgb), float(w_sky), _ptr(rays), _ptr(loss),
                       _stream(r))
         ctx.save_for_backward(r, px, op, sm)
-        ctx.w, ctx.shapes = (float(w_rgb), float(w_sky)), (rgb.shape, None if opacity is None else opacity.shape)
+        ctx.w, ctx.shapes = (float(w_rgb) * float(grad_scale), float(w_sky) * float(grad_scale)), (rgb.shape, None if opacity is None else opacity.shape)
         return loss
 
     @staticmethod
@@ -590,14 +591,16 @@ class _PixelLossFn(torch.autograd.Function):
             do = torch.empty_like(op) if need_o else None
             _lib.call("emer_pixel_loss_bwd", _ptr(r), _ptr(px), _ptr(op), _ptr(sm), R, ctx.w[0], ctx.w[1], _ptr(gc), _ptr(dr), _ptr(do),
                       _stream(r))
-        return (None if dr is None else dr.view(ctx.shapes[0])), (None if do is None else do.view(ctx.shapes[1])), None, None, None, None
+        return (None if dr is None else dr.view(ctx.shapes[0])), (None if do is None else do.view(ctx.shapes[1])), None, None, None, None, None
 
 
 def pixel_loss(rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask: Optional[Tensor], w_rgb: float = 1.0,
-               w_sky: float = 0.001) -> Tensor:
-    """rgb L2 + opacity-based sky BCE of a pixel-ray batch as one scalar (0-dim tensor)."""
+               w_sky: float = 0.001, grad_scale: float = 1.0) -> Tensor:
+    """rgb L2 + opacity-based sky BCE of a pixel-ray batch as one scalar (0-dim tensor).  ``grad_scale`` multiplies the
+    GRADIENTS only (a trainer's loss scale folded into the backward kernel: the returned value stays the plain loss and
+    no ``loss * scale`` launch, nor its backward, is needed)."""
     _check_cuda(rgb, opacity, pixels, sky_mask)
-    return _PixelLossFn.apply(rgb, opacity, pixels, sky_mask, w_rgb, w_sky)
+    return _PixelLossFn.apply(rgb, opacity, pixels, sky_mask, w_rgb, w_sky, grad_scale)
 
 
 class _LidarLossFn(torch.autograd.Function):

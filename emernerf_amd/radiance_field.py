@@ -471,6 +471,35 @@ class RadianceField(nn.Module):
         return torch.ones((*directions.shape[:-1], self.appearance_embedding_dim), device=directions.device) \
             * self.appearance_embedding.weight.mean(dim=0)
 
+    def _ray_inputs(self, directions: Tensor, data_dict: Optional[Dict[str, Tensor]]):
+        """(rgb-head rows, sky-head rows) = [direction PE | appearance embedding] per RAY from one launch, shared by the two
+        heads of a forward pass (they look up the same indices, :637-643 and :668-674), or None when the inputs are not
+        per-ray / there is no embedding (then the general path below runs).  The cache holds one entry and is keyed by the
+        storages and versions involved, so it never serves stale rows; forward() clears it on entry."""
+        if not (self.enable_cam_embedding or self.enable_img_embedding) or directions is None:
+            return None
+        data_dict = data_dict or {}
+        key = "cam_idx" if ("cam_idx" in data_dict and self.enable_cam_embedding) else \
+            ("img_idx" if ("img_idx" in data_dict and self.enable_img_embedding) else None)
+        if key is None:
+            return None
+        idx = data_dict[key]
+        idx = idx[:, 0] if self._per_ray(idx) else idx
+        d = directions[:, 0] if (directions.dim() == 3 and self._per_ray(directions)) else directions
+        enc = self.direction_encoding
+        if not (idx.dim() == 1 and d.dim() == 2 and d.shape[0] == idx.shape[0] and idx.dtype == torch.int64 and d.is_cuda
+                and d.dtype == torch.float32 and d.stride(1) == 1 and not d.requires_grad
+                and enc.n_input_dims == 3 and enc.min_deg == 0 and enc.enable_identity):
+            return None
+        w = self.appearance_embedding.weight
+        ck = (w.data_ptr(), w._version, idx.data_ptr(), idx._version, idx.stride(0), d.data_ptr(), d._version, d.stride(0),
+              d.shape[0], torch.is_grad_enabled())
+        hit = _EMBED_CACHE.get(ck)
+        if hit is None:
+            _EMBED_CACHE.clear()
+            hit = _EMBED_CACHE[ck] = fused.ray_inputs(w, idx, d, enc.max_deg)
+        return hit
+
     def _query_rgb_fused(self, directions, geo_feats, dynamic_geo_feats, data_dict):
         """Fused rgb head: per-ray [dir-PE | appearance emb] stays per ray, geo stays per sample, the whole
         3-layer skip MLP + sigmoid is one chain.  Applies when render_rays hands in stride-0 per-ray views."""
@@ -481,7 +510,10 @@ class RadianceField(nn.Module):
         R, S = directions.shape[:2]
         data_dict = data_dict or {}
         emb = None
-        if self.enable_cam_embedding or self.enable_img_embedding:
+        both = self._ray_inputs(directions, data_dict)
+        if both is not None:
+            hray = both[0]
+        elif self.enable_cam_embedding or self.enable_img_embedding:
             key = "cam_idx" if ("cam_idx" in data_dict and self.enable_cam_embedding) else \
                 ("img_idx" if ("img_idx" in data_dict and self.enable_img_embedding) else None)
             if key is None:
@@ -490,8 +522,9 @@ class RadianceField(nn.Module):
                 emb = _embed_per_ray(self.appearance_embedding.weight, data_dict[key][:, 0])
             else:
                 return None
-        pe = self.direction_encoding(directions[:, 0].contiguous(), remap=True)
-        hray = pe if emb is None else torch.cat([pe, emb], dim=-1)
+        if both is None:
+            pe = self.direction_encoding(directions[:, 0].contiguous(), remap=True)
+            hray = pe if emb is None else torch.cat([pe, emb], dim=-1)
         lw = [p for l in head.layers for p in (l.weight, l.bias)]
 
         def run(geo):
@@ -525,10 +558,14 @@ class RadianceField(nn.Module):
     def query_sky(self, directions: Tensor, data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
         """:660-686 (per ray).  Note: the reference does NOT remap directions for the sky head."""
         d = directions if directions.dim() == 2 else directions[:, 0]
-        dd = self.direction_encoding(d, remap=False)
-        emb = self._appearance(directions, data_dict)
-        if emb is not None:
-            dd = torch.cat([dd, emb], dim=-1)
+        both = self._ray_inputs(d, data_dict)
+        if both is not None:
+            dd = both[1]
+        else:
+            dd = self.direction_encoding(d, remap=False)
+            emb = self._appearance(directions, data_dict)
+            if emb is not None:
+                dd = torch.cat([dd, emb], dim=-1)
         head = self.sky_head
         if dd.dim() == 2 and len(head.layers) == 3 and list(head.skip_connections) == [1] and head.hidden_dims % 4 == 0:
             lw = [p for l in head.layers for p in (l.weight, l.bias)]

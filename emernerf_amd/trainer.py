@@ -285,26 +285,49 @@ class Trainer:
         self._early_done, self._early_work = False, []
         self._prop_work = None  # async all-reduce of the trained proposal net's range (launched right after ITS backward)
         self._hold_buckets = False  # graph warm-up / capture: no collectives from inside the forward+backward
+        self._one = torch.ones((), device=self.device, dtype=torch.float32)
         if world_size > 1:
             self.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = self._launch_early_bucket
         self.model.train(); self.estimator.train()
         for p in self.props:
             p.train()
 
-    def losses(self, results, data) -> Tensor:
-        """rgb L2 (loss/base.py:83-146, coef 1) + opacity-based sky BCE (loss/base.py:149-185, coef 0.001)."""
-        loss = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001)  # one launch
+    def _extra_losses(self, results, data) -> Optional[Tensor]:
+        """The regularisers of the dynamic / flow / feature models (None for the static model)."""
+        terms = []
         if "dynamic_density" in results["extras"]:
-            loss = loss + 0.01 * results["extras"]["dynamic_density"].mean()
+            terms.append(0.01 * results["extras"]["dynamic_density"].mean())
         if "shadow_ratio" in results:
-            loss = loss + 0.01 * results["shadow_ratio"].mean()
+            terms.append(0.01 * results["shadow_ratio"].mean())
         if "dino_feat" in results and "features" in data:  # feature supervision: l2, coefficient 0.5 (default_config.yaml:141-143)
-            loss = loss + 0.5 * F.mse_loss(results["dino_feat"], data["features"])
+            terms.append(0.5 * F.mse_loss(results["dino_feat"], data["features"]))
         if "forward_flow" in results["extras"]:
             ex = results["extras"]
-            loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
-                                        + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
-        return loss
+            terms.append(0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
+                                       + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean())
+        if not terms:
+            return None
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
+
+    def losses(self, results, data) -> Tensor:
+        """rgb L2 (loss/base.py:83-146, coef 1) + opacity-based sky BCE (loss/base.py:149-185, coef 0.001) + the regularisers."""
+        loss = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001)  # one launch
+        extra = self._extra_losses(results, data)
+        return loss if extra is None else loss + extra
+
+    def _scaled_losses(self, results, data):
+        """(tensor to back-propagate, plain loss value): the loss scale is folded into the pixel-loss backward kernel, so the
+        static step needs no ``loss * scale`` launch, no backward of it, and -- with the persistent ``self._one`` as the
+        seed -- no ones_like fill."""
+        pix = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001,
+                             grad_scale=self.loss_scale)
+        extra = self._extra_losses(results, data)
+        if extra is None:
+            return pix, pix.detach()
+        return pix + extra * self.loss_scale, (pix + extra).detach()
 
     def lidar_losses(self, results, data, step: int) -> Tensor:
         """Depth + line-of-sight supervision of the lidar step (train_emernerf.py:770-808 with
@@ -333,10 +356,12 @@ class Trainer:
             results = render_rays(radiance_field=self.model, proposal_estimator=self.estimator, proposal_networks=self.props,
                                   data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad, prefix="lidar_")
             if prop_grad:
-                self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale).backward()
+                pl = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
+                pl.backward(gradient=self._seed(pl))
                 self._launch_prop_bucket()
             loss = self.lidar_losses(results, data, step)
-            (loss * self.loss_scale).backward()
+            scaled = loss * self.loss_scale
+            scaled.backward(gradient=self._seed(scaled))
         fused.join_side_stream()
         self._exchange_grads(prop_grad)
         lr = self.lr * lr_factor(self.sched_ticks, self.num_iters)
@@ -345,6 +370,10 @@ class Trainer:
         self._adam("main", lr)
         self.sched_ticks += 1
         return {"loss": loss.detach(), "prop_grad": prop_grad}
+
+    def _seed(self, like: Tensor) -> Tensor:
+        """A persistent 1.0 as the backward seed of a scalar loss (autograd would launch a ones_like fill per backward)."""
+        return self._one if like.shape == self._one.shape else self._one.expand(like.shape)
 
     # ------------------------------------------------------------------------------------------- data parallel
     def _launch_early_bucket(self) -> None:
@@ -447,12 +476,12 @@ class Trainer:
                                   data_dict=data, cfg=self.rcfg, proposal_requires_grad=prop_grad)
             if prop_grad:
                 prop_loss = self.estimator.compute_loss(results["extras"]["trans"], loss_scaler=self.loss_scale)
-                prop_loss.backward()
+                prop_loss.backward(gradient=self._seed(prop_loss))
                 self._launch_prop_bucket()
-            loss = self.losses(results, data)
-            (loss * self.loss_scale).backward()
+            target, loss = self._scaled_losses(results, data)
+            target.backward(gradient=self._seed(target))
         fused.join_side_stream()  # weight gradients written on the side stream are complete from here on
-        return loss.detach()
+        return loss
 
     def _graphed_forward_backward(self, data: Dict[str, Tensor], prop_grad: bool) -> Tensor:
         """hipGraph replay of _forward_backward: one graph per step type (with / without proposal-net training),

@@ -438,6 +438,47 @@ int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_st
 int emer_dir_encode(const float *dirs, float *out, int64_t n, int32_t max_deg, int remap,
                     void *stream);
 
+/* ---- per-ray side of the colour heads (csrc/rayinputs.hip) ---------------------------------------------
+ * Input rows of the rgb head (radiance_field.py:622-643: PE of the remapped direction | appearance embedding of the ray's
+ * image / camera) and of the sky head (:660-674: PE of the raw direction | the same embedding) in one launch.
+ * dirs [n_rays, >=3] (row stride ld_dirs); idx [n_rays] int64 with element stride idx_stride (NULL: row 0);
+ * emb [n_emb, emb_dim] (emb_dim 0: no embedding); out_* [n_rays, 3*(1+2*(max_deg+1)) + emb_dim] (either may be NULL).
+ * An index outside [0, n_emb) writes NaN into the row (torch raises a device assert). */
+int emer_ray_inputs_fwd(const float *dirs, int64_t ld_dirs, const int64_t *idx, int64_t idx_stride,
+                        const float *emb, int32_t n_emb, int32_t emb_dim, int32_t max_deg,
+                        int64_t n_rays, float *out_rgb, int64_t ld_rgb, float *out_sky,
+                        int64_t ld_sky, void *stream);
+/* Gradient of the embedding table (nn.Embedding backward, radiance_field.py:134-141): dw[e] += sum over the rays with
+ * idx == e of g_a[ray] + g_b[ray]; g_* point at the FIRST embedding column of the two consumers' input gradients (either
+ * may be NULL).  Deterministic (fixed summation order), no atomics, no workspace. */
+int emer_embed_grad(const float *g_a, int64_t ld_a, const float *g_b, int64_t ld_b, const int64_t *idx,
+                    int64_t idx_stride, int64_t n_rays, int32_t n_emb, int32_t emb_dim, float *dw,
+                    void *stream);
+/* The per-ray operand's share of layers 0 and 1 of the rgb head (mlp.py:38-46, skip connection into layer 1): h [n_rays, kh]
+ * multiplies column block [0, kh) of W0 and [n_hidden, n_hidden + kh) of W1 for every sample of the ray, so it is applied
+ * once per ray.  wa / wb point at those blocks INSIDE the weight matrices (row strides ld_wa / ld_wb).
+ *   fwd: rb[r] = [wa h[r] + ba | wb h[r] + bb]   [n_rays, 2 n_hidden]   (the offsets emer_rgb_head_fwd adds per ray)
+ *   bwd: dh[r] = s0[r] wa + s1[r] wb             s0 / s1 [n_rays, n_hidden]: per-ray sums of dpre0 / dpre1 */
+int emer_ray_pre_fwd(const float *h, int64_t ld_h, int64_t n_rays, int32_t kh, int32_t n_hidden,
+                     const float *wa, int64_t ld_wa, const float *ba, const float *wb, int64_t ld_wb,
+                     const float *bb, float *rb, int64_t ld_rb, void *stream);
+int emer_ray_pre_bwd(const float *s0, const float *s1, int64_t ld_s, int64_t n_rays, int32_t kh,
+                     int32_t n_hidden, const float *wa, int64_t ld_wa, const float *wb, int64_t ld_wb,
+                     float *dh, int64_t ld_dh, void *stream);
+
+/* The per-ray skip MLP itself (the sky head, radiance_field.py:156-187,660-686: mlp.MLP(num_layers=3, skip_connections=[1]),
+ * hidden width 64, n_out <= 16) after emer_ray_pre_fwd has applied the input x to layers 0 and 1 (wa = W0, wb = W1[:, 64:]):
+ *   fwd: a1 = relu(rb[:, :64]); a2 = relu(W1[:, :64] a1 + rb[:, 64:]); out = act(W2 a2 + b2)   act: EMER_ACT_NONE / _SIGMOID
+ *   bwd: dpre2 = dout * act'(out); dpre1 = (a2 > 0) (dpre2 W2); dpre0 = (a1 > 0) (dpre1 W1[:, :64])
+ * a1 / a2 / dpre1 / dpre0 [n_rows, 64], out / dout / dpre2 [n_rows, n_out], all contiguous.  The input gradient is
+ * emer_ray_pre_bwd(dpre0, dpre1, ...); the weight gradients are emer_wgrad_segmented on dpre0 / dpre1 / dpre2. */
+int emer_ray_head_fwd(const float *rb, int64_t ld_rb, int64_t n_rows, const float *w1, int64_t ld_w1,
+                      const float *w2, const float *b2, int32_t n_out, int act, float *a1, float *a2,
+                      float *out, void *stream);
+int emer_ray_head_bwd(const float *dout, const float *out, const float *a1, const float *a2,
+                      int64_t n_rows, const float *w1, int64_t ld_w1, const float *w2, int32_t n_out,
+                      int act, float *dpre2, float *dpre1, float *dpre0, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-ray generation (replaces datasets/base/pixel_source.py:39-76 get_rays and
  * :564-731 sample_uniform_rays / sample_important_rays / the gathers of get_train_rays) on device-resident

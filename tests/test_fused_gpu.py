@@ -193,7 +193,7 @@ def test_grad_sinks_equal_autograd_accumulation(hip_lib):
             _close(f"side {k}{i}", a.grad - 0.25, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
-@pytest.mark.parametrize("N,K0,act", [(8192, 43, "sigmoid"), (100, 27, "sigmoid"), (33, 43, "none")])
+@pytest.mark.parametrize("N,K0,act", [(8192, 43, "sigmoid"), (100, 27, "sigmoid"), (33, 43, "none"), (64, 70, "sigmoid")])  # K0 = 70: the general chain path
 def test_skip_mlp3(hip_lib, N, K0, act):
     """fused.skip_mlp3 (per-ray sky head) vs fp64 torch: MLP(3 layers, skip at 1) + sigmoid."""
     from emernerf_amd import fused, _lib

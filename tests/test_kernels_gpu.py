@@ -721,3 +721,73 @@ def test_nonfinite_gradient_is_reported_before_the_scatter(hip_lib, oracle, monk
     lm = ops.hashgrid_encode_lm(x, p, desc)
     lm.backward(clean)   # finite gradients pass the check
     assert bool(torch.isfinite(p.grad).all())
+
+
+# ------------------------------------------------------------------------------------------ per-ray inputs of the heads
+@pytest.mark.parametrize("R,n_emb,E,max_deg", [(8192, 150, 16, 4), (8192, 2, 16, 4), (37, 3, 16, 4), (513, 1000, 5, 2), (64, 1, 16, 0), (5000, 1, 20, 4)])
+def test_ray_inputs_and_embedding_gradient(hip_lib, R, n_emb, E, max_deg):
+    """emer_ray_inputs_fwd == [emer_dir_encode | weight[idx]] bit for bit (rgb rows on remapped directions, sky rows on raw
+    ones); emer_embed_grad == index_add of the two consumers' gradients in fp64 (tolerance 1e-6 relative to the largest
+    entry: fp32 sums of up to R terms), and is deterministic (two runs bit-identical)."""
+    from emernerf_amd import fused, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + n_emb)
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    idx_full = torch.randint(0, n_emb, (R, 2), generator=g).to(dev)
+    idx = idx_full[:, 1]  # strided indices (a column of a wider tensor)
+    w = torch.randn(n_emb, E, generator=g).to(dev).requires_grad_(True)
+    rgb_rows, sky_rows = fused.ray_inputs(w, idx, dirs, max_deg)
+    P = 3 if max_deg == 0 else 3 * (1 + 2 * (max_deg + 1))
+    assert rgb_rows.shape == (R, P + E) and sky_rows.shape == (R, P + E)
+    assert torch.equal(rgb_rows[:, :P], ops.dir_encode(dirs, max_deg, remap=True))
+    assert torch.equal(sky_rows[:, :P], ops.dir_encode(dirs, max_deg, remap=False))
+    assert torch.equal(rgb_rows[:, P:], w.detach()[idx]) and torch.equal(sky_rows[:, P:], w.detach()[idx])
+    ga = torch.randn(R, P + E, generator=g).to(dev)
+    gb = torch.randn(R, P + E, generator=g).to(dev)
+    ref = torch.zeros(n_emb, E, dtype=torch.float64, device=dev).index_add_(0, idx, (ga[:, P:] + gb[:, P:]).double())
+    (dw,) = torch.autograd.grad([rgb_rows, sky_rows], [w], [ga, gb], retain_graph=True)
+    assert (dw.double() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    (dw2,) = torch.autograd.grad([rgb_rows, sky_rows], [w], [ga, gb], retain_graph=True)
+    assert torch.equal(dw, dw2)
+    (dw_one,) = torch.autograd.grad([sky_rows], [w], [gb])  # one consumer only (eval of the sky head alone)
+    ref_one = torch.zeros(n_emb, E, dtype=torch.float64, device=dev).index_add_(0, idx, gb[:, P:].double())
+    assert (dw_one.double() - ref_one).abs().max().item() <= 1e-6 * max(1.0, ref_one.abs().max().item())
+
+
+def test_ray_inputs_out_of_range_index_poisons_the_row(hip_lib):
+    from emernerf_amd import fused
+    dev = _dev()
+    dirs = torch.nn.functional.normalize(torch.randn(8, 3), dim=-1).to(dev)
+    idx = torch.tensor([0, 1, 2, 3, 4, 5, 6, 2], device=dev)
+    w = torch.randn(5, 16, device=dev)
+    rgb_rows, _ = fused.ray_inputs(w, idx, dirs, 4)
+    bad = torch.isnan(rgb_rows[:, 33:]).all(dim=1)
+    assert bad.tolist() == [False, False, False, False, False, True, True, False]
+
+
+@pytest.mark.parametrize("R,Kh,H", [(8192, 49, 64), (45, 33, 64), (1000, 64, 64), (70, 7, 16)])
+def test_ray_pre_matches_fp64(hip_lib, R, Kh, H):
+    """emer_ray_pre_fwd / bwd against fp64 matmuls on the same column blocks of wider weight matrices (1e-6 relative to the
+    largest entry: fp32 dot products of <= 128 terms)."""
+    import ctypes
+    from emernerf_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + Kh)
+    NG = 64
+    W0 = torch.randn(H, Kh + NG, generator=g).to(dev)
+    W1 = torch.randn(H, H + Kh + NG, generator=g).to(dev)
+    b0, b1 = torch.randn(H, generator=g).to(dev), torch.randn(H, generator=g).to(dev)
+    h = torch.randn(R, Kh, generator=g).to(dev)
+    rb = torch.empty(R, 2 * H, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wb = W1[:, H:]
+    _lib.call("emer_ray_pre_fwd", h.data_ptr(), h.stride(0), R, Kh, H, W0.data_ptr(), W0.stride(0), b0.data_ptr(), wb.data_ptr(), W1.stride(0),
+              b1.data_ptr(), rb.data_ptr(), 2 * H, st)
+    ref = torch.cat([h.double() @ W0[:, :Kh].double().T + b0.double(), h.double() @ W1[:, H:H + Kh].double().T + b1.double()], 1)
+    assert (rb.double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    s0, s1 = torch.randn(R, H, generator=g).to(dev), torch.randn(R, H, generator=g).to(dev)
+    dh = torch.empty(R, Kh, device=dev)
+    _lib.call("emer_ray_pre_bwd", s0.data_ptr(), s1.data_ptr(), H, R, Kh, H, W0.data_ptr(), W0.stride(0), wb.data_ptr(), W1.stride(0),
+              dh.data_ptr(), Kh, st)
+    ref = s0.double() @ W0[:, :Kh].double() + s1.double() @ W1[:, H:H + Kh].double()
+    assert (dh.double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
