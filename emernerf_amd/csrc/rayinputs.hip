@@ -318,6 +318,106 @@ __global__ __launch_bounds__(kRayThreads) void ray_head_bwd_kernel(const float *
     if (rbw < R) dpre0[rbw * 64 + c] = m1b > 0.f ? acc1 : 0.f;
 }
 
+// Weight gradients of per-ray layers, several layers per launch: job j computes dw_j[n][dst + k] += sum_rows dy_j[row][n] x_j[row][k]
+// (x given as one or two column blocks: the virtual concat of a skip connection) and dbias_j[n] += sum_rows dy_j[row][n] (an extra
+// all-ones operand column).  Workgroup (chunk of 256 rows, job) of sixteen waves.  What bounds these launches is memory LATENCY
+// (~2 us per dependent round trip, one workgroup per CU), so the chunk is fetched in two rounds of 128 rows with every load of a
+// round in flight at once (up to 24 per lane, coalesced, branch-free) and parked in LDS; wave (q, t) then accumulates output
+// rows 16t..16t+15 over rows 32q..32q+31 of the round with v_mfma_f32_16x16x4_f32 fed from LDS.  The four row quarters are summed
+// through LDS in a fixed order and the chunk's sums leave with relaxed float atomics (0.2 M at 8192 rows; 64-row chunks were
+// atomic-bound, operands loaded per MFMA step latency-bound).
+constexpr int kWgChunk = 256, kWgRound = 128, kWgThreads = 1024, kDyLd = 72, kXLd = 136;
+struct RayWgradJobs { emer_ray_wgrad_job j[EMER_RAY_WGRAD_MAX_JOBS]; };
+using f32x4r = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+
+__global__ __launch_bounds__(kWgThreads) void ray_wgrad_kernel(const RayWgradJobs jobs, int64_t M) {
+    extern __shared__ float lds_f[];
+    float *dys = lds_f;                       // [128][kDyLd]
+    float *xs = lds_f + kWgRound * kDyLd;     // [128][kXLd]
+    const emer_ray_wgrad_job &J = jobs.j[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, t = wave & 3, q = wave >> 2;
+    const int c = lane & 15, kk = lane >> 4;
+    const int32_t N = J.n, w0 = J.width[0], w1 = J.n_segs > 1 ? J.width[1] : 0, Kx = w0 + w1;
+    const int32_t Kt = Kx + (J.dbias ? 1 : 0);  // operand columns incl. the ones column
+    const int32_t KT = (Kt + 15) >> 4;          // k-tiles in use (<= 8)
+    const bool active = 16 * t < N;              // this wave's output rows exist
+    f32x4r acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4r{0.f, 0.f, 0.f, 0.f};
+    for (int round = 0; round < kWgChunk / kWgRound; ++round) {
+        const int64_t r0 = (int64_t)blockIdx.x * kWgChunk + round * kWgRound;
+        if (r0 >= M) break;
+        // uniform base pointers + 32-bit lane offsets (a 64-bit address per load in flight would not fit the register file);
+        // rows past the end are clamped to the last row and their dy is zeroed, columns past a block's width are clamped and
+        // land in LDS columns whose outputs are never written
+        float vd[8], va[8], vb[8];
+        const float *__restrict__ bdy = J.dy, *__restrict__ bx0 = J.x[0], *__restrict__ bx1 = J.n_segs > 1 ? J.x[1] : J.x[0];
+        const uint32_t ldd = (uint32_t)J.ld_dy, ld0 = (uint32_t)J.ld_x[0], ld1 = (uint32_t)(J.n_segs > 1 ? J.ld_x[1] : J.ld_x[0]);
+        const uint32_t last = (uint32_t)(M - 1 - r0);  // last live row of the round (may exceed 127)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // 128 rows x 64 slots per block
+            const uint32_t i = u * kWgThreads + tid, rr = i >> 6, cc = i & 63;
+            const uint32_t row = (uint32_t)r0 + (rr < last ? rr : last);
+            vd[u] = bdy[row * ldd + (cc < (uint32_t)N ? cc : N - 1)];
+            va[u] = bx0[row * ld0 + (cc < (uint32_t)w0 ? cc : w0 - 1)];
+            if (w1 > 0) vb[u] = bx1[row * ld1 + (cc < (uint32_t)w1 ? cc : w1 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = u * kWgThreads + tid, rr = i >> 6, cc = i & 63;
+            const bool live = rr <= last;
+            dys[rr * kDyLd + cc] = live ? vd[u] : 0.f;
+            if (cc < (uint32_t)w0) xs[rr * kXLd + cc] = va[u];
+            if (w1 > 0 && cc < (uint32_t)w1) xs[rr * kXLd + w0 + cc] = vb[u];
+        }
+        if (tid < kWgRound) xs[tid * kXLd + Kx] = 1.0f;  // the ones column (read only when the job has a bias)
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int s = 0; s < 8; ++s) {  // this wave's 32 rows of the round, 4 per MFMA step
+                const int rr = q * 32 + 4 * s + kk;
+                const float av = dys[rr * kDyLd + 16 * t + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < KT) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xs[rr * kXLd + 16 * j + c], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // quarters 2, 3 -> LDS; quarters 0, 1 add; quarter 1 -> LDS; quarter 0 adds and owns the chunk's sums
+    f32x4r *slot = reinterpret_cast<f32x4r *>(lds_f);  // [8 slots][8 k-tiles][64 lanes]: 64 KiB over the staging area
+    if (q >= 2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[(((q - 2) * 4 + t) * 8 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (q < 2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += slot[((q * 4 + t) * 8 + j) * 64 + lane];
+    __syncthreads();
+    if (q == 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[(t * 8 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (q != 0 || !active) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j >= KT) continue;
+        const f32x4r o = acc[j] + slot[(t * 8 + j) * 64 + lane];
+        const int32_t k = 16 * j + c;  // D layout: row 4 kk + i of the tile, column c
+        if (k >= Kt) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t n = 16 * t + 4 * kk + i;
+            if (n >= N) continue;
+            float *dst;
+            if (k < w0) dst = J.dw + (int64_t)n * J.ld_dw + J.dst_col[0] + k;
+            else if (k < Kx) dst = J.dw + (int64_t)n * J.ld_dw + J.dst_col[1] + (k - w0);
+            else dst = J.dbias + n;
+            __hip_atomic_fetch_add(dst, o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 static inline uint32_t small_blocks(int64_t n) { return (uint32_t)(ceil_div(n, 256) < 4096 ? ceil_div(n, 256) : 4096); }
 
 }  // namespace emer
@@ -393,4 +493,28 @@ extern "C" int emer_ray_head_bwd(const float *dout, const float *out, const floa
     hipLaunchKernelGGL(ray_head_bwd_kernel, dim3((uint32_t)ceil_div(n_rows, kRayTile)), dim3(kRayThreads), 0, as_stream(stream), dout, out, a1, a2, n_rows, w1,
                        ld_w1, w2, n_out, act, dpre2, dpre1, dpre0);
     return check_launch("ray_head_bwd");
+}
+
+extern "C" int emer_ray_wgrad(const emer_ray_wgrad_job *jobs, int32_t n_jobs, int64_t m, void *stream) {
+    EMER_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= EMER_RAY_WGRAD_MAX_JOBS && m >= 0, "ray_wgrad: 1..%d jobs", EMER_RAY_WGRAD_MAX_JOBS);
+    if (m == 0) return EMER_OK;
+    RayWgradJobs J;
+    for (int32_t i = 0; i < n_jobs; ++i) {
+        const emer_ray_wgrad_job &j = jobs[i];
+        EMER_REQUIRE(j.dy && j.dw && j.n >= 1 && j.n <= 64 && j.ld_dy >= j.n && (j.n_segs == 1 || j.n_segs == 2), "ray_wgrad: job %d: n in [1, 64], one or two operand blocks", i);
+        int32_t k = 0;
+        for (int32_t s = 0; s < j.n_segs; ++s) {
+            EMER_REQUIRE(j.x[s] && j.width[s] >= 1 && j.ld_x[s] >= j.width[s] && j.dst_col[s] >= 0 && j.dst_col[s] + j.width[s] <= j.ld_dw,
+                         "ray_wgrad: job %d: operand block %d", i, s);
+            k += j.width[s];
+        }
+        EMER_REQUIRE(k + 1 <= 128 && j.width[0] <= 64 && (j.n_segs == 1 || j.width[1] <= 64), "ray_wgrad: job %d: operand blocks of at most 64 columns, 127 in total", i);
+        EMER_REQUIRE(m * (j.ld_dy > j.ld_x[0] ? j.ld_dy : j.ld_x[0]) < ((int64_t)1 << 31) && (j.n_segs == 1 || m * j.ld_x[1] < ((int64_t)1 << 31)),
+                     "ray_wgrad: job %d: rows * row stride must stay below 2^31", i);
+        J.j[i] = j;
+    }
+    const size_t lds = (size_t)kWgRound * (kDyLd + kXLd) * sizeof(float);  // 104 KiB (the 64 KiB of reduction slots alias it)
+    if (int rc = reserve_lds(reinterpret_cast<const void *>(ray_wgrad_kernel), lds, "ray_wgrad")) return rc;
+    hipLaunchKernelGGL(ray_wgrad_kernel, dim3((uint32_t)ceil_div(m, kWgChunk), (uint32_t)n_jobs), dim3(kWgThreads), lds, as_stream(stream), J, m);
+    return check_launch("ray_wgrad");
 }

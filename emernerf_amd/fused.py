@@ -49,6 +49,28 @@ class ChainDesc(ctypes.Structure):
                 ("n_layers", c_int32), ("buf_cols", c_int32), ("_pad", c_int32)]
 
 
+class RayWgradJob(ctypes.Structure):
+    """emer_ray_wgrad_job of include/emernerf_hip.h."""
+    _fields_ = [("dy", c_void_p), ("ld_dy", c_int64), ("x", c_void_p * 2), ("ld_x", c_int64 * 2), ("dw", c_void_p), ("ld_dw", c_int64),
+                ("dbias", c_void_p), ("n", c_int32), ("n_segs", c_int32), ("width", c_int32 * 2), ("dst_col", c_int32 * 2)]
+
+
+def ray_wgrad(jobs, ref: Tensor) -> None:
+    """Weight gradients of per-ray layers in ONE launch.  jobs: [(dy [M, n], [(x [M, >= width], width, dst_col), ...], dw, dbias | None)]
+    -- dw[:, dst_col : dst_col + width] += dy^T x and dbias += colsum(dy), accumulated into the given tensors."""
+    arr = (RayWgradJob * len(jobs))()
+    M = jobs[0][0].shape[0]
+    for a, (dy, blocks, dw, db) in zip(arr, jobs):
+        assert dy.shape[0] == M and dy.stride(1) == 1 and dw.stride(1) == 1 and 1 <= len(blocks) <= 2
+        a.dy, a.ld_dy, a.n, a.n_segs = dy.data_ptr(), dy.stride(0), dy.shape[1], len(blocks)
+        a.dw, a.ld_dw, a.dbias = dw.data_ptr(), dw.stride(0), (None if db is None else db.data_ptr())
+        for i, (x, width, dst) in enumerate(blocks):
+            assert x.shape[0] == M and x.stride(1) == 1
+            a.x[i], a.ld_x[i], a.width[i], a.dst_col[i] = x.data_ptr(), x.stride(0), width, dst
+    with torch.cuda.device(ref.device):
+        _lib.call("emer_ray_wgrad", arr, len(jobs), M, _stream(ref))
+
+
 def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -501,8 +523,7 @@ class _RgbHeadFn(torch.autograd.Function):
             wgrad(dpre0, [seg(g, 0, NG, ld=g.stride(0), dst_col=Kh)], NG, want_bias=False, out_w=tw0)
             # ... and everything that multiplies the per-ray operand from the per-ray sums of dpre1 / dpre0
             # (8192-row GEMMs; colsum(s) is the bias gradient)
-            wgrad(s1, [seg(hr, 0, Kh, dst_col=H)], Kh, out_w=tw1, out_b=tb1)
-            wgrad(s0, [seg(hr, 0, Kh, dst_col=0)], Kh, out_w=tw0, out_b=tb0)
+            ray_wgrad([(s1, [(hr, Kh, H)], tw1, tb1), (s0, [(hr, Kh, 0)], tw0, tb0)], g)
             dhray = torch.empty((R, Kh), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
                 _lib.call("emer_ray_pre_bwd", _p(s0), _p(s1), H, R, Kh, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dhray), Kh,
@@ -662,9 +683,12 @@ class _SkipMLP3Fn(torch.autograd.Function):
         tb1, rb1 = _target(sb1, (H,), dev)
         tw0, rw0 = _target(sw0, (H, K0), dev)
         tb0, rb0 = _target(sb0, (H,), dev)
-        wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
-        wgrad(dpre1, [seg(a1, 0, H), seg(X, H, K0)], H + K0, out_w=tw1, out_b=tb1)
-        wgrad(dpre0, [seg(X, 0, K0)], K0, out_w=tw0, out_b=tb0)
+        if ctx.fast and N <= 65536:  # per-ray head: all three layers in one launch
+            ray_wgrad([(dpre2, [(a2, H, 0)], tw2, tb2), (dpre1, [(a1, H, 0), (X, K0, H)], tw1, tb1), (dpre0, [(X, K0, 0)], tw0, tb0)], X)
+        else:
+            wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
+            wgrad(dpre1, [seg(a1, 0, H), seg(X, H, K0)], H + K0, out_w=tw1, out_b=tb1)
+            wgrad(dpre0, [seg(X, 0, K0)], K0, out_w=tw0, out_b=tb0)
         return dx, rw0, rb0, rw1, rb1, rw2, rb2, None
 
 

@@ -479,6 +479,26 @@ int emer_ray_head_bwd(const float *dout, const float *out, const float *a1, cons
                       int64_t n_rows, const float *w1, int64_t ld_w1, const float *w2, int32_t n_out,
                       int act, float *dpre2, float *dpre1, float *dpre0, void *stream);
 
+/* Weight gradients of per-ray layers (a few thousand rows), up to EMER_RAY_WGRAD_MAX_JOBS layers per launch -- the three
+ * layers of the sky head, or the per-ray column blocks of the rgb head's layers 0 and 1 (autograd of mlp.py:38-46):
+ *   dw[i][dst_col_s + j] += sum_rows dy[row][i] x_s[row][j]   (s = 0 .. n_segs-1: the column blocks of a virtual concat)
+ *   dbias[i]             += sum_rows dy[row][i]               (dbias may be NULL)
+ * dy [m, n], n <= 64; operand blocks of at most 64 columns, 127 in total; all jobs share m.  Row chunks combine with relaxed float
+ * atomics (summation order not fixed, like emer_wgrad_segmented's reduction). */
+#define EMER_RAY_WGRAD_MAX_JOBS 8
+typedef struct emer_ray_wgrad_job {
+    const float *dy;
+    int64_t ld_dy;
+    const float *x[2];
+    int64_t ld_x[2];
+    float *dw;
+    int64_t ld_dw;
+    float *dbias;
+    int32_t n, n_segs;
+    int32_t width[2], dst_col[2];
+} emer_ray_wgrad_job;
+int emer_ray_wgrad(const emer_ray_wgrad_job *jobs, int32_t n_jobs, int64_t m, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-ray generation (replaces datasets/base/pixel_source.py:39-76 get_rays and
  * :564-731 sample_uniform_rays / sample_important_rays / the gathers of get_train_rays) on device-resident

@@ -791,3 +791,32 @@ def test_ray_pre_matches_fp64(hip_lib, R, Kh, H):
               dh.data_ptr(), Kh, st)
     ref = s0.double() @ W0[:, :Kh].double() + s1.double() @ W1[:, H:H + Kh].double()
     assert (dh.double() - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [8192, 300, 1])
+def test_ray_wgrad_matches_fp64(hip_lib, M):
+    """emer_ray_wgrad: several per-ray layers' weight / bias gradients in one launch, accumulated into column blocks of wider
+    matrices, against fp64 (2e-6 relative to the largest entry: fp32 sums over <= 8192 rows in chunk order)."""
+    from emernerf_amd import fused
+    dev = _dev()
+    g = torch.Generator().manual_seed(M)
+    H, K0, C = 64, 49, 3
+    a1, a2, x = (torch.randn(M, w, generator=g).to(dev) for w in (H, H, K0))
+    d2, d1, d0 = (torch.randn(M, w, generator=g).to(dev) for w in (C, H, H))
+    wide = torch.randn(M, 200, generator=g).to(dev)  # a strided operand (columns 7..56 of a wider tensor)
+    xs = wide[:, 7:7 + K0]
+    dw2, dw1, dw0 = torch.ones(C, H, device=dev), torch.ones(H, H + K0 + 10, device=dev), torch.ones(H, K0, device=dev)
+    db2, db1 = torch.ones(C, device=dev), torch.ones(H, device=dev)
+    fused.ray_wgrad([(d2, [(a2, H, 0)], dw2, db2), (d1, [(a1, H, 0), (xs, K0, H + 10)], dw1, db1), (d0, [(x, K0, 0)], dw0, None)], x)
+
+    def chk(got, want):
+        assert (got.double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+
+    chk(dw2, 1.0 + d2.double().T @ a2.double())
+    chk(db2, 1.0 + d2.double().sum(0))
+    want1 = torch.ones(H, H + K0 + 10, dtype=torch.float64, device=dev)
+    want1[:, :H] += d1.double().T @ a1.double()
+    want1[:, H + 10:] += d1.double().T @ xs.double()
+    chk(dw1, want1)  # columns H .. H+10 untouched
+    chk(db1, 1.0 + d1.double().sum(0))
+    chk(dw0, 1.0 + d0.double().T @ x.double())
