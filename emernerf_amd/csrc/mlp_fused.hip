@@ -393,6 +393,70 @@ __global__ __launch_bounds__(kNThreads, 4) void neck_fwd_kernel(const NeckFwdArg
     }
 }
 
+// Density MLP of a proposal network when its input is narrow (L * F <= 16; the reference's proposal grids are L8 / F1):
+// the first layer has only two (.. four) k-steps of the fp32 matrix instruction, which is cheaper than six bf16 products of a
+// K = 32 step that is three quarters padding (8 x 32 cycles against 24 x 20 per 16 rows), needs no operand split, and takes the
+// encoding in its own layout: lane (m, g) reads features 4 s + g of row m.  W0 / b0 / W1 live in registers.  The launch is
+// latency-bound (one wave processes 16 tiles), so a chunk's eight tiles are loaded with all loads in flight (branch-free:
+// clamped row and feature; the weight of a padded feature is zero) before any is consumed.
+template <int KS4>
+__global__ __launch_bounds__(kNThreads, 4) void density_fwd_kernel(const NeckFwdArgs a, int32_t F) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const int32_t K0 = a.w0.k;
+    float aw[4][KS4];
+    int64_t koff[KS4];  // element offset of feature 4 s + g inside the level-major encoding, without the row
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+        const int32_t k = 4 * s + g, kc = k < K0 ? k : K0 - 1;
+        koff[s] = (int64_t)(kc / F) * a.n * F + kc % F;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) aw[p][s] = k < K0 ? a.w0.w[(int64_t)(16 * p + m) * a.w0.sn + (int64_t)k * a.w0.sk] : 0.0f;
+    }
+    f32x4 b0r[4], w1r[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b0r[p][i] = a.b0 ? a.b0[16 * p + 4 * g + i] : 0.0f;
+            w1r[p][i] = a.w1.w[(int64_t)(16 * p + 4 * g + i) * a.w1.sk];
+        }
+    const float b1 = a.b1 ? a.b1[0] : 0.0f;
+    const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t t0 = c * kNeckChunk;
+        float x[kNeckChunk][KS4];
+#pragma unroll
+        for (int j = 0; j < kNeckChunk; ++j) {
+            const int64_t row = (t0 + j) * 16 + m, rc = row < a.n ? row : a.n - 1;
+#pragma unroll
+            for (int s = 0; s < KS4; ++s) x[j][s] = a.enc[koff[s] + rc * F];
+        }
+#pragma unroll
+        for (int j = 0; j < kNeckChunk; ++j) {
+            if (t0 + j >= n_tiles) break;
+            const int64_t row = (t0 + j) * 16 + m;
+            const bool ok = row < a.n;
+            f32x4 h[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = b0r[p];
+#pragma unroll
+            for (int s = 0; s < KS4; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) h[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[p][s], x[j][s], h[p], 0, 0, 0);
+            relu<4>(h);
+            if (a.h1) st_rm<4>(a.h1 + row * 64, ok, g, h);
+            float dot = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dot = fmaf(w1r[p][i], h[p][i], dot);
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            if (ok && g == 0) a.dens[row] = expf(dot + b1 - 1.0f);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- neck backward
 struct NeckBwdArgs {
     const float *d0;     // [n][64] gradient of output features 0..63 (null: zero)
@@ -761,6 +825,7 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
         const int64_t row0 = ray * tpr * 16;
         const float *geo = a.geo + row0 * a.ld_geo;
         float *a1 = a.a1 + row0 * 64, *a2 = a.a2 + row0 * 64, *outp = a.out + row0 * 3;
+        const bool keep = a.a1 != nullptr;  // inference: the hidden activations are not stored (2/3 of the kernel's bytes)
         for (int j = 0; j < tpr; ++j) {
             f32x4 x[4];
 #pragma unroll
@@ -772,8 +837,9 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
             for (int p = 0; p < 4; ++p) h[p] = *reinterpret_cast<const f32x4 *>(rb0 + 16 * p);
             tgemm<2, 4, false>(w0p, xo, h);
             relu<4>(h);
+            if (keep)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a1 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h[p];
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a1 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h[p];
             f32x4 h2[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) h2[p] = *reinterpret_cast<const f32x4 *>(rb1 + 16 * p);
@@ -782,8 +848,9 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
             make_opd<4>(h, ho);
             tgemm<2, 4, false>(w1ap, ho, h2);
             relu<4>(h2);
+            if (keep)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
             make_opd<4>(h2, ho);
             f32x4 o[1];
             init_bias<1>(b2l, g, o);
@@ -1125,7 +1192,13 @@ extern "C" int emer_neck_fwd(const float *enc_lm, int32_t n_levels, int32_t n_fe
     a.b0 = b0; a.b1 = b1; a.h1 = h1; a.out0 = out0; a.out1 = out1; a.dens = dens;
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
-    if (n_out == 1) {
+    if (n_out == 1 && k0 <= 16) {  // narrow input (the proposal networks): fp32 matrix instruction, weights in registers
+        const int ks4 = (k0 + 3) / 4;
+#define EMER_DENS(KS) hipLaunchKernelGGL(density_fwd_kernel<KS>, dim3(grid), dim3(kNThreads), 0, st, a, n_feat)
+        if (ks4 == 1) EMER_DENS(1); else if (ks4 == 2) EMER_DENS(2); else if (ks4 == 3) EMER_DENS(3); else EMER_DENS(4);
+#undef EMER_DENS
+        return check_launch("neck_fwd");
+    } else if (n_out == 1) {
         auto lds = [](int kt0) { return (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(1, 2)) * 16 + (64 + 16 + 64) * sizeof(float); };
         EMER_NECK_DISPATCH(neck_fwd_kernel, 1, a, lds, "neck_fwd");
     } else if (n_out == 64) {
@@ -1245,7 +1318,7 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
                                  const float *b2, float *a1, float *a2, float *out, void *stream) {
     EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "rgb_head_fwd: bad sizes (S must be a multiple of 16)");
     if (n_rays == 0) return EMER_OK;
-    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && a1 && a2 && out && ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_rb % 4 == 0,
+    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && (a1 != nullptr) == (a2 != nullptr) && out && ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_rb % 4 == 0,
                  "rgb_head_fwd: bad arguments");
     RgbFwdArgs a;
     a.geo = geo; a.ld_geo = ld_geo; a.rb0 = rb0; a.rb1 = rb1; a.ld_rb = ld_rb; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;

@@ -71,6 +71,17 @@ def ray_wgrad(jobs, ref: Tensor) -> None:
         _lib.call("emer_ray_wgrad", arr, len(jobs), M, _stream(ref))
 
 
+def _ng(*args):
+    """Arguments for a Function.apply call outside autograd recording (torch.no_grad, set_grad_enabled(False): evaluation,
+    the proposal sampling of the steps that do not train the proposal nets).  A Function's forward still sees
+    needs_input_grad == requires_grad of its inputs there (and torch.is_grad_enabled() is False inside EVERY forward), so
+    the inputs are detached here: the forwards then skip what only a backward needs -- hidden activations (256 B per sample),
+    the grid backward's bitmaps -- instead of writing it for nobody."""
+    if torch.is_grad_enabled():
+        return args
+    return tuple(a.detach() if isinstance(a, Tensor) else a for a in args)
+
+
 def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -287,7 +298,7 @@ class _BaseMLPFn(torch.autograd.Function):
 
 def base_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tuple[Tensor, Tensor]:
     """(feats [N, NG], density [N]) from the level-major grid encoding [L, N, F]."""
-    return _BaseMLPFn.apply(enc_lm, w0, b0, w1, b1)
+    return _BaseMLPFn.apply(*_ng(enc_lm, w0, b0, w1, b1))
 
 
 
@@ -373,7 +384,7 @@ class _NeckFn(torch.autograd.Function):
 def neck(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
     """Register-resident neck: returns (feats[:, :64], feats[:, 64:128] or None, density [N]).  Requires
     ``neck_supported(L, F, hidden, n_out)`` with n_out in (64, 128)."""
-    r = _NeckFn.apply(enc_lm, w0, b0, w1, b1)
+    r = _NeckFn.apply(*_ng(enc_lm, w0, b0, w1, b1))
     return (r[0], None, r[1]) if len(r) == 2 else r
 
 
@@ -441,7 +452,7 @@ class _DensityMLPFn(torch.autograd.Function):
 
 def density_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
     """trunc_exp(Linear(ReLU(Linear(enc))) - 1) -> [N]."""
-    return _DensityMLPFn.apply(enc_lm, w0, b0, w1, b1)
+    return _DensityMLPFn.apply(*_ng(enc_lm, w0, b0, w1, b1))
 
 
 # ------------------------------------------------------------------------------------------ rgb head
@@ -458,8 +469,10 @@ class _RgbHeadFn(torch.autograd.Function):
         H, K0, C = W0.shape[0], Kh + NG, W2.shape[0]
         assert W0.shape[1] == K0 and W1.shape[1] == H + K0 and W2.shape[1] == H
         dev = g.device
-        a1 = torch.empty((N, H), device=dev, dtype=torch.float32)
-        a2 = torch.empty((N, H), device=dev, dtype=torch.float32)
+        keep = any(ctx.needs_input_grad)  # inference (inputs detached by rgb_head): the fast kernel stores no activations
+        fast = (H == 64 and NG == 64 and C == 3 and Kh <= 64 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
+        a1 = torch.empty((N, H), device=dev, dtype=torch.float32) if (keep or not fast) else None
+        a2 = torch.empty((N, H), device=dev, dtype=torch.float32) if (keep or not fast) else None
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
         ctx.S = S
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
@@ -552,7 +565,7 @@ class _RgbHeadFn(torch.autograd.Function):
 
 def rgb_head(hray: Tensor, geo: Tensor, samples_per_ray: int, w0, b0, w1, b1, w2, b2) -> Tensor:
     """sigmoid(MLP3-skip1([hray[ray] | geo])) -> [N, 3]; hray [R, Kh] per ray, geo [N, NG] per sample."""
-    return _RgbHeadFn.apply(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2)
+    return _RgbHeadFn.apply(*_ng(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2))
 
 
 # ------------------------------------------------------------------------------------------ per-ray inputs
@@ -604,7 +617,7 @@ class _RayInputsFn(torch.autograd.Function):
 
 def ray_inputs(emb_weight: Tensor, idx: Tensor, dirs: Tensor, max_deg: int):
     """(rgb-head rows, sky-head rows), each [R, PE + emb_dim], for per-ray directions [R, 3] and embedding indices [R]."""
-    return _RayInputsFn.apply(emb_weight, idx, dirs, max_deg)
+    return _RayInputsFn.apply(*_ng(emb_weight, idx, dirs, max_deg))
 
 
 # ------------------------------------------------------------------------- 3-layer skip MLP on row-major input
@@ -695,7 +708,7 @@ class _SkipMLP3Fn(torch.autograd.Function):
 def skip_mlp3(x: Tensor, w0, b0, w1, b1, w2, b2, final_act: int = ACT_SIGMOID) -> Tensor:
     """final_act(MLP3-skip1(x)) for x [rows, K0]; final_act ACT_SIGMOID or ACT_NONE."""
     assert final_act in (ACT_SIGMOID, ACT_NONE)
-    return _SkipMLP3Fn.apply(x, w0, b0, w1, b1, w2, b2, final_act)
+    return _SkipMLP3Fn.apply(*_ng(x, w0, b0, w1, b1, w2, b2, final_act))
 
 
 # ----------------------------------------------------------------- plain nn.Sequential heads (shadow / flow / dino)
@@ -861,8 +874,8 @@ def seq_mlp(x: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:
     assert final_act in (ACT_NONE, ACT_SIGMOID)
     wb = [t for pair in zip(weights, biases) for t in pair]
     if x.shape[-1] % 4 == 0 and rmlp_supported(weights, x.shape[-1], 0):
-        return _RMlpFn.apply(x, False, final_act, *wb)
-    return _SeqMLPFn.apply(x, final_act, *wb)
+        return _RMlpFn.apply(*_ng(x, False, final_act, *wb))
+    return _SeqMLPFn.apply(*_ng(x, final_act, *wb))
 
 
 def seq_mlp_lm(enc_lm: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:
@@ -870,4 +883,4 @@ def seq_mlp_lm(enc_lm: Tensor, weights, biases, final_act: int = ACT_NONE) -> Te
     comes back level-major for the grid backward).  Requires ``rmlp_supported(weights, L * F, F)``."""
     assert final_act in (ACT_NONE, ACT_SIGMOID)
     wb = [t for pair in zip(weights, biases) for t in pair]
-    return _RMlpFn.apply(enc_lm, True, final_act, *wb)
+    return _RMlpFn.apply(*_ng(enc_lm, True, final_act, *wb))

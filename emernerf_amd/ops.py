@@ -31,6 +31,14 @@ def _check_cuda(*ts: Tensor):
             raise _lib.EmerError("emernerf_amd ops need GPU (HIP) tensors; there is no CPU fallback")
 
 
+def _ng(*args):
+    """Outside autograd recording the inputs of a Function.apply call are detached, so that its forward does not prepare a
+    backward nobody will run (see fused._ng)."""
+    if torch.is_grad_enabled():
+        return args
+    return tuple(a.detach() if isinstance(a, Tensor) else a for a in args)
+
+
 def _f32c(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -301,12 +309,12 @@ class _HashGridLMFn(torch.autograd.Function):
 def hashgrid_encode_lm(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None, table_dtype=None, skip_dx_rows: int = 0) -> Tensor:
     """x [N,D] in [0,1] -> level-major [L, N, F] fp32, differentiable w.r.t. params and x (see _HashGridLMFn for
     ``table_dtype`` / ``skip_dx_rows``)."""
-    return _HashGridLMFn.apply(x, params, desc, grad_dtype, table_dtype, skip_dx_rows)
+    return _HashGridLMFn.apply(*_ng(x, params, desc, grad_dtype, table_dtype, skip_dx_rows))
 
 
 def hashgrid_encode(x: Tensor, params: Tensor, desc: GridDesc, grad_dtype=None) -> Tensor:
     """x [N,D] in [0,1] -> [N, L*F] fp32, differentiable w.r.t. params and x."""
-    return _HashGridFn.apply(x, params, desc, grad_dtype)
+    return _HashGridFn.apply(*_ng(x, params, desc, grad_dtype))
 
 
 # ------------------------------------------------------------------------------ contraction

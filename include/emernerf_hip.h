@@ -414,7 +414,8 @@ int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float 
  * pre-activations rb0 = hray W0[:, :kh]^T + b0 and rb1 = hray W1[:, 64:64+kh]^T + b1 ([rays][64], row stride ld_rb); the kernel
  * does the per-sample part: a1 = relu(geo W0[:, kh:]^T + rb0), a2 = relu(a1 W1[:, :64]^T + geo W1[:, 64+kh:]^T
  * + rb1), out = sigmoid(a2 W2^T + b2).  w0 [64][kh+64], w1 [64][64+kh+64], w2 [3][64] are the torch Linear
- * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward. */
+ * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward (both NULL:
+ * inference, nothing is stored). */
 int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
                       const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);

@@ -304,3 +304,27 @@ def test_seq_mlp_routes_to_register_resident_kernels(hip_lib):
     assert fused.rmlp_supported(mk(64, 64, 64, 64), 64, 0)     # feature heads
     assert fused.rmlp_supported(mk(40, 64, 64, 6), 40, 4)      # flow MLP on the xyzt grid (L10 x F4)
     assert not fused.rmlp_supported(mk(43, 32, 5), 43, 0)
+
+
+def test_forwards_outside_autograd_recording_match(hip_lib):
+    """Under torch.no_grad() the heads detach their inputs and skip what only a backward needs (hidden activations, the grid
+    backward's bitmaps); the values must be bit-identical to the recorded forward."""
+    from emernerf_amd import fused, ops, _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    R, S, Kh, H = 64, 32, 49, 64
+    hr, geo = torch.randn(R, Kh, generator=g).to(dev), torch.randn(R * S, H, generator=g).to(dev)
+    ws = [torch.randn(H, Kh + H, generator=g) / 10, torch.randn(H, generator=g) / 10, torch.randn(H, H + Kh + H, generator=g) / 12,
+          torch.randn(H, generator=g) / 10, torch.randn(3, H, generator=g) / 8, torch.randn(3, generator=g) / 10]
+    ws = [w.to(dev).requires_grad_(True) for w in ws]
+    want = fused.rgb_head(hr, geo, S, *ws)
+    with torch.no_grad():
+        got = fused.rgb_head(hr, geo, S, *ws)
+    assert torch.equal(want, got) and not got.requires_grad
+    enc = torch.randn(8, R * S, 1, generator=g).to(dev)
+    dw = [torch.randn(H, 8, generator=g) / 3, torch.randn(H, generator=g) / 10, torch.randn(1, H, generator=g) / 8, torch.randn(1, generator=g) / 10]
+    dw = [w.to(dev).requires_grad_(True) for w in dw]
+    want = fused.density_mlp(enc, *dw)
+    with torch.no_grad():
+        got = fused.density_mlp(enc, *dw)
+    assert torch.equal(want, got) and not got.requires_grad
