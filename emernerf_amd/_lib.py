@@ -82,7 +82,7 @@ SIGNATURES = {
     "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rgb_head_fwd": [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
-    "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
@@ -104,6 +104,7 @@ SIGNATURES = {
 INT64_FUNCTIONS = {
     "emer_linear_bwd_workspace": [c_int64, c_int32, c_int32],
     "emer_neck_bwd_fused_workspace": [c_int32, c_int32, c_int64, c_int32],
+    "emer_rgb_head_bwd_workspace": [c_int64],
 }
 
 ALLOW_MISSING_SYMBOLS = False  # never set by the product path

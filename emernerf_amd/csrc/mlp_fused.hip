@@ -873,6 +873,7 @@ struct RgbBwdArgs {
     float *dpre2;                      // [n][3]
     float *dpre1, *dpre0, *dgeo;       // [n][64]
     float *s1, *s0;                    // [rays][64] sums of dpre1 / dpre0 over the samples of each ray
+    float *w2part;                     // [workgroups][196] partial (dW2 [3][64] | db2 [3]) per workgroup, or null: not computed here
 };
 
 template <int CTRL>
@@ -885,6 +886,25 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     v += dpp_mov<0x141>(v);  // row_half_mirror: quad q <-> quad q ^ 1
     v += dpp_mov<0x140>(v);  // row_mirror: lower eight <-> upper eight
     return v;
+}
+
+// Sum over the 16 lanes of a DPP row of SIXTEEN quantities at once, lane m ending with the total of quantity m ("reduce-scatter":
+// 8 + 4 + 2 + 1 exchange steps instead of 16 x 4).  Partners: m ^ 8 (row_ror:8), m ^ 7 (row_half_mirror), m ^ 2, m ^ 1 (quad
+// permutes); at each step a lane keeps the half of its quantities whose index bit equals its own lane bit and sends the other.
+// The quantities are scale * e[p][i] (index 4 p + i), formed inside the first step so that no 16-entry product array is ever live.
+__device__ __forceinline__ float row16_reduce_scatter(const f32x4 (&e)[4], float scale, int m) {
+    const bool b3 = m & 8, b2 = m & 4, b1 = m & 2, b0 = m & 1;
+    float r1[8], r2[4], r3[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float lo = e[j >> 2][j & 3], hi = e[2 + (j >> 2)][j & 3];  // quantities j and 8 + j
+        r1[j] = scale * (b3 ? hi : lo) + dpp_mov<0x128>(scale * (b3 ? lo : hi));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r2[j] = (b2 ? r1[4 + j] : r1[j]) + dpp_mov<0x141>(b2 ? r1[j] : r1[4 + j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r3[j] = (b1 ? r2[2 + j] : r2[j]) + dpp_mov<0x4E>(b1 ? r2[j] : r2[2 + j]);
+    return (b0 ? r3[1] : r3[0]) + dpp_mov<0xB1>(b0 ? r3[0] : r3[1]);
 }
 
 __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs a) {
@@ -904,6 +924,9 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
     for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
     const int tpr = a.tiles_per_ray;
     const unsigned lo64 = (unsigned)(m * 64 + 4 * g), lo3 = (unsigned)(3 * m + g);
+    // dW2 / db2 ride along (a.w2part): lane (m, g) owns dW2[c][16 (m >> 2) + 4 g + (m & 3)] for the three channels c and, for
+    // g < 3, its rows' share of db2[g] -- three + one accumulators for the whole kernel instead of a 280 MB pass over a2.
+    float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
     for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         f32x4 s1[4], s0[4];
         zero<4>(s1); zero<4>(s0);
@@ -918,16 +941,23 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
                 d2 = doutp[o3] * y * (1.0f - y);  // sigmoid'
                 dpre2[o3] = d2;
             }
+            f32x4 m2[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) m2[p] = *reinterpret_cast<const f32x4 *>(a2 + (o64 + 16u * p));
+            if (a.w2part) {  // wave-uniform; before d1 exists: only the mask, the ray sums and d2 are live here
+                b2acc += d2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dc = __shfl(d2, 16 * c + m, 64);  // channel c of this lane's row
+                    w2acc[c] += row16_reduce_scatter(m2, dc, m);
+                    __builtin_amdgcn_sched_barrier(0);  // one channel at a time
+                }
+            }
             f32x4 d1[4];
             zero<4>(d1);
 #pragma unroll
             for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
-            {
-                f32x4 m2[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) m2[p] = *reinterpret_cast<const f32x4 *>(a2 + (o64 + 16u * p));
-                relu_mask<4>(d1, m2);
-            }
+            relu_mask<4>(d1, m2);
 #pragma unroll
             for (int p = 0; p < 4; ++p) { *reinterpret_cast<f32x4 *>(dpre1 + (o64 + 16u * p)) = d1[p]; s1[p] += d1[p]; }
             Opd<2> d1o;
@@ -958,6 +988,21 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
         if (m == 0) {
             st_rm<4>(a.s1 + ray * 64, true, g, s1);
             st_rm<4>(a.s0 + ray * 64, true, g, s0);
+        }
+    }
+    if (a.w2part) {  // the eight waves' sums through LDS (the weights are dead), one 196-float partial per workgroup
+        __syncthreads();
+        float *part = reinterpret_cast<float *>(smem);
+        const int nw = (int)(blockDim.x >> 6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[wave * 196 + c * 64 + 16 * (m >> 2) + 4 * g + (m & 3)] = w2acc[c];
+        b2acc = row16_sum(b2acc);
+        if (m == 0 && g < 3) part[wave * 196 + 192 + g] = b2acc;
+        __syncthreads();
+        if ((int)threadIdx.x < 195) {
+            float t = 0.0f;
+            for (int w = 0; w < nw; ++w) t += part[w * 196 + threadIdx.x];
+            a.w2part[(int64_t)blockIdx.x * 196 + threadIdx.x] = t;
         }
     }
 }
@@ -1338,10 +1383,12 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
 // [rays][64] of dpre1 / dpre0 (everything the per-ray operands hray, W0h, W1h, b0, b1 need).
 extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const float *a1, const float *a2, int64_t n_rays,
                                  int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1, const float *w2,
-                                 float *dpre2, float *dpre1, float *dpre0, float *dgeo, float *s1, float *s0, void *stream) {
+                                 float *dpre2, float *dpre1, float *dpre0, float *dgeo, float *s1, float *s0, float *workspace,
+                                 float *dw2, int64_t ld_dw2, float *db2, void *stream) {
     EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "rgb_head_bwd: bad sizes (S must be a multiple of 16)");
     if (n_rays == 0) return EMER_OK;
     EMER_REQUIRE(dout && out && a1 && a2 && w0 && w1 && w2 && dpre2 && dpre1 && dpre0 && dgeo && s1 && s0, "rgb_head_bwd: null pointer");
+    EMER_REQUIRE(!dw2 || (workspace && ld_dw2 >= 64), "rgb_head_bwd: dw2 needs emer_rgb_head_bwd_workspace floats of workspace and ld_dw2 >= 64");
     RgbBwdArgs a;
     a.dout = dout; a.out = out; a.a1 = a1; a.a2 = a2; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
     const int64_t k0 = kh + 64, k1 = 64 + k0;
@@ -1350,10 +1397,19 @@ extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const floa
     a.w1gt = WSrc{w1 + 64 + kh, 1, k1, 64, 64};
     a.w0gt = WSrc{w0 + kh, 1, k0, 64, 64};
     a.dpre2 = dpre2; a.dpre1 = dpre1; a.dpre0 = dpre0; a.dgeo = dgeo; a.s1 = s1; a.s0 = s0;
+    a.w2part = dw2 ? workspace : nullptr;
     const size_t lds = (size_t)(3 * w3_units(4, 2)) * 16;
     if (int rc = set_lds(rgb_bwd_kernel, lds, "rgb_head_bwd")) return rc;
-    hipLaunchKernelGGL(rgb_bwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
-    return check_launch("rgb_head_bwd");
+    const uint32_t grid = fused_grid(n_rays, kNThreads);
+    hipLaunchKernelGGL(rgb_bwd_kernel, dim3(grid), dim3(kNThreads), lds, as_stream(stream), a);
+    if (int rc = check_launch("rgb_head_bwd")) return rc;
+    if (dw2) return launch_dw_reduce(workspace, (int32_t)grid, 196, 3, 64, dw2, ld_dw2, db2, as_stream(stream));
+    return EMER_OK;
+}
+
+// floats of workspace emer_rgb_head_bwd needs when it also produces dw2 / db2
+extern "C" int64_t emer_rgb_head_bwd_workspace(int64_t n_rays) {
+    return n_rays <= 0 ? 0 : (int64_t)fused_grid(n_rays, kNThreads) * 196;
 }
 
 // ---- plain 2- / 3-layer heads -------------------------------------------------------------------------------------

@@ -520,9 +520,6 @@ class _RgbHeadFn(torch.autograd.Function):
             dgeo = torch.empty((N, NG), device=dev, dtype=torch.float32)
             s1 = torch.empty((R, H), device=dev, dtype=torch.float32)
             s0 = torch.empty((R, H), device=dev, dtype=torch.float32)
-            with torch.cuda.device(dev):
-                _lib.call("emer_rgb_head_bwd", _p(_c(dout)), _p(out), _p(a1), _p(a2), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(dpre2),
-                          _p(dpre1), _p(dpre0), _p(dgeo), _p(s1), _p(s0), _stream(g))
             sw0, sb0, sw1, sb1, sw2, sb2 = ctx.sinks
             tw2, rw2 = _target(sw2, (C, H), dev)
             tb2, rb2 = _target(sb2, (C,), dev)
@@ -530,7 +527,15 @@ class _RgbHeadFn(torch.autograd.Function):
             tb1, rb1 = _target(sb1, (H,), dev)
             tw0, rw0 = _target(sw0, (H, K0), dev)
             tb0, rb0 = _target(sb0, (H,), dev)
-            wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
+            with torch.cuda.device(dev):
+                # the output layer's weight gradient (3 x 64 + 3 numbers) rides along in the backward kernel, where a2 and
+                # dpre2 are in registers: a separate pass would re-read 280 MB for it
+                ws = torch.empty((int(_lib.load().emer_rgb_head_bwd_workspace(R)),), device=dev, dtype=torch.float32) if FUSED_WGRAD else None
+                _lib.call("emer_rgb_head_bwd", _p(_c(dout)), _p(out), _p(a1), _p(a2), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(dpre2),
+                          _p(dpre1), _p(dpre0), _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw2) if FUSED_WGRAD else None, tw2.stride(0),
+                          _p(tb2) if FUSED_WGRAD else None, _stream(g))
+            if not FUSED_WGRAD:
+                wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
             # per-sample column blocks [A1 | . | geo] of dW1 and [. | geo] of dW0 ...
             wgrad(dpre1, [seg(a1, 0, H, dst_col=0), seg(g, H, NG, ld=g.stride(0), dst_col=H + Kh)], H + NG, want_bias=False, out_w=tw1)
             wgrad(dpre0, [seg(g, 0, NG, ld=g.stride(0), dst_col=Kh)], NG, want_bias=False, out_w=tw0)

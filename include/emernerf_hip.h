@@ -421,11 +421,15 @@ int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const 
                       const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);
 /* Data gradients: dpre2 [n][3] = dout * out * (1 - out), dpre1 / dpre0 [n][64] (pre-activation gradients of
  * layers 1 / 0, the wgrad operands), dgeo [n][64], and s1 / s0 [rays][64] = sums of dpre1 / dpre0 over the
- * samples of each ray (all that hray, W0[:, :kh], W1[:, 64:64+kh], b0 and b1 need). */
+ * samples of each ray (all that hray, W0[:, :kh], W1[:, 64:64+kh], b0 and b1 need).
+ * dw2 (may be NULL) [3][ld_dw2 >= 64] += dpre2^T a2 and db2 (may be NULL) [3] += column sums of dpre2: the output layer's
+ * weight gradient rides along (a2 and dpre2 are in registers here; a separate pass would re-read 280 MB for 195 numbers);
+ * needs emer_rgb_head_bwd_workspace(n_rays) floats of workspace. */
+int64_t emer_rgb_head_bwd_workspace(int64_t n_rays);
 int emer_rgb_head_bwd(const float *dout, const float *out, const float *a1, const float *a2, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
                       const float *w2, float *dpre2, float *dpre1, float *dpre0, float *dgeo, float *s1,
-                      float *s0, void *stream);
+                      float *s0, float *workspace, float *dw2, int64_t ld_dw2, float *db2, void *stream);
 
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */

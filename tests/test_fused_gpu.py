@@ -103,9 +103,11 @@ def test_density_mlp(hip_lib, L, N):
         _close("density_nograd", fused.density_mlp(*[v.detach() for v in t]), d_ref)
 
 
-@pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64)])
-def test_rgb_head(hip_lib, R, S, Kh, NG, ld):
+@pytest.mark.parametrize("fusedw", [True, False])  # output layer's weight gradient inside the backward kernel / separate pass
+@pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64), (5000, 16, 49, 64, 64)])
+def test_rgb_head(hip_lib, monkeypatch, R, S, Kh, NG, ld, fusedw):
     from emernerf_amd import fused
+    monkeypatch.setattr(fused, "FUSED_WGRAD", fusedw)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(R * S + Kh)
     N, H, K0 = R * S, 64, Kh + NG
