@@ -491,9 +491,9 @@ class Trainer:
         if self._static_data is None:
             self._static_data = {k: v.clone() for k, v in data.items()}
         elif data is not self._static_data:
-            for k, v in data.items():
-                if v.data_ptr() != self._static_data[k].data_ptr():
-                    self._static_data[k].copy_(v)
+            pairs = [(self._static_data[k], v) for k, v in data.items() if v.data_ptr() != self._static_data[k].data_ptr()]
+            if pairs:  # one multi-tensor launch per dtype instead of one copy per tensor
+                torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
         sd = self._static_data
         if prop_grad not in self._graphs:
             self._hold_buckets = True  # the warm-up passes and the capture must not start gradient collectives

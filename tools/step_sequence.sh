@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/seq; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/seq
-timeout 300 rocprofv3 --kernel-trace -d /tmp/seq -o s --output-format csv -- python $R/bench.py --eager --no-cpu-baseline --no-extras --no-second-state --no-secondary --no-fp16-state --steps 6 --warmup 2 > $OUT/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace -d /tmp/seq -o s --output-format csv -- python $R/bench.py ${KIND:+--kind $KIND} --eager --no-cpu-baseline --no-extras --no-second-state --no-secondary --no-fp16-state --steps 6 --warmup 2 > $OUT/log.txt 2>&1
 python - <<'P' > $OUT/sequence.txt
 import csv, glob
 f = glob.glob('/tmp/seq/**/*kernel_trace.csv', recursive=True)[0]
