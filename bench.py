@@ -300,7 +300,8 @@ def main():
                               "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd",
                               "emer_rmlp_fwd", "emer_rmlp_bwd", "emer_contract_bwd", "emer_blend_accumulate_fwd", "emer_blend_accumulate_bwd",
                               "emer_prop_loss", "emer_ray_epilogue_fwd", "emer_ray_epilogue_bwd", "emer_pixel_loss_fwd", "emer_pixel_loss_bwd",
-                              "emer_trunc_exp_fwd", "emer_trunc_exp_bwd"]
+                              "emer_trunc_exp_fwd", "emer_trunc_exp_bwd", "emer_ray_inputs_fwd", "emer_embed_grad", "emer_ray_pre_fwd",
+                              "emer_ray_pre_bwd", "emer_ray_head_fwd", "emer_ray_head_bwd", "emer_ray_wgrad", "emer_lidar_loss"]
     # (graph replay launches no kernel from Python, so there is nothing to bracket inside the timed region: with --graph
     # the roofline kernels are timed in the eager instrumented pass below instead)
     timer = _lib.KernelTimer(grid_names) if (rank == 0 and not args.graph) else None

@@ -55,3 +55,15 @@ timeit("ray_head_bwd", lambda: _lib.call("emer_ray_head_bwd", dout.data_ptr(), o
                                          _lib.ACT_SIGMOID, d2.data_ptr(), d1.data_ptr(), d0.data_ptr(), st()))
 x = torch.empty(1 << 20, device=dev)
 timeit("torch fill 4 MB (launch floor reference)", lambda: x.fill_(1.0))
+
+# emer_ray_wgrad: per-job cost and scaling with the row count (one workgroup per 256-row chunk and job)
+from emernerf_amd import fused
+C = 3
+for M in (64, 2048, 8192):
+    a1, a2, x = (torch.randn(M, w, device=dev) for w in (H, H, Kh))
+    e2, e1, e0 = (torch.randn(M, w, device=dev) for w in (C, H, H))
+    dw2, dw1, dw0 = torch.zeros(C, H, device=dev), torch.zeros(H, H + Kh, device=dev), torch.zeros(H, Kh, device=dev)
+    db2, db1, db0 = torch.zeros(C, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    timeit(f"ray_wgrad M={M}: sky head, 3 jobs", lambda: fused.ray_wgrad([(e2, [(a2, H, 0)], dw2, db2), (e1, [(a1, H, 0), (x, Kh, H)], dw1, db1),
+                                                                       (e0, [(x, Kh, 0)], dw0, db0)], x))
+    timeit(f"ray_wgrad M={M}: 64 x 114 job alone", lambda: fused.ray_wgrad([(e1, [(a1, H, 0), (x, Kh, H)], dw1, db1)], x))
