@@ -82,6 +82,8 @@ SIGNATURES = {
     "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rgb_head_fwd": [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "emer_field_fwd_supported": [c_int32, c_int32],
+    "emer_field_fwd": [_P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],

@@ -864,6 +864,103 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
     }
 }
 
+// ------------------------------------------------------------------------------ neck + rgb head in one forward kernel
+// The static field of a colour query: level-major grid encoding -> neck (geometry features, density) -> rgb head, a wave
+// keeping its 16 rows in registers from the encoding to the colour.  Same arithmetic, instruction for instruction, as
+// neck_fwd_kernel followed by rgb_fwd_kernel; what it saves is the rgb head's read of the 256 B / sample geometry features
+// (they are still WRITTEN once: the backward needs them) and a launch.  The weights of both stages (114-126 KB) leave room for
+// one workgroup per CU, so the workgroup is 1024 lanes = the same four waves per SIMD as the separate kernels.
+constexpr int kFieldThreads = 1024;
+struct FieldFwdArgs {
+    const float *enc; int64_t n; int32_t n_levels;   // [L][n][F], n = n_rays * samples_per_ray
+    WSrc nw0, nw1; const float *nb0, *nb1;           // neck: W0 [64][L F], W1 [64][64]
+    float *geo;                                      // [n][64]
+    float *dens;                                     // [n] exp(feature 0 - 1)
+    RgbFwdArgs r;                                    // the rgb head (r.geo / r.ld_geo unused)
+};
+
+template <int KT0, int F>
+__global__ __launch_bounds__(kFieldThreads) void field_fwd_kernel(const FieldFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int KS0 = (KT0 + 1) / 2;
+    u32x4 *nw0l = smem, *nw1l = nw0l + w3_units(4, KS0), *w0l = nw1l + w3_units(4, 2), *w1al = w0l + w3_units(4, 2),
+          *w1gl = w1al + w3_units(4, 2), *w2l = w1gl + w3_units(4, 2);
+    float *nb0l = reinterpret_cast<float *>(w2l + w3_units(1, 2)), *nb1l = nb0l + 64, *b2l = nb1l + 64;
+    stage_w3(nw0l, 4, KS0, a.nw0);
+    stage_w3(nw1l, 4, 2, a.nw1);
+    stage_w3(w0l, 4, 2, a.r.w0g);
+    stage_w3(w1al, 4, 2, a.r.w1a);
+    stage_w3(w1gl, 4, 2, a.r.w1g);
+    stage_w3(w2l, 1, 2, a.r.w2);
+    stage_b(nb0l, 64, a.nb0, a.nw0.n);
+    stage_b(nb1l, 64, a.nb1, a.nw1.n);
+    stage_b(b2l, 16, a.r.b2, a.r.w2.n);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 nw0p = w3_at(nw0l, 4, KS0, lane), nw1p = w3_at(nw1l, 4, 2, lane);
+    const W3 w0p = w3_at(w0l, 4, 2, lane), w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w2p = w3_at(w2l, 1, 2, lane);
+    const int tpr = a.r.tiles_per_ray;
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g);
+    const bool keep = a.r.a1 != nullptr;
+    for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.r.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const float *rb0 = a.r.rb0 + ray * a.r.ld_rb + 4 * g, *rb1 = a.r.rb1 + ray * a.r.ld_rb + 4 * g;
+        const int64_t row0 = ray * tpr * 16;   // wave-uniform: one scalar base per tensor, 32-bit lane offsets
+        const float *encp = a.enc + row0 * F;
+        float *geo = a.geo + row0 * 64, *dens = a.dens + row0, *a1 = a.r.a1 + row0 * 64, *a2 = a.r.a2 + row0 * 64, *outp = a.r.out + row0 * 3;
+        for (int j = 0; j < tpr; ++j) {
+            f32x4 x[4];
+            {   // neck: enc -> relu(W0 . + b0) -> W1 . + b1 = geometry features
+                f32x4 e[KT0];
+                ld_lm_t<KT0, F>(encp + (unsigned)j * 16u * (unsigned)F, (unsigned)a.n, a.n_levels, (unsigned)m, g, e);
+                Opd<KS0> eo;
+                make_opd<KT0>(e, eo);
+                f32x4 hn[4];
+                init_bias<4>(nb0l, g, hn);
+                tgemm<KS0, 4>(nw0p, eo, hn);
+                relu<4>(hn);
+                Opd<2> hno;
+                make_opd<4>(hn, hno);
+                init_bias<4>(nb1l, g, x);
+                tgemm<2, 4>(nw1p, hno, x);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(geo + (lo64 + (unsigned)j * 1024u + 16u * p)) = x[p];
+            if (g == 0) dens[(unsigned)j * 16u + (unsigned)m] = expf(x[0][0] - 1.0f);
+            // rgb head (rgb_fwd_kernel's tile body)
+            Opd<2> xo;
+            make_opd<4>(x, xo);
+            f32x4 h[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = *reinterpret_cast<const f32x4 *>(rb0 + 16 * p);
+            tgemm<2, 4, false>(w0p, xo, h);
+            relu<4>(h);
+            if (keep)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a1 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h[p];
+            f32x4 h2[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h2[p] = *reinterpret_cast<const f32x4 *>(rb1 + 16 * p);
+            tgemm<2, 4, false>(w1gp, xo, h2);
+            Opd<2> ho;
+            make_opd<4>(h, ho);
+            tgemm<2, 4, false>(w1ap, ho, h2);
+            relu<4>(h2);
+            if (keep)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
+            make_opd<4>(h2, ho);
+            f32x4 o[1];
+            init_bias<1>(b2l, g, o);
+            tgemm<2, 1>(w2p, ho, o);
+            if (g == 0) {
+                float *op = outp + ((unsigned)j * 48u + 3u * m);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) op[i] = 1.0f / (1.0f + expf(-o[0][i]));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ rgb backward
 struct RgbBwdArgs {
     const float *dout, *out;           // [n][3] gradient of / saved sigmoid output
@@ -1377,6 +1474,54 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
     if (int rc = set_lds(rgb_fwd_kernel, lds, "rgb_head_fwd")) return rc;
     hipLaunchKernelGGL(rgb_fwd_kernel, dim3(fused_grid(n_rays, kNThreads)), dim3(kNThreads), lds, as_stream(stream), a);
     return check_launch("rgb_head_fwd");
+}
+
+// 1 when emer_field_fwd covers a neck of this input shape (64 hidden, 64 geometry features) followed by the rgb head
+extern "C" int emer_field_fwd_supported(int32_t n_levels, int32_t n_feat) {
+    const int k0 = n_levels * n_feat;
+    return ((n_feat == 2 || n_feat == 4) && k0 >= 1 && k0 <= 64) ? 1 : 0;
+}
+
+// neck (emer_neck_fwd with n_out = 64, no hidden layer stored) + rgb head (emer_rgb_head_fwd) in one launch; rows of ray r are
+// r*S .. r*S+S-1.  Outputs: geo [n][64], dens [n], a1 / a2 [n][64] (both NULL: inference), out [n][3].
+extern "C" int emer_field_fwd(const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t n_rays, int32_t samples_per_ray,
+                              const float *nw0, const float *nb0, const float *nw1, const float *nb1, const float *rb0, const float *rb1,
+                              int64_t ld_rb, int32_t kh, const float *w0, const float *w1, const float *w2, const float *b2, float *geo,
+                              float *dens, float *a1, float *a2, float *out, void *stream) {
+    EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "field_fwd: bad sizes (S must be a multiple of 16)");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(emer_field_fwd_supported(n_levels, n_feat), "field_fwd: unsupported encoding L=%d F=%d", n_levels, n_feat);
+    EMER_REQUIRE(enc_lm && nw0 && nw1 && rb0 && rb1 && w0 && w1 && w2 && geo && dens && out && (a1 != nullptr) == (a2 != nullptr) &&
+                 ld_rb >= 64 && ld_rb % 4 == 0, "field_fwd: bad arguments");
+    const int64_t n = n_rays * samples_per_ray;
+    const int k0 = n_levels * n_feat;
+    EMER_REQUIRE(n * k0 < ((int64_t)1 << 30), "field_fwd: n * L * F must stay below 2^30 (32-bit lane offsets)");
+    FieldFwdArgs a;
+    a.enc = enc_lm; a.n = n; a.n_levels = n_levels;
+    a.nw0 = WSrc{nw0, k0, 1, 64, k0};
+    a.nw1 = WSrc{nw1, 64, 1, 64, 64};
+    a.nb0 = nb0; a.nb1 = nb1; a.geo = geo; a.dens = dens;
+    a.r.geo = nullptr; a.r.ld_geo = 64; a.r.rb0 = rb0; a.r.rb1 = rb1; a.r.ld_rb = ld_rb; a.r.tiles_per_ray = samples_per_ray / 16; a.r.n_rays = n_rays;
+    const int64_t kk0 = kh + 64, kk1 = 64 + kk0;
+    a.r.w0g = WSrc{w0 + kh, kk0, 1, 64, 64};
+    a.r.w1a = WSrc{w1, kk1, 1, 64, 64};
+    a.r.w1g = WSrc{w1 + 64 + kh, kk1, 1, 64, 64};
+    a.r.w2 = WSrc{w2, 64, 1, 3, 64};
+    a.r.b2 = b2; a.r.a1 = a1; a.r.a2 = a2; a.r.out = out;
+    const int kt0 = (k0 + 15) / 16;
+    const size_t lds = (size_t)(w3_units(4, (kt0 + 1) / 2) + 4 * w3_units(4, 2) + w3_units(1, 2)) * 16 + (64 + 64 + 16) * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    int64_t blocks = (n_rays + kFieldThreads / 64 - 1) / (kFieldThreads / 64);
+    const uint32_t grid = (uint32_t)(blocks > 256 ? 256 : blocks);  // persistent: one workgroup per CU
+    int rc = EMER_E_INVALID;
+    auto go = [&](auto kern) {
+        if (int r = set_lds(kern, lds, "field_fwd")) return r;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kFieldThreads), lds, st, a);
+        return check_launch("field_fwd");
+    };
+    if (n_feat == 2) { if (kt0 == 1) rc = go(field_fwd_kernel<1, 2>); else if (kt0 == 2) rc = go(field_fwd_kernel<2, 2>); else if (kt0 == 3) rc = go(field_fwd_kernel<3, 2>); else rc = go(field_fwd_kernel<4, 2>); }
+    else { if (kt0 == 1) rc = go(field_fwd_kernel<1, 4>); else if (kt0 == 2) rc = go(field_fwd_kernel<2, 4>); else if (kt0 == 3) rc = go(field_fwd_kernel<3, 4>); else rc = go(field_fwd_kernel<4, 4>); }
+    return rc;
 }
 
 // rgb head data-gradient chain.  Writes dpre2 [n][3], dpre1 / dpre0 / dgeo [n][64] and the per-ray sums s1 / s0

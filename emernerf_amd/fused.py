@@ -307,6 +307,32 @@ def neck_supported(n_levels: int, n_feat: int, hidden: int, n_out: int) -> bool:
     return bool(_lib.load().emer_neck_supported(n_levels, n_feat, hidden, n_out))
 
 
+class RgbRider:
+    """A colour query that rides along in the neck's forward launch (emer_field_fwd): the neck Function computes the rgb head's
+    activations and output together with the geometry features and parks them here; the rgb head Function that is called
+    next WITH THOSE geometry features picks them up instead of launching its own forward.  The autograd graph (neck node ->
+    rgb node) and both backward passes are exactly those of the separate calls."""
+
+    def __init__(self, hray: Tensor, samples_per_ray: int, params, keep: bool):
+        self.hray, self.S, self.params, self.keep = hray, int(samples_per_ray), tuple(params), bool(keep)
+        self.geo_ptr = None
+        self.rb = self.a1 = self.a2 = self.out = None
+
+    def usable(self, L: int, F: int, N: int, n_out: int) -> bool:
+        w0, _, w1, _, w2, _ = self.params
+        R, Kh = self.hray.shape
+        return bool(n_out == 64 and self.S % 16 == 0 and R * self.S == N and Kh <= 64 and w0.shape == (64, Kh + 64)
+                    and w1.shape == (64, 128 + Kh) and w2.shape == (3, 64) and N * L * F < 2 ** 30
+                    and _lib.load().emer_field_fwd_supported(L, F))
+
+
+_RIDERS: dict = {}   # data_ptr of a neck's geometry features -> the rider whose rgb results were computed with them
+
+
+def clear_riders() -> None:
+    _RIDERS.clear()
+
+
 def _neck_fwd(enc: Tensor, W0, B0, W1, B1, n_out: int, want_h: bool):
     L, N, F = enc.shape
     dev = enc.device
@@ -324,14 +350,19 @@ class _NeckFn(torch.autograd.Function):
     """(features 0..63, features 64..127 or None, density) = neck(enc_lm); density = trunc_exp(feature 0 - 1)."""
 
     @staticmethod
-    def forward(ctx, enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+    def forward(ctx, enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, rider: Optional[RgbRider] = None):
         ctx.set_materialize_grads(False)
         enc, W0, B0, W1, B1 = _c(enc_lm), _c(w0), _c(b0), _c(w1), _c(b1)
         n_out = W1.shape[0]
         L, N, F = enc.shape
         # the fused backward recomputes the hidden layer from enc: the forward then does not store it (268 MB at 1 M rows)
         ctx.fused_bwd = bool(FUSED_WGRAD and any(ctx.needs_input_grad) and _lib.load().emer_neck_bwd_fused_workspace(L, F, N, n_out) > 0)
-        h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, any(ctx.needs_input_grad) and not ctx.fused_bwd)
+        want_h = any(ctx.needs_input_grad) and not ctx.fused_bwd
+        if rider is not None and not want_h and rider.usable(L, F, N, n_out):
+            h1, out1 = None, None
+            out0, dens = _field_fwd(enc, W0, B0, W1, B1, rider)
+        else:
+            h1, out0, out1, dens = _neck_fwd(enc, W0, B0, W1, B1, n_out, want_h)
         ctx.save_for_backward(enc, W0, W1, h1, dens, B0)
         ctx.n_out = n_out
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1))
@@ -345,7 +376,7 @@ class _NeckFn(torch.autograd.Function):
         n_out = ctx.n_out
         d0, d1, ddens = (grads[0], None, grads[1]) if n_out == 64 else grads
         if d0 is None and d1 is None and ddens is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         L, N, F = enc.shape
         dev = enc.device
         d0c = None if d0 is None else _c(d0)
@@ -363,7 +394,7 @@ class _NeckFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.call("emer_neck_bwd_fused", _p(d0c), _p(fa), _p(dens), _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), n_out,
                           _p(denc), _p(ws), _p(tw0), tw0.stride(0), _p(tb0), _p(tw1), tw1.stride(0), _p(tb1), _stream(enc))
-            return denc, rw0, rb0, rw1, rb1
+            return denc, rw0, rb0, rw1, rb1, None
         dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
         # column 0 of the output-layer wgrad operand = d0[:, 0] + trunc_exp side gradient, written by the kernel
         col0 = None if fa is None else torch.empty((N,), device=dev, dtype=torch.float32)
@@ -378,13 +409,37 @@ class _NeckFn(torch.autograd.Function):
         if n_out == 128 and d1c is not None:
             wgrad(d1c, [seg(h1, 0, 64)], 64, out_w=tw1[64:], out_b=tb1[64:])
         wgrad(dpre0, [seg_lm(enc, 0)], L * F, out_w=tw0, out_b=tb0)
-        return denc, rw0, rb0, rw1, rb1
+        return denc, rw0, rb0, rw1, rb1, None
 
 
-def neck(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
+def _field_fwd(enc: Tensor, W0, B0, W1, B1, rider: RgbRider):
+    """emer_field_fwd: the neck and the rider's rgb head in one launch; the rgb results are parked on the rider."""
+    L, N, F = enc.shape
+    dev = enc.device
+    hr = _c(rider.hray)
+    RW0, RB0, RW1, RB1, RW2, RB2 = (_c(p) for p in rider.params)
+    R, Kh = hr.shape
+    geo = torch.empty((N, 64), device=dev, dtype=torch.float32)
+    dens = torch.empty((N,), device=dev, dtype=torch.float32)
+    rb = torch.empty((R, 128), device=dev, dtype=torch.float32)
+    a1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if rider.keep else None
+    a2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if rider.keep else None
+    out = torch.empty((N, 3), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.call("emer_ray_pre_fwd", _p(hr), hr.stride(0), R, Kh, 64, _p(RW0), RW0.stride(0), _p(RB0), _p(RW1[:, 64:]), RW1.stride(0),
+                  _p(RB1), _p(rb), 128, _stream(enc))
+        _lib.call("emer_field_fwd", _p(enc), L, F, R, rider.S, _p(W0), _p(B0), _p(W1), _p(B1), _p(rb), _p(rb[:, 64:]), 128, Kh,
+                  _p(RW0), _p(RW1), _p(RW2), _p(RB2), _p(geo), _p(dens), _p(a1), _p(a2), _p(out), _stream(enc))
+    rider.geo_ptr, rider.a1, rider.a2, rider.out = geo.data_ptr(), a1, a2, out
+    _RIDERS[geo.data_ptr()] = rider
+    return geo, dens
+
+
+def neck(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor, rider: Optional[RgbRider] = None):
     """Register-resident neck: returns (feats[:, :64], feats[:, 64:128] or None, density [N]).  Requires
-    ``neck_supported(L, F, hidden, n_out)`` with n_out in (64, 128)."""
-    r = _NeckFn.apply(*_ng(enc_lm, w0, b0, w1, b1))
+    ``neck_supported(L, F, hidden, n_out)`` with n_out in (64, 128).  ``rider``: a colour query on the resulting geometry
+    features to evaluate in the same launch (see RgbRider)."""
+    r = _NeckFn.apply(*_ng(enc_lm, w0, b0, w1, b1), rider)
     return (r[0], None, r[1]) if len(r) == 2 else r
 
 
@@ -458,7 +513,7 @@ def density_mlp(enc_lm: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) 
 # ------------------------------------------------------------------------------------------ rgb head
 class _RgbHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hray: Tensor, geo: Tensor, S: int, w0, b0, w1, b1, w2, b2):
+    def forward(ctx, hray: Tensor, geo: Tensor, S: int, w0, b0, w1, b1, w2, b2, pre: Optional[RgbRider] = None):
         ctx.set_materialize_grads(False)
         hr, W0, B0, W1, B1, W2, B2 = _c(hray), _c(w0), _c(b0), _c(w1), _c(b1), _c(w2), _c(b2)
         g = geo.detach()
@@ -477,6 +532,10 @@ class _RgbHeadFn(torch.autograd.Function):
         ctx.S = S
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
         ctx.fast = (H == 64 and NG == 64 and C == 3 and Kh <= 64 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
+        if pre is not None and ctx.fast and (pre.keep or not keep):
+            # already evaluated inside the neck's launch on exactly these tensors (rgb_head checked): nothing to launch
+            ctx.save_for_backward(hr, g, W0, W1, W2, pre.a1, pre.a2, pre.out)
+            return pre.out
         if ctx.fast:
             # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row launch instead of two 1M-row GEMMs),
             # reading the two column blocks of W0 / W1 in place
@@ -506,7 +565,7 @@ class _RgbHeadFn(torch.autograd.Function):
     def backward(ctx, dout: Optional[Tensor]):
         hr, g, W0, W1, W2, a1, a2, out = ctx.saved_tensors
         if dout is None:
-            return (None,) * 9
+            return (None,) * 10
         S = ctx.S
         N, NG = g.shape
         R, Kh = hr.shape
@@ -546,7 +605,7 @@ class _RgbHeadFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.call("emer_ray_pre_bwd", _p(s0), _p(s1), H, R, Kh, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dhray), Kh,
                           _stream(g))
-            return dhray, dgeo, None, rw0, rb0, rw1, rb1, rw2, rb2
+            return dhray, dgeo, None, rw0, rb0, rw1, rb1, rw2, rb2, None
         dpre2 = (_c(dout) * out * (1.0 - out)).contiguous()            # sigmoid'
         dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
         dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
@@ -565,12 +624,18 @@ class _RgbHeadFn(torch.autograd.Function):
         dw1, db1 = wgrad(dpre1, [seg(a1, 0, H), seg(hr, H, Kh, row_div=S), seg(g, H + Kh, NG, ld=g.stride(0))], H + K0)
         dw0, db0 = wgrad(dpre0, [seg(hr, 0, Kh, row_div=S), seg(g, Kh, NG, ld=g.stride(0))], K0)
         dhray = dh.view(R, S, Kh).sum(dim=1)
-        return dhray, dgeo, None, dw0, db0, dw1, db1, dw2, db2
+        return dhray, dgeo, None, dw0, db0, dw1, db1, dw2, db2, None
 
 
 def rgb_head(hray: Tensor, geo: Tensor, samples_per_ray: int, w0, b0, w1, b1, w2, b2) -> Tensor:
     """sigmoid(MLP3-skip1([hray[ray] | geo])) -> [N, 3]; hray [R, Kh] per ray, geo [N, NG] per sample."""
-    return _RgbHeadFn.apply(*_ng(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2))
+    pre = _RIDERS.pop(geo.data_ptr(), None)
+    if pre is not None:  # the same query, tensor for tensor, that rode along in the neck's launch?
+        same = (pre.S == samples_per_ray and pre.hray.data_ptr() == hray.data_ptr() and pre.hray.shape == hray.shape
+                and geo.dim() == 2 and geo.shape[1] == 64 and geo.stride(0) == 64
+                and all(a is b for a, b in zip(pre.params, (w0, b0, w1, b1, w2, b2))))
+        pre = pre if same else None
+    return _RgbHeadFn.apply(*_ng(hray, geo, samples_per_ray, w0, b0, w1, b1, w2, b2), pre)
 
 
 # ------------------------------------------------------------------------------------------ per-ray inputs

@@ -11,6 +11,8 @@ learnable PE map.
 """
 from __future__ import annotations
 
+import os
+
 import logging
 from typing import Callable, Dict, List, Optional, Tuple, Union
 
@@ -124,6 +126,7 @@ class MLP(nn.Module):
 
 
 BATCH_XYZT = True  # flow configs: evaluate each xyzt table once per dependency level (RadianceField._flow_branch_batched)
+FUSE_FIELD = os.environ.get("EMER_FUSE_FIELD", "1") != "0"   # neck + rgb head of the static model as one forward launch (fused.RgbRider); 0: two launches
 
 
 class RadianceField(nn.Module):
@@ -274,7 +277,7 @@ class RadianceField(nn.Module):
         enc_lm = encoder.tcnn_encoding.forward_level_major(x)
         return fused.base_mlp(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
 
-    def _base_split(self, encoder: HashEncoder, mlp: nn.Sequential, x: Tensor):
+    def _base_split(self, encoder: HashEncoder, mlp: nn.Sequential, x: Tensor, rider=None):
         """(geo feats, semantic feats or None, density) of the neck.  With the shipped widths (hidden 64, geometry and
         semantic features 64 each) this is the register-resident kernel, which writes the two halves as separate
         [N, 64] tensors -- the split of :400 costs nothing and an unused semantic half gets no backward work."""
@@ -283,7 +286,11 @@ class RadianceField(nn.Module):
         if (self.geometry_feature_dim == 64 and n_out in (64, 128) and n_out == 64 + self.semantic_feature_dim
                 and fused.neck_supported(enc.desc.n_levels, enc.desc.n_features, mlp[0].out_features, n_out)):
             enc_lm = enc.forward_level_major(x)
-            return fused.neck(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+            # the rider is built AFTER the encode: its per-ray input node must be younger than the grid node, so that autograd
+            # runs the embedding gradient BEFORE the table backward (the data-parallel early bucket relies on the static
+            # table's backward being the last writer of the step, trainer.py)
+            rider = rider() if callable(rider) else rider
+            return fused.neck(enc_lm, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, rider=rider)
         feats, density = self._base(encoder, mlp, x)
         geo, sem = torch.split(feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)
         return geo, sem, density
@@ -293,8 +300,21 @@ class RadianceField(nn.Module):
         lead = normed_positions.shape[:-1]
         return feats.view(*lead, -1), density.view(*lead)
 
-    def _static_split(self, normed_positions: Tensor):
-        geo, sem, density = self._base_split(self.xyz_encoder, self.base_mlp, normed_positions.reshape(-1, self.num_dims))
+    def _rgb_rider(self, directions: Optional[Tensor], data_dict):
+        """The colour query of this forward pass as a rider of the static neck's launch (fused.RgbRider), or None when the
+        query is not the per-ray, 64-wide, skip-at-1 head the fused kernel covers."""
+        head = self.rgb_head
+        if not (FUSE_FIELD and directions is not None and directions.dim() == 3 and self._per_ray(directions)
+                and len(head.layers) == 3 and list(head.skip_connections) == [1] and head.hidden_dims == 64):
+            return None
+        both = self._ray_inputs(directions, data_dict)
+        lw = [p for l in head.layers for p in (l.weight, l.bias)]
+        if both is None or any(p is None for p in lw):
+            return None
+        return fused.RgbRider(both[0], directions.shape[1], lw, torch.is_grad_enabled())
+
+    def _static_split(self, normed_positions: Tensor, rider=None):
+        geo, sem, density = self._base_split(self.xyz_encoder, self.base_mlp, normed_positions.reshape(-1, self.num_dims), rider)
         lead = normed_positions.shape[:-1]
         return geo.view(*lead, -1), (None if sem is None else sem.view(*lead, -1)), density.view(*lead)
 
@@ -587,9 +607,12 @@ class RadianceField(nn.Module):
         branch ("to be studied" in the reference, consumed by nothing): render_rays never reads them."""
         results_dict = {}
         _EMBED_CACHE.clear()
+        fused.clear_riders()
         if normed_positions is None:
             normed_positions = self.contract_points(positions)
-        geo_feats, semantic_feats, static_density = self._static_split(normed_positions)
+        # the static colour query rides along in the neck's launch when it is the plain per-ray one (static model)
+        rider = (lambda: self._rgb_rider(directions, data_dict)) if (not return_density_only and normed_positions.dim() == 3) else None
+        geo_feats, semantic_feats, static_density = self._static_split(normed_positions, rider)
 
         has_timestamps = "normed_timestamps" in data_dict or "lidar_normed_timestamps" in data_dict
         dynamic = self.dynamic_xyz_encoder is not None and has_timestamps

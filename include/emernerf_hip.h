@@ -419,6 +419,18 @@ int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float 
 int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
                       const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);
+/* emer_neck_fwd (n_out = 64, hidden layer not stored) followed by emer_rgb_head_fwd as ONE launch (RadianceField.forward of the
+ * static model: radiance_field.py:302-318,400 then :622-658): a wave keeps its 16 rows in registers from the grid encoding to
+ * the colour; the geometry features are written once (the backward needs them) and never read back.  enc_lm [L][n][F] with
+ * n = n_rays * samples_per_ray, nw0 [64][L F], nw1 [64][64] (the neck), the other arguments as in emer_rgb_head_fwd.
+ * Outputs geo [n][64], dens [n] = exp(geo[:, 0] - 1), a1 / a2 [n][64] (both NULL: inference), out [n][3].  The results are
+ * bit-identical to the two separate calls. */
+int emer_field_fwd_supported(int32_t n_levels, int32_t n_feat);
+int emer_field_fwd(const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t n_rays, int32_t samples_per_ray,
+                   const float *nw0, const float *nb0, const float *nw1, const float *nb1, const float *rb0,
+                   const float *rb1, int64_t ld_rb, int32_t kh, const float *w0, const float *w1,
+                   const float *w2, const float *b2, float *geo, float *dens, float *a1, float *a2,
+                   float *out, void *stream);
 /* Data gradients: dpre2 [n][3] = dout * out * (1 - out), dpre1 / dpre0 [n][64] (pre-activation gradients of
  * layers 1 / 0, the wgrad operands), dgeo [n][64], and s1 / s0 [rays][64] = sums of dpre1 / dpre0 over the
  * samples of each ray (all that hray, W0[:, :kh], W1[:, 64:64+kh], b0 and b1 need).

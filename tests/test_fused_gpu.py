@@ -330,3 +330,52 @@ def test_forwards_outside_autograd_recording_match(hip_lib):
     with torch.no_grad():
         got = fused.density_mlp(enc, *dw)
     assert torch.equal(want, got) and not got.requires_grad
+
+
+@pytest.mark.parametrize("L,Fe,R,S", [(16, 2, 64, 32), (10, 4, 7, 16), (4, 2, 3, 128)])
+def test_field_forward_rides_along(hip_lib, L, Fe, R, S):
+    """emer_field_fwd (neck + rgb head in one launch, fused.RgbRider) against the two separate launches: geometry features,
+    density and colour bit-identical; gradients of every parameter identical too (the backward is the separate kernels' in
+    both cases, fed by the saved activations)."""
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(L * 100 + R)
+    N, H, Kh = R * S, 64, 49
+    enc = (torch.randn(L, N, Fe, generator=g) * 0.5).to(dev)
+    neck = [torch.randn(H, L * Fe, generator=g) / (L * Fe) ** 0.5, torch.randn(H, generator=g) * 0.1, torch.randn(H, H, generator=g) / 8, torch.randn(H, generator=g) * 0.1]
+    head = [torch.randn(H, Kh + H, generator=g) / 10, torch.randn(H, generator=g) / 10, torch.randn(H, H + Kh + H, generator=g) / 12,
+            torch.randn(H, generator=g) / 10, torch.randn(3, H, generator=g) / 8, torch.randn(3, generator=g) / 10]
+    hray = torch.randn(R, Kh, generator=g).to(dev)
+    wrgb = torch.randn(N, 3, generator=g).to(dev)
+    wden = torch.randn(N, generator=g).to(dev)
+
+    def run(ride):
+        pn = [w.clone().to(dev).requires_grad_(True) for w in neck]
+        ph = [w.clone().to(dev).requires_grad_(True) for w in head]
+        hr = hray.clone().requires_grad_(True)
+        fused.clear_riders()
+        rider = fused.RgbRider(hr, S, ph, True) if ride else None
+        geo, _, dens = fused.neck(enc, *pn, rider=rider)
+        if ride:
+            assert rider.out is not None, "the rider was not taken (shape not covered?)"
+        rgb = fused.rgb_head(hr, geo, S, *ph)
+        if ride:
+            assert rgb.data_ptr() == rider.out.data_ptr(), "rgb_head launched its own forward"
+        ((rgb * wrgb).sum() + (dens * wden).sum() + 0.01 * geo.sum()).backward()
+        return [geo, dens, rgb] + [p.grad for p in pn + ph] + [hr.grad]
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a[:3], b[:3])):
+        assert torch.equal(x, y), f"output {i} differs"
+    for i, (x, y) in enumerate(zip(a[3:], b[3:])):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max())), f"gradient {i} differs"  # atomics in the reductions
+    # a query with other tensors must not pick the parked results up
+    pn = [w.clone().to(dev) for w in neck]
+    ph = [w.clone().to(dev) for w in head]
+    fused.clear_riders()
+    rider = fused.RgbRider(hray, S, ph, False)
+    with torch.no_grad():
+        geo, _, _ = fused.neck(enc, *pn, rider=rider)
+        other = [w.clone() for w in ph]
+        rgb = fused.rgb_head(hray, geo, S, *other)
+    assert rgb.data_ptr() != rider.out.data_ptr() and torch.equal(rgb, rider.out)
