@@ -83,6 +83,7 @@ SIGNATURES = {
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rgb_head_fwd": [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_field_fwd_supported": [c_int32, c_int32],
+    "emer_density_bwd_fused": [_P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P],
     "emer_field_fwd": [_P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
@@ -107,6 +108,7 @@ INT64_FUNCTIONS = {
     "emer_linear_bwd_workspace": [c_int64, c_int32, c_int32],
     "emer_neck_bwd_fused_workspace": [c_int32, c_int32, c_int64, c_int32],
     "emer_rgb_head_bwd_workspace": [c_int64],
+    "emer_density_bwd_fused_workspace": [c_int32, c_int32, c_int64],
 }
 
 ALLOW_MISSING_SYMBOLS = False  # never set by the product path

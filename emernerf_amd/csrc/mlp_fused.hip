@@ -1104,6 +1104,121 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
     }
 }
 
+// ------------------------------------------------------------------------ density MLP backward with its weight gradients
+// Backward of density_fwd_kernel (narrow input, L F <= 16) INCLUDING dW0, db0, dW1, db1 -- the proposal network's step.  The
+// hidden layer is recomputed from the encoding (two k-steps of the fp32 matrix instruction), the gradient of the single
+// output is rank-1 (dh = (h > 0) w1 dpre1), the input gradient is sixteen more fp32 matrix instructions, and every weight
+// gradient is a sum over ROWS of per-lane products -- 10 + L F of the 16-quantity DPP reduce-scatters of the rgb backward per
+// tile, 11 + L F accumulators per lane for the whole kernel.  Against the unfused path (hidden layer stored by the forward and
+// re-read twice, dpre0 written and re-read: 1.1 GB per million rows) this moves 72 MB.
+struct DensBwdWArgs {
+    const float *ddens, *dens, *enc; int64_t n; int32_t n_levels;
+    WSrc w0; const float *b0; const float *w1;   // W0 [64][K0], b0 [64], W1 [64] (one output row)
+    float *denc;                                  // level-major [L][n][F]
+    float *partials; int64_t stride;              // per workgroup: dW0 [64][K0] | db0 [64] | dW1 [64] | db1 [1]
+};
+constexpr int kDensPartMax = 64 * 16 + 64 + 64 + 4;
+
+template <int KS4>
+__global__ __launch_bounds__(kNThreads, 2) void density_bwdw_kernel(const DensBwdWArgs a, int32_t F) {
+    __shared__ float part[kNThreads / 64][kDensPartMax];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const int32_t K0 = a.w0.k;
+    float aw[4][KS4];
+    int64_t koff[KS4];
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+        const int32_t k = 4 * s + g, kc = k < K0 ? k : K0 - 1;
+        koff[s] = (int64_t)(kc / F) * a.n * F + kc % F;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) aw[p][s] = k < K0 ? a.w0.w[(int64_t)(16 * p + m) * a.w0.sn + (int64_t)k * a.w0.sk] : 0.0f;
+    }
+    f32x4 b0r[4], w1r[4], awt[4];  // awt[p][i] = W0[16 p + 4 g + i][m]: the A operand of the input gradient (rows = input feature m)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t nf = 16 * p + 4 * g + i;
+            b0r[p][i] = a.b0 ? a.b0[nf] : 0.0f;
+            w1r[p][i] = a.w1[nf];
+            awt[p][i] = m < K0 ? a.w0.w[(int64_t)nf * a.w0.sn + (int64_t)m * a.w0.sk] : 0.0f;
+        }
+    float w0acc[4 * KS4], w1acc = 0.0f, b0acc = 0.0f, b1acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4 * KS4; ++k) w0acc[k] = 0.0f;
+    const int64_t n_tiles = (a.n + 15) >> 4, n_chunks = (n_tiles + kNeckChunk - 1) / kNeckChunk;
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; c < n_chunks; c += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t t0 = c * kNeckChunk;
+        float x[kNeckChunk][KS4], dd[kNeckChunk], de[kNeckChunk];
+#pragma unroll
+        for (int j = 0; j < kNeckChunk; ++j) {  // the chunk's inputs, all loads in flight (clamped rows)
+            const int64_t row = (t0 + j) * 16 + m, rc = row < a.n ? row : a.n - 1;
+#pragma unroll
+            for (int s = 0; s < KS4; ++s) x[j][s] = a.enc[koff[s] + rc * F];
+            dd[j] = a.ddens[rc];
+            de[j] = a.dens[rc];
+        }
+#pragma unroll
+        for (int j = 0; j < kNeckChunk; ++j) {
+            if (t0 + j >= n_tiles) break;
+            const int64_t row = (t0 + j) * 16 + m;
+            const bool ok = row < a.n;
+            f32x4 h[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = b0r[p];
+#pragma unroll
+            for (int s = 0; s < KS4; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) h[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[p][s], x[j][s], h[p], 0, 0, 0);
+            relu<4>(h);
+            const float fix = ok ? dd[j] * fminf(de[j], 3269017.3724721107f) : 0.0f;  // trunc_exp': d(pre-activation of the output)
+            f32x4 dh[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dh[p][i] = h[p][i] > 0.0f ? w1r[p][i] * fix : 0.0f;
+            // input gradient: dx[k][row] = sum_n W0[n][k] dh[n][row]; lane (m, g) receives k = 4 g .. 4 g + 3 of row m
+            f32x4 dx = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(awt[p][i], dh[p][i], dx, 0, 0, 0);
+            if (ok)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int32_t k = 4 * g + r;
+                    if (k < K0) a.denc[(int64_t)(k / F) * a.n * F + row * F + k % F] = dx[r];
+                }
+            // weight gradients: sums over the tile's rows, lane m keeping feature 16 (m >> 2) + 4 g + (m & 3)
+            w1acc += row16_reduce_scatter(h, fix, m);
+            b0acc += row16_reduce_scatter(dh, 1.0f, m);
+            if (g == 0) b1acc += fix;
+#pragma unroll
+            for (int k = 0; k < 4 * KS4; ++k) {
+                const float ek = __shfl(x[j][k >> 2], 16 * (k & 3) + m, 64);  // input feature k of this lane's row
+                w0acc[k] += row16_reduce_scatter(dh, ek, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // the waves' sums through LDS, one partial per workgroup
+    const int nf = 16 * (m >> 2) + 4 * g + (m & 3);
+#pragma unroll
+    for (int k = 0; k < 4 * KS4; ++k)
+        if (k < K0) part[wave][nf * K0 + k] = w0acc[k];
+    part[wave][64 * K0 + nf] = b0acc;
+    part[wave][64 * K0 + 64 + nf] = w1acc;
+    b1acc = row16_sum(b1acc);
+    if (lane == 0) part[wave][64 * K0 + 128] = b1acc;
+    __syncthreads();
+    const int total = 64 * K0 + 129;
+    for (int i = threadIdx.x; i < total; i += (int)blockDim.x) {
+        float t = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w][i];
+        a.partials[(int64_t)blockIdx.x * a.stride + i] = t;
+    }
+}
+
 // --------------------------------------------------------------- plain 2- / 3-layer heads (hidden width 64)
 // out = act(W_last relu(... relu(W0 x + b0) ...) + b_last): the flow MLP (xyzt grid 40 -> 64 -> 64 -> 6,
 // radiance_field.py:101-111), the shadow head (64 -> 64 -> 1 + sigmoid, :148-153) and the feature heads (64 -> 64 -> 64 ->
@@ -1449,6 +1564,38 @@ extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const fl
     if (rc) return rc;
     if (int r = launch_dw_reduce(workspace, (int32_t)grid, a.stride, 64, 64, dw1, ld_dw1, db1, st)) return r;
     return launch_dw_reduce(workspace + 64 * 64 + 64, (int32_t)grid, a.stride, 64, k0, dw0, ld_dw0, db0, st);
+}
+
+// Backward of the density MLP (emer_neck_fwd with n_out = 1) INCLUDING the weight gradients, for narrow inputs (L F <= 16: the
+// proposal networks).  Writes denc_lm [L][n][F]; ACCUMULATES dw0 [64][ld_dw0 >= L F], db0 [64], dw1 [1][64], db1 [1].  The hidden
+// layer is recomputed from enc_lm (pass h1 = NULL to emer_neck_fwd).
+static inline int64_t dens_bwdw_stride(int k0) { return ((int64_t)64 * k0 + 129 + 3) / 4 * 4; }
+extern "C" int64_t emer_density_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n) {
+    const int k0 = n_levels * n_feat;
+    if (n <= 0 || k0 < 1 || k0 > 16 || !emer_neck_supported(n_levels, n_feat, 64, 1)) return 0;
+    return (int64_t)fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads) * dens_bwdw_stride(k0);
+}
+extern "C" int emer_density_bwd_fused(const float *ddens, const float *dens, const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t n,
+                                      const float *w0, const float *b0, const float *w1, float *denc_lm, float *workspace, float *dw0,
+                                      int64_t ld_dw0, float *db0, float *dw1, float *db1, void *stream) {
+    EMER_REQUIRE(n >= 0, "density_bwd_fused: negative n");
+    if (n == 0) return EMER_OK;
+    const int k0 = n_levels * n_feat;
+    EMER_REQUIRE(emer_density_bwd_fused_workspace(n_levels, n_feat, n) > 0, "density_bwd_fused: unsupported shape L=%d F=%d (needs L F <= 16)", n_levels, n_feat);
+    EMER_REQUIRE(ddens && dens && enc_lm && w0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1 && ld_dw0 >= k0, "density_bwd_fused: bad arguments");
+    DensBwdWArgs a;
+    a.ddens = ddens; a.dens = dens; a.enc = enc_lm; a.n = n; a.n_levels = n_levels;
+    a.w0 = WSrc{w0, k0, 1, 64, k0};
+    a.b0 = b0; a.w1 = w1; a.denc = denc_lm; a.partials = workspace; a.stride = dens_bwdw_stride(k0);
+    hipStream_t st = as_stream(stream);
+    const uint32_t grid = fused_grid(((n + 15) / 16 + kNeckChunk - 1) / kNeckChunk, kNThreads);
+    const int ks4 = (k0 + 3) / 4;
+#define EMER_DBW(KS) hipLaunchKernelGGL(density_bwdw_kernel<KS>, dim3(grid), dim3(kNThreads), 0, st, a, n_feat)
+    if (ks4 == 1) EMER_DBW(1); else if (ks4 == 2) EMER_DBW(2); else if (ks4 == 3) EMER_DBW(3); else EMER_DBW(4);
+#undef EMER_DBW
+    if (int rc = check_launch("density_bwd_fused")) return rc;
+    if (int r = launch_dw_reduce(workspace, (int32_t)grid, a.stride, 64, k0, dw0, ld_dw0, db0, st)) return r;
+    return launch_dw_reduce(workspace + 64 * k0 + 64, (int32_t)grid, a.stride, 1, 64, dw1, 64, db1, st);
 }
 
 // rgb head forward: a1 = relu(geo W0g^T + rb0[ray]); a2 = relu(a1 W1a^T + geo W1g^T + rb1[ray]); out = sigmoid(a2 W2^T + b2).

@@ -455,9 +455,11 @@ class _DensityMLPFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         ctx.fast = neck_supported(L, F, H, 1)
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1))
+        # narrow inputs (the proposal networks): one backward kernel with the weight gradients, hidden layer recomputed
+        ctx.fused_bwd = bool(ctx.fast and FUSED_WGRAD and need_grad and _lib.load().emer_density_bwd_fused_workspace(L, F, N) > 0)
         if ctx.fast:
-            h, _, _, dens = _neck_fwd(enc, W0, B0, W1, B1, 1, need_grad)
-            ctx.save_for_backward(enc, W0, W1, h, dens)
+            h, _, _, dens = _neck_fwd(enc, W0, B0, W1, B1, 1, need_grad and not ctx.fused_bwd)
+            ctx.save_for_backward(enc, W0, W1, h, dens, B0)
             return dens
         h = torch.empty((N, H), device=dev, dtype=torch.float32) if need_grad else None
         dens = torch.empty((N, 1), device=dev, dtype=torch.float32)
@@ -466,17 +468,30 @@ class _DensityMLPFn(torch.autograd.Function):
         run_chain([seg_lm(enc, 0)],
                   [layer(W0, B0, 0, c_h, ACT_RELU, store=h), layer(W1, B1, c_h, c_o, ACT_TRUNC_EXP, store=dens)],
                   c_o + 4, N, enc)
-        ctx.save_for_backward(enc, W0, W1, h, dens)
+        ctx.save_for_backward(enc, W0, W1, h, dens, B0)
         return dens.view(N)
 
     @staticmethod
     def backward(ctx, ddens: Optional[Tensor]):
-        enc, W0, W1, h, dens = ctx.saved_tensors
+        enc, W0, W1, h, dens, B0 = ctx.saved_tensors
         if ddens is None:
             return None, None, None, None, None
         L, N, F = enc.shape
         K0, H = L * F, W0.shape[0]
         dev = enc.device
+        if ctx.fused_bwd:
+            denc = torch.empty((L, N, F), device=dev, dtype=torch.float32)
+            sw0, sb0, sw1, sb1 = ctx.sinks
+            tw0, rw0 = _target(sw0, (H, K0), dev)
+            tb0, rb0 = _target(sb0, (H,), dev)
+            tw1, rw1 = _target(sw1, (1, H), dev)
+            tb1, rb1 = _target(sb1, (1,), dev)
+            assert tw1.is_contiguous()
+            ws = torch.empty((int(_lib.load().emer_density_bwd_fused_workspace(L, F, N)),), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                _lib.call("emer_density_bwd_fused", _p(_c(ddens).reshape(-1)), _p(dens), _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), _p(denc), _p(ws),
+                          _p(tw0), tw0.stride(0), _p(tb0), _p(tw1), _p(tb1), _stream(enc))
+            return denc, rw0, rb0, rw1, rb1
         if ctx.fast:
             dpre1 = torch.empty((N, 1), device=dev, dtype=torch.float32)
             dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)

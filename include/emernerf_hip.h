@@ -419,6 +419,17 @@ int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float 
 int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
                       const float *w2, const float *b2, float *a1, float *a2, float *out, void *stream);
+/* Backward of the density MLP (emer_neck_fwd with n_out = 1: DensityField.base_mlp + trunc_exp, radiance_field.py:808-812,
+ * 836-840) INCLUDING its weight gradients, for narrow inputs (L * F <= 16: the proposal networks, L8 / F1): writes denc_lm
+ * [L][n][F] and ACCUMULATES (+=) dw0 [64][ld_dw0 >= L F], db0 [64], dw1 [1][64], db1 [1].  The hidden layer is recomputed from
+ * enc_lm, so the forward need not store it (h1 = NULL).  workspace: emer_density_bwd_fused_workspace floats (0: unsupported
+ * shape, use emer_neck_bwd + emer_wgrad_segmented). */
+int64_t emer_density_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n);
+int emer_density_bwd_fused(const float *ddens, const float *dens, const float *enc_lm, int32_t n_levels,
+                           int32_t n_feat, int64_t n, const float *w0, const float *b0, const float *w1,
+                           float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0,
+                           float *dw1, float *db1, void *stream);
+
 /* emer_neck_fwd (n_out = 64, hidden layer not stored) followed by emer_rgb_head_fwd as ONE launch (RadianceField.forward of the
  * static model: radiance_field.py:302-318,400 then :622-658): a wave keeps its 16 rows in registers from the grid encoding to
  * the colour; the geometry features are written once (the backward needs them) and never read back.  enc_lm [L][n][F] with

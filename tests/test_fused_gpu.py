@@ -81,12 +81,15 @@ def test_neck_register_resident(hip_lib, monkeypatch, L, Fe, NG, N, which, fused
         _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
-@pytest.mark.parametrize("L,N", [(8, 1000), (8, 17), (4, 256)])
-def test_density_mlp(hip_lib, L, N):
+@pytest.mark.parametrize("fusedw", [True, False])  # weight gradients inside the backward kernel (L F <= 16) / separate passes
+@pytest.mark.parametrize("L,N,Fe", [(8, 1000, 1), (8, 17, 1), (4, 256, 1), (8, 70000, 1), (4, 333, 4), (7, 100, 2), (12, 50, 2)])
+def test_density_mlp(hip_lib, monkeypatch, L, N, Fe, fusedw):
     from emernerf_amd import fused
+    monkeypatch.setattr(fused, "FUSED_WGRAD", fusedw)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(L + N)
-    enc = torch.randn(L, N, 1, generator=g)
+    enc = torch.randn(L, N, Fe, generator=g)
+    L_rows, L = L, L * Fe  # K0 = L * F input features
     W0, b0 = torch.randn(64, L, generator=g) / L ** 0.5, torch.randn(64, generator=g) * 0.1
     W1, b1 = torch.randn(1, 64, generator=g) / 8, torch.randn(1, generator=g) * 0.1
     t = [v.to(dev).requires_grad_(True) for v in (enc, W0, b0, W1, b1)]
