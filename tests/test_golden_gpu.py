@@ -100,9 +100,17 @@ def test_render_rays_matches_reference(hip_lib, case):
     assert set(results) - {"extras"} == out_keys, f"result keys differ: {set(results) ^ out_keys}"
     assert set(results["extras"]) == ex_keys, f"extras keys differ: {set(results['extras']) ^ ex_keys}"
     for k in sorted(out_keys):
-        if k == "median_depth":  # index-valued: tolerate a one-sample slip on a few rays
-            g, w = results[k].detach().cpu().numpy(), gold["out/" + k]
-            assert (np.isclose(g, w, rtol=1e-4).mean() > 0.9), k
+        if k == "median_depth":  # index-valued (the sample at which the accumulated weight crosses one half)
+            g, w = results[k].detach().cpu().numpy().reshape(-1), gold["out/" + k].reshape(-1)
+            same = np.isclose(g, w, rtol=1e-4)
+            assert same.mean() > 0.9, k
+            tv = gold["extras/t_vals"]
+            if tv.shape[0] == g.shape[0] and not same.all():
+                # a ray that disagrees may only have slipped to the NEIGHBOURING sample (cumulative weight within rounding
+                # of one half at the boundary): compare sample indices, not depths
+                ig = np.abs(tv - g[:, None]).argmin(1)
+                iw = np.abs(tv - w[:, None]).argmin(1)
+                assert (np.abs(ig - iw)[~same] <= 1).all(), f"{k}: a ray moved by more than one sample"
             continue
         _check("out/" + k, results[k], gold["out/" + k])
     for k in sorted(ex_keys):

@@ -201,3 +201,34 @@ def test_slice_plan_host_logic(hip_lib, grid, rows):
     assert hip_lib.emer_rmlp_supported(3, 40, 4, 64, 6) == 1 and hip_lib.emer_rmlp_supported(2, 64, 0, 64, 1) == 1
     assert hip_lib.emer_rmlp_supported(3, 64, 0, 64, 64) == 1 and hip_lib.emer_rmlp_supported(2, 43, 0, 32, 5) == 0
     assert hip_lib.emer_neck_supported(16, 2, 64, 64) == 1 and hip_lib.emer_neck_supported(10, 4, 64, 128) == 1
+
+
+def test_inputs_are_detached_outside_autograd_recording():
+    """A Function's forward sees needs_input_grad == requires_grad whatever the grad mode (and is_grad_enabled() is False inside
+    every forward), so the public wrappers detach under torch.no_grad(): nothing is then saved for a backward that cannot run."""
+    import torch
+    from emernerf_amd import fused, ops
+    w, x = torch.ones(3, requires_grad=True), torch.ones(3)
+    for ng in (fused._ng, ops._ng):
+        a = ng(x, w, 5, None)
+        assert a[1] is w and a[0] is x
+        with torch.no_grad():
+            b = ng(x, w, 5, None)
+        assert not b[1].requires_grad and b[1].data_ptr() == w.data_ptr() and b[2] == 5 and b[3] is None
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            Probe.seen = (ctx.needs_input_grad[0], torch.is_grad_enabled())
+            return t * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    with torch.no_grad():
+        Probe.apply(w)
+    assert Probe.seen == (True, False), "the premise changed: revisit fused._ng"
+    with torch.no_grad():
+        Probe.apply(*fused._ng(w))
+    assert Probe.seen == (False, False)
