@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--table-dtype", default="f32", choices=["f32", "f16"], help="hash-table precision: f32 (the reference's; the headline) or "
                     "f16 (tcnn half-precision tables: fp32 master cast per call, fp32 gradient accumulation; BASELINE.md 2.2)")
     ap.add_argument("--no-fp16-state", action="store_true", help="skip the short fp16-table run behind roofline_fp16_tables")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2..3] (dynamic, flow, flow at "
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE configs[2..4] (dynamic, flow, flow and feature at "
                     "the 2048-ray per-rank shard of configs[3])")
     ap.add_argument("--secondary-steps", type=int, default=0, help="timed steps of each secondary run (0: min(--steps, 12))")
     args = ap.parse_args()
@@ -449,7 +449,8 @@ def main():
     if rank == 0 and world == 1 and args.kind == "static" and not args.no_secondary:
         ss = args.secondary_steps or min(args.steps, 12)
         secondary = []
-        for kind_, rays_ in (("dynamic", args.rays), ("flow", args.rays), ("flow", max(args.rays // 4, 256))):
+        # ... and configs[4] (flow + feature head) at its 2048-ray shard
+        for kind_, rays_ in (("dynamic", args.rays), ("flow", args.rays), ("flow", max(args.rays // 4, 256)), ("feature", max(args.rays // 4, 256))):
             try:
                 secondary.append(measure_config(kind_, rays_, args.samples, dev, steps=ss, warmup=4, init_steps=14))
             except Exception as e:  # reporting only
