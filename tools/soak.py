@@ -1,16 +1,32 @@
-import sys, os, time, torch
-sys.path.insert(0, "/root/repo")
-from emernerf_amd.trainer import Trainer, synthetic_rays
+"""Stability soak: N optimizer steps of the static model from scratch (training schedule from step 0: the proposal nets train on
+every early step), eager and hipGraph replay; the loss must fall, the parameters stay finite, the memory high-water mark flat."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emernerf_amd.trainer import Trainer, synthetic_rays  # noqa: E402
+
 dev = torch.device("cuda:0")
-tr = Trainer(kind="static", device=dev, table_init=None)
-datas = [synthetic_rays(8192, dev, seed=s) for s in range(4)]
-torch.cuda.synchronize(); t0 = time.perf_counter()
-losses = []
-for i in range(1500):
-    out = tr.train_step(datas[i % 4])
-    if i % 250 == 0:
-        losses.append(float(out["loss"]))
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-p = tr.flat.params
-print("steps/s", 1500 / dt, "losses", [round(l, 5) for l in losses], "finite params", bool(torch.isfinite(p).all()), "mem GB", torch.cuda.max_memory_allocated() / 1e9)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+for use_graph in (False, True):
+    tr = Trainer(kind="static", device=dev, table_init=None, use_graph=use_graph)
+    datas = [synthetic_rays(8192, dev, seed=s) for s in range(4)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses, mem = [], []
+    for i in range(steps):
+        out = tr.train_step(datas[i % 4])
+        if i % (steps // 6) == 0:
+            losses.append(float(out["loss"]))
+            mem.append(round(torch.cuda.max_memory_allocated() / 1e9, 2))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = tr.flat.params
+    print("graph" if use_graph else "eager", "steps/s", round(steps / dt, 1), "losses", [round(v, 5) for v in losses], "finite params",
+          bool(torch.isfinite(p).all()), "mem GB", mem)
+    assert torch.isfinite(p).all() and losses[-1] < losses[0]
+    del tr
+    torch.cuda.empty_cache()
