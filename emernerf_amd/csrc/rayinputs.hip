@@ -1,15 +1,18 @@
 // Per-ray side of the colour heads: everything that is evaluated once per RAY (8192 rows) instead of once per sample.
 //
-//   emer_ray_inputs_fwd   [dir-PE | appearance embedding] rows of the rgb head (remapped directions) and of the sky head
-//                         (raw directions) in one launch        (radiance_field.py:622-643, 660-674; encodings.py:86-104)
-//   emer_embed_grad       gradient of the embedding table: a deterministic per-row segment sum of both consumers' input
-//                         gradients (replaces autograd's add + zero fill + atomic index_add)
-//   emer_ray_pre_fwd/bwd  the per-ray operand's share of the rgb head's layers 0 and 1 (mlp.py:38-46 with
-//                         skip_connections=[1]): pre-activation offsets rb = [W0[:, :Kh] h + b0 | W1[:, H:H+Kh] h + b1]
-//                         and d h = s0 W0[:, :Kh] + s1 W1[:, H:H+Kh], reading the weight blocks in place (row strides).
+//   emer_ray_inputs_fwd     [dir-PE | appearance embedding] rows of the rgb head (remapped directions) and of the sky head
+//                           (raw directions) in one launch        (radiance_field.py:622-643, 660-674; encodings.py:86-104)
+//   emer_embed_grad         gradient of the embedding table: a deterministic per-row segment sum of both consumers' input
+//                           gradients (replaces autograd's add + zero fill + atomic index_add)
+//   emer_ray_pre_fwd/bwd    the per-ray operand's share of the rgb head's layers 0 and 1 (mlp.py:38-46 with
+//                           skip_connections=[1]): pre-activation offsets rb = [W0[:, :Kh] h + b0 | W1[:, H:H+Kh] h + b1]
+//                           and d h = s0 W0[:, :Kh] + s1 W1[:, H:H+Kh], reading the weight blocks in place (row strides);
+//                           also the input's share of the sky head's layers 0 and 1
+//   emer_ray_head_fwd/bwd   the rest of the sky head (mlp.MLP, 3 layers, skip at 1, hidden 64) and its data gradients
+//   emer_ray_wgrad          weight / bias gradients of per-ray layers, several layers per launch
 //
-// 8192-row problems: a few MFLOP each, so plain VALU kernels with LDS-staged weights; what matters is that each is ONE
-// launch (the torch formulation was 4-6 launches apiece).
+// A few MFLOP each: what they cost is launches and memory LATENCY, so each is ONE launch (the torch / generic
+// formulation was 3-6 launches apiece) whose loads are issued in large independent batches.
 #include "common.h"
 
 namespace emer {
