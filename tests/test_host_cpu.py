@@ -232,3 +232,20 @@ def test_inputs_are_detached_outside_autograd_recording():
     with torch.no_grad():
         Probe.apply(*fused._ng(w))
     assert Probe.seen == (False, False)
+
+
+def test_ctypes_signatures_have_the_declared_arity():
+    """Every entry point is bound with as many ctypes argument types as its declaration in include/emernerf_hip.h has
+    parameters (a call with a stale argtypes list would pass the wrong registers to the kernel launch, silently)."""
+    from emernerf_amd import _lib
+    src = open(os.path.join(ROOT, "include", "emernerf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(emer_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)}
+    checked = 0
+    for table in (_lib.SIGNATURES, _lib.INT64_FUNCTIONS):
+        for name, argtypes in table.items():
+            params = decl[name].strip()
+            n = 0 if params in ("", "void") else params.count(",") + 1
+            assert n == len(argtypes), f"{name}: header declares {n} parameters, _lib binds {len(argtypes)}"
+            checked += 1
+    assert checked >= 60
