@@ -1,6 +1,7 @@
 """CPU tests (no GPU): the C-ABI library loads and exports exactly what include/emernerf_hip.h declares,
 host-side logic (level tables, schedules, flat buffers, proposal-loss restatement) and the N>1 data-parallel
 plumbing over gloo (world_size 2).  No kernel is launched here."""
+import ctypes
 import os
 import re
 import socket
@@ -247,5 +248,15 @@ def test_ctypes_signatures_have_the_declared_arity():
             params = decl[name].strip()
             n = 0 if params in ("", "void") else params.count(",") + 1
             assert n == len(argtypes), f"{name}: header declares {n} parameters, _lib binds {len(argtypes)}"
+            for i, (par, t) in enumerate(zip([q.strip() for q in params.split(",")], argtypes)):
+                if "*" in par:
+                    assert t is _lib._P or (isinstance(t, type) and issubclass(t, ctypes._Pointer)), \
+                        f"{name}: parameter {i} is `{par}` in the header but bound as {t}"
+                    continue
+                else:
+                    ctype = par.replace("const", "").split()[0] if par.replace("const", "").split()[0] != "unsigned" else "unsigned"
+                    want = {"int64_t": (ctypes.c_int64,), "int32_t": (ctypes.c_int32, ctypes.c_int), "int": (ctypes.c_int, ctypes.c_int32),
+                            "uint64_t": (ctypes.c_uint64,), "uint32_t": (ctypes.c_uint32,), "float": (ctypes.c_float,)}[ctype]
+                assert t in want, f"{name}: parameter {i} is `{par}` in the header but bound as {t}"
             checked += 1
     assert checked >= 60
