@@ -216,6 +216,32 @@ __global__ __launch_bounds__(256) void trunc_exp_bwd_kernel(const float *__restr
         dx[i * stride] = dy[i] * fminf(y[i], 3269017.3724721107f);  // g * exp(min(x - 1, 15))
 }
 
+// Temporal aggregation of the flow branch (radiance_field.py:553-620: features at the current, forward- and backward-warped
+// positions, evaluated as ONE 3 N-row batch): out[i] = (x[i] + 0.5 x[N + i] + 0.5 x[2 N + i]) / 2 -- the reference's expression,
+// term for term (the halvings are exact, so are the fused multiply-adds) -- and its backward dx = [g / 2 | g / 4 | g / 4].
+// float4 streams: one read of the three thirds and one write, instead of five elementwise launches each way and a 3 N-row cat.
+__global__ __launch_bounds__(256) void aggregate3_fwd_kernel(const float4 *__restrict__ x, int64_t n4, float4 *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = x[i], b = x[n4 + i], c = x[2 * n4 + i];
+        float4 r;
+        r.x = ((a.x + 0.5f * b.x) + 0.5f * c.x) / 2.0f;
+        r.y = ((a.y + 0.5f * b.y) + 0.5f * c.y) / 2.0f;
+        r.z = ((a.z + 0.5f * b.z) + 0.5f * c.z) / 2.0f;
+        r.w = ((a.w + 0.5f * b.w) + 0.5f * c.w) / 2.0f;
+        out[i] = r;
+    }
+}
+__global__ __launch_bounds__(256) void aggregate3_bwd_kernel(const float4 *__restrict__ g, int64_t n4, float4 *__restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g[i];
+        const float4 h = {v.x / 2.0f, v.y / 2.0f, v.z / 2.0f, v.w / 2.0f};
+        const float4 q = {0.5f * h.x, 0.5f * h.y, 0.5f * h.z, 0.5f * h.w};
+        dx[i] = h;
+        dx[n4 + i] = q;
+        dx[2 * n4 + i] = q;
+    }
+}
+
 static inline uint32_t stream_blocks(int64_t n) {
     const int64_t b = ceil_div(n, 256);
     return (uint32_t)(b < 2048 ? b : 2048);
@@ -335,3 +361,21 @@ extern "C" int emer_cast_f32_f16(const float *src, void *dst_f16, int64_t n, voi
     return emer::check_launch("cast_f32_f16");
 }
 
+
+extern "C" int emer_aggregate3_fwd(const float *x3, int64_t n, float *out, void *stream) {
+    EMER_REQUIRE(n >= 0 && n % 4 == 0, "aggregate3_fwd: the element count of one third must be a multiple of 4");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x3 && out && (uintptr_t)x3 % 16 == 0 && (uintptr_t)out % 16 == 0, "aggregate3_fwd: null or unaligned pointer");
+    hipLaunchKernelGGL(aggregate3_fwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(x3), n / 4,
+                       reinterpret_cast<float4 *>(out));
+    return check_launch("aggregate3_fwd");
+}
+
+extern "C" int emer_aggregate3_bwd(const float *g, int64_t n, float *dx3, void *stream) {
+    EMER_REQUIRE(n >= 0 && n % 4 == 0, "aggregate3_bwd: the element count of one third must be a multiple of 4");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(g && dx3 && (uintptr_t)g % 16 == 0 && (uintptr_t)dx3 % 16 == 0, "aggregate3_bwd: null or unaligned pointer");
+    hipLaunchKernelGGL(aggregate3_bwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(g), n / 4,
+                       reinterpret_cast<float4 *>(dx3));
+    return check_launch("aggregate3_bwd");
+}

@@ -745,6 +745,34 @@ def trunc_exp_column(feats: Tensor, col: int = 0) -> Tensor:
     return _TruncExpFn.apply(feats.contiguous(), col)
 
 
+class _Aggregate3Fn(torch.autograd.Function):
+    """(cur + 0.5 fwd + 0.5 bwd) / 2 of a [3 N, C] batch laid out [current | forward-warped | backward-warped]
+    (temporal_aggregation, radiance_field.py:553-620) -> [N, C]; one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x3: Tensor):
+        x = _f32c(x3)
+        n3, C = x.shape
+        assert n3 % 3 == 0 and (n3 // 3 * C) % 4 == 0
+        with torch.cuda.device(x.device):
+            out = torch.empty((n3 // 3, C), device=x.device, dtype=torch.float32)
+            _lib.call("emer_aggregate3_fwd", _ptr(x), out.numel(), _ptr(out), _stream(x))
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        gc = _f32c(g)
+        with torch.cuda.device(gc.device):
+            dx = torch.empty((3 * gc.shape[0], gc.shape[1]), device=gc.device, dtype=torch.float32)
+            _lib.call("emer_aggregate3_bwd", _ptr(gc), gc.numel(), _ptr(dx), _stream(gc))
+        return dx
+
+
+def aggregate3(x3: Tensor) -> Tensor:
+    _check_cuda(x3)
+    return _Aggregate3Fn.apply(x3)
+
+
 def dir_encode(dirs: Tensor, max_deg: int = 4, remap: bool = True) -> Tensor:
     """SinusoidalEncoder(3, 0, max_deg); remap=True applies (dirs+1)/2 first (radiance_field.py:629; no grad)."""
     _check_cuda(dirs)

@@ -447,13 +447,22 @@ class RadianceField(nn.Module):
         # (3) dynamic table: one evaluation of 3N samples, one neck
         enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0), skip_dx_rows=N)  # the current positions carry no gradient
         geo3, sem3, _ = fused.neck(enc3, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
-        feats3 = geo3 if sem3 is None else torch.cat([geo3, sem3], dim=-1)
-        cur_f, fwd_f, bwd_f = (t.view(*lead, -1) for t in feats3.split(N, dim=0))
+        # temporal aggregation (:595-613) per feature half, straight from the 3N-row batch: one launch each way, no [., 128]
+        # concatenation and no 3N-row cat in the backward
+        agg_ok = (N * 64) % 4 == 0
+        if agg_ok:
+            dyn = ops.aggregate3(geo3).view(*lead, -1)
+            if sem3 is not None:
+                dyn = (dyn, ops.aggregate3(sem3).view(*lead, -1))  # forward() takes the pair as (geometry, semantic) features
+        else:
+            feats3 = geo3 if sem3 is None else torch.cat([geo3, sem3], dim=-1)
+            cur_f, fwd_f, bwd_f = (t.view(*lead, -1) for t in feats3.split(N, dim=0))
+            dyn = (cur_f + 0.5 * fwd_f + 0.5 * bwd_f) / 2.0
         # (4) flow table at both warped sets: one evaluation of 2N samples
         flow2 = fused.seq_mlp_lm(enc_f.forward_level_major(torch.cat([x_fwd, x_bwd], dim=0)), fw, fb)
         fwd_pred, bwd_pred = (t.view(*lead, 6) for t in flow2.split(N, dim=0))
         out = {"forward_flow": forward_flow, "backward_flow": backward_flow,
-               "dynamic_feats": (cur_f + 0.5 * fwd_f + 0.5 * bwd_f) / 2.0,
+               "dynamic_feats": dyn,
                "forward_pred_backward_flow": fwd_pred[..., 3:], "backward_pred_forward_flow": bwd_pred[..., :3]}
         if want_hash:  # row-major copies of the encodings: part of forward()'s contract (:453-459, 615-617), consumed by nobody
             cur_h, fwd_h, bwd_h = (t.view(*lead, -1) for t in ops.lm_to_rm(enc3).split(N, dim=0))
@@ -625,7 +634,12 @@ class RadianceField(nn.Module):
             if batched is not None:
                 dynamic_feats = batched["dynamic_feats"]
                 results_dict.update(batched)
-                dynamic_density = ops.trunc_exp_column(dynamic_feats, 0)
+                if isinstance(dynamic_feats, tuple):  # (geometry, semantic) halves kept apart: the reference's tensor on request only
+                    if hash_encodings:
+                        results_dict["dynamic_feats"] = torch.cat(dynamic_feats, dim=-1)
+                    else:
+                        del results_dict["dynamic_feats"]
+                dynamic_density = ops.trunc_exp_column(dynamic_feats[0] if isinstance(dynamic_feats, tuple) else dynamic_feats, 0)
             else:
                 dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
                     normed_positions, normed_timestamps, want_density=not use_flow, want_hash=use_flow)

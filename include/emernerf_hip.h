@@ -460,6 +460,12 @@ int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, vo
 int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_stride, int64_t n,
                        void *stream);
 
+/* Temporal aggregation of the flow branch (radiance_field.py:553-620) on a batch laid out [current | forward-warped |
+ * backward-warped]: x3 holds three thirds of n floats each (n % 4 == 0, 16-byte aligned),
+ *   fwd: out[i] = (x3[i] + 0.5 x3[n + i] + 0.5 x3[2 n + i]) / 2          bwd: dx3 = [g / 2 | g / 4 | g / 4]. */
+int emer_aggregate3_fwd(const float *x3, int64_t n, float *out, void *stream);
+int emer_aggregate3_bwd(const float *g, int64_t n, float *dx3, void *stream);
+
 /* Direction encoding used by the rgb / sky heads: d -> (d+1)/2 -> [x, sin(2^i x), sin(2^i x + pi/2)]
  * i = 0..max_deg (radiance_fields/encodings.py:60-104, radiance_field.py:629-632).
  * dirs [n,3] -> out [n, 3*(1+2*(max_deg+1))].  remap != 0 applies the (d+1)/2 step first. */

@@ -820,3 +820,19 @@ def test_ray_wgrad_matches_fp64(hip_lib, M):
     chk(dw1, want1)  # columns H .. H+10 untouched
     chk(db1, 1.0 + d1.double().sum(0))
     chk(dw0, 1.0 + d0.double().T @ x.double())
+
+
+@pytest.mark.parametrize("N,C", [(1000, 64), (3, 4), (4096, 64)])
+def test_aggregate3_matches_the_reference_expression(hip_lib, N, C):
+    """emer_aggregate3: (cur + 0.5 fwd + 0.5 bwd) / 2 of a [cur | fwd | bwd] batch, bit for bit the reference's expression
+    (radiance_field.py:595-613), and its backward [g/2 | g/4 | g/4]."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + C)
+    x3 = torch.randn(3 * N, C, generator=g).to(dev).requires_grad_(True)
+    out = ops.aggregate3(x3)
+    cur, fwd, bwd = x3.detach().split(N, dim=0)
+    assert torch.equal(out, (cur + 0.5 * fwd + 0.5 * bwd) / 2.0)
+    up = torch.randn(N, C, generator=g).to(dev)
+    (dx,) = torch.autograd.grad(out, x3, up)
+    assert torch.equal(dx, torch.cat([up / 2.0, 0.5 * (up / 2.0), 0.5 * (up / 2.0)], 0))
