@@ -6,8 +6,9 @@ Mirrors the rendering half of the reference's radiance_fields/video_utils.py: ``
 gt_rgbs, depths, opacities, static_* / dynamic_* decomposition, shadow_reduced_static_rgbs, flows, sky_masks ...).
 
 What changed underneath: an image's rays come from ``PixelSource.get_render_rays`` (one gather kernel), all chunks of an
-image are rendered before any result leaves the GPU (the reference interleaves ``.cpu().numpy()`` with rendering), and
-PSNR is computed on the device.  Out of scope here, as in SURVEY section 2: video encoding, SSIM (scikit-image), DINO-feature PCA colouring.
+image are rendered before any result leaves the GPU, an image's results leave it as ONE asynchronous transfer that overlaps
+the next image's rendering (the reference interleaves a blocking ``.cpu().numpy()`` per key with the rendering), and PSNR is
+computed on the device.  Out of scope here, as in SURVEY section 2: video encoding, SSIM (scikit-image), DINO-feature PCA colouring.
 """
 from __future__ import annotations
 
@@ -35,6 +36,36 @@ _COLLECT = {"rgb": "rgbs", "static_rgb": "static_rgbs", "shadow_reduced_static_r
 def compute_psnr(prediction: Tensor, target: Tensor) -> float:
     """datasets/metrics.py:31-46."""
     return float(-10.0 * torch.log10(torch.nn.functional.mse_loss(prediction, target)))
+
+
+def _pack_to_host(keep: Dict[str, Tensor], pinned: Dict[int, Tensor], slot: int):
+    """Start the transfer of one image's results: (names, shapes, dtypes, host buffer, event)."""
+    names = list(keep)
+    parts = [keep[n].squeeze() for n in names]
+    flat = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]) if parts else None
+    if flat is None:
+        return names, [], [], None, None
+    buf = pinned.get(slot)
+    if buf is None or buf.numel() < flat.numel():
+        buf = pinned[slot] = torch.empty((flat.numel(),), dtype=torch.float32, pin_memory=True)
+    host = buf[:flat.numel()]
+    host.copy_(flat, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return names, [tuple(p.shape) for p in parts], [p.dtype for p in parts], host, ev
+
+
+def _unpack(item, out: Dict[str, list]) -> None:
+    names, shapes, dtypes, host, ev = item
+    if host is None:
+        return
+    ev.synchronize()
+    arr, o = host.numpy(), 0
+    for name, shape, dt in zip(names, shapes, dtypes):
+        n = int(np.prod(shape)) if len(shape) else 1
+        a = arr[o:o + n].reshape(shape).copy()  # the pinned buffer is reused two images later
+        out[name].append(a if dt == torch.float32 else a.astype(torch.empty((), dtype=dt).numpy().dtype))
+        o += n
 
 
 def render_pixels(cfg, model: RadianceField, proposal_estimator: PropNetEstimator, dataset,
@@ -70,8 +101,10 @@ def render(dataset, render_func: Callable, model: Optional[RadianceField] = None
               "dynamic_opacities"]
     out: Dict[str, list] = {v: [] for v in _COLLECT.values()}
     out.update({"gt_rgbs": [], "dynamic_rgbs": [], "median_depths": [], "gt_sky_masks": []})
-    psnrs: List[float] = []
-    n_rays, t0 = 0, time.perf_counter()
+    psnrs: List[Tensor] = []
+    pending: list = []
+    pinned: Dict[int, Tensor] = {}
+    n_rays, n_images, t0 = 0, 0, time.perf_counter()
     green = None
     with torch.no_grad():
         indices = vis_indices if vis_indices is not None else range(len(dataset))
@@ -93,15 +126,22 @@ def render(dataset, render_func: Callable, model: Optional[RadianceField] = None
                 keep["gt_rgbs"] = data["pixels"]
             if "sky_masks" in data:
                 keep["gt_sky_masks"] = data["sky_masks"]
-            if compute_metrics and "pixels" in data:
-                psnrs.append(compute_psnr(res["rgb"], data["pixels"]))
-            for name, t in keep.items():  # one squeeze + device->host copy per key, after the image is complete
-                out[name].append(t.squeeze().cpu().numpy())
+            if compute_metrics and "pixels" in data:  # stays on the device until the loop is over (no sync per image)
+                psnrs.append(-10.0 * torch.log10(torch.nn.functional.mse_loss(res["rgb"], data["pixels"])))
+            # ONE device->host transfer per image: every kept tensor packed into a flat buffer, copied asynchronously into
+            # pinned memory and unpacked while the NEXT image renders (the reference interleaves a blocking .cpu().numpy() per
+            # key with the rendering; on a slow host that halves the loop's throughput)
+            pending.append(_pack_to_host(keep, pinned, n_images & 1))  # two alternating pinned buffers
+            n_images += 1
+            if len(pending) > 1:
+                _unpack(pending.pop(0), out)
+        while pending:
+            _unpack(pending.pop(0), out)
     torch.cuda.synchronize()
     out = {k: v for k, v in out.items() if len(v) > 0 or k in always}
     dt = time.perf_counter() - t0
     out["render_rays_per_s"] = n_rays / dt if dt > 0 else float("nan")
-    out["psnr"] = (float(np.mean(psnrs)) if psnrs else -1.0) if compute_metrics else -1
+    out["psnr"] = (float(torch.stack(psnrs).mean()) if psnrs else -1.0) if compute_metrics else -1
     for k in ("ssim", "feat_psnr", "masked_psnr", "masked_ssim", "masked_feat_psnr"):
         out[k] = -1
     return out
