@@ -130,7 +130,10 @@ def _check_finite_grid_grad(dlm: Tensor, desc: GridDesc) -> None:
     backward reduces runs of equal cells with 0/1-masked multiply-adds, so ONE non-finite entry of the incoming gradient
     contaminates other table entries of its wave (0 x inf = NaN; upstream's atomics keep it in the sample's own cells): looking
     at the table gradient afterwards points at the wrong entries.  This check names the offending (level, sample) pairs BEFORE
-    the scatter; it costs one reduction over the gradient and a host read, so it is off by default."""
+    the scatter; it costs one reduction over the gradient and a host read, so it is off by default (and skipped while a hipGraph
+    is being captured: a host read is not capturable -- run the step eagerly, ``Trainer(use_graph=False)``, to use it)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
     bad = ~torch.isfinite(dlm)
     if bool(bad.any()):
         idx = torch.nonzero(bad.any(dim=-1))[:8].tolist()
