@@ -41,31 +41,14 @@ def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
 
 def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
     """Oracle port (oracle/ref_path.py on the C oracle) timed on this box's host cores, bounded sample."""
-    from oracle import oracle as O
-    from oracle.ref_path import RefPath
-    from emernerf_amd.trainer import AABB, PROP_KW, synthetic_rays
+    from oracle.train_parity import cotrain, ref_from_trainer
+    from emernerf_amd.trainer import synthetic_rays
     cores = min(os.cpu_count() or 1, 32)  # more threads only add torch/OpenMP overhead at this sample size
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    c = trainer.cfg
-    grids = {"model/xyz_encoder": O.grid_meta_from_encoder_args(3, c.xyz_encoder.n_levels, c.xyz_encoder.base_resolution,
-                                                                 c.xyz_encoder.max_resolution, c.xyz_encoder.log2_hashmap_size,
-                                                                 c.xyz_encoder.n_features_per_level)}
-    for i, kw in enumerate(PROP_KW):
-        grids[f"prop{i}/xyz_encoder"] = O.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
-                                                                      kw["log2_hashmap_size"], kw["n_features_per_level"])
-    ms = {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}
-    ps = [{k: v.detach().cpu() for k, v in p.state_dict().items()} for p in trainer.props]
-    ref = RefPath(ms, ps, grids, AABB)
-    opt_main = torch.optim.Adam(ref.trainable("model/"), lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
-    opt_prop = torch.optim.Adam(ref.trainable("prop"), lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
+    ref = ref_from_trainer(trainer)
     data = synthetic_rays(rays, "cpu", seed=123)
-    g = torch.Generator().manual_seed(7)
     prop_samples = trainer.rcfg.nerf.propnet.num_samples_per_prop
-
-    def one(prop_grad):
-        jit = [torch.rand(rays, generator=g) for _ in range(len(prop_samples) + 1)]
-        ref.train_step(data, opt_main, opt_prop, samples, prop_samples, jitters=jit, prop_grad=prop_grad)
 
     # PSNR of the HIP path vs the oracle on identical rays / parameters (the second half of BASELINE.json's metric):
     # eval-mode render (no stratified jitter), composited rgb, -10 log10(mse); depth as relative error
@@ -83,15 +66,25 @@ def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
     mse = float(((hip["rgb"].cpu().double() - orc["rgb"].double()) ** 2).mean())
     psnr = float("inf") if mse == 0.0 else -10.0 * math.log10(mse)
     depth_rel = float(((hip["depth"].cpu().double() - orc["depth"].double()).abs() / orc["depth"].double().abs().clamp_min(1e-6)).max())
-    one(True)   # warm-up both step types (allocations, OpenMP pool)
-    one(False)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(i % 6 == 0)
-    dt = time.perf_counter() - t0
-    return {"value": rays * steps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    # The timed sample IS a K-step training job on rays coloured by a synthetic ground-truth field, run by the oracle and by the
+    # HIP path from identical parameters with replayed jitter (oracle/train_parity.py; tests/test_train_parity_gpu.py holds the
+    # assertions): 2 warm-up + `steps` timed oracle steps, 1 step in 6 training the proposal nets, then the PSNR of an evaluation
+    # render of each against the ground truth -- the second half of BASELINE.json's metric ("PSNR vs ref" after K steps).
+    K = steps + 2
+    co = cotrain(trainer.kind, trainer.device, K=K, rays=rays, samples=samples,
+                 prop_samples=tuple(prop_samples), num_iters=200, table_init=0.3, use_graph=False, schedule_steps=1, time_oracle_from=2)
+    dt = co["oracle_s_per_step"] * steps
+    return {"value": rays / co["oracle_s_per_step"], "unit": "rays/s", "cores": cores, "kind": "port",
             "psnr_vs_oracle_db": min(psnr, 999.0), "depth_max_rel_err_vs_oracle": depth_rel,
-            "sample": f"{steps} full optimizer steps of {rays} rays x {samples} samples (same model/config, 1 in 6 steps "
+            "psnr_vs_gt_after_k": {"K": K, "hip_db": co["hip_psnr_vs_gt_db"], "oracle_db": co["ref_psnr_vs_gt_db"],
+                                   "loss_first_last_hip": [co["hip_losses"][0], co["hip_losses"][-1]],
+                                   "loss_first_last_oracle": [co["ref_losses"][0], co["ref_losses"][-1]],
+                                   "loss_max_rel_diff": co["loss_max_rel_diff"], "param_l2_diff_over_travel": co["param_l2_diff"] / co["travel"],
+                                   "note": "both trained for K optimizer steps from identical parameters on rays rendered from a fixed synthetic GT "
+                                           "field (second random-table model), jitter replayed; PSNR of an eval render of 2048 held-out rays vs the GT"},
+            "deviation": "BASELINE.md 2.4 names configs[0] (L4 grid, 4096 x 64) for the CPU figure; this is the SAME model as the GPU line (configs[1]: "
+                         f"L16/F2/T2^19 grid, full heads, proposal rounds 128 + 64) on a bounded sample of {rays} rays x {samples} samples",
+            "sample": f"{steps} full optimizer steps (after 2 warm-up steps) of {rays} rays x {samples} samples (same model/config, 1 in 6 steps "
                       f"trains the proposal nets), oracle/ref_path.py on oracle/emer_oracle.c, torch {torch.get_num_threads()} "
                       f"threads + OpenMP; {dt:.1f} s"}
 
@@ -151,21 +144,27 @@ def rccl_summary(path, world):
     return {"world_size": world, "backend": "nccl (RCCL)", "log_lines_total": n, "log_excerpt": keep}
 
 
-def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: int, init_steps: int, start_step: int = 1000):
+def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: int, init_steps: int, start_step: int = 1000,
+                   use_graph: bool = False):
     """A short run of another BASELINE config on this GPU (rank 0, single GPU): ms/step, rays/s and the roofline of its xyzt
-    encoders, with the same step definition as the headline (full optimizer step, a new seeded batch every step)."""
+    encoders, with the same step definition AND the same launch mode as the headline (full optimizer step, a new seeded batch
+    every step; ``use_graph``: forward + backward replayed as a captured hipGraph).  The grid kernels are bracketed by HIP events
+    in an eager loop (a replay launches nothing from the host); in graph mode that is a second loop after the timed one."""
     from emernerf_amd import _lib
     from emernerf_amd.trainer import Trainer, synthetic_rays
-    tr = Trainer(kind=kind, device=dev, num_samples=samples, world_size=1)
-    tr.step_count = start_step
+    tr = Trainer(kind=kind, device=dev, num_samples=samples, world_size=1, use_graph=use_graph)
+    tr.set_step(start_step)
     for s_ in range(start_step):
         tr.requires_grad_fn(s_)
     kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
     batches = [synthetic_rays(rays, dev, seed=3000 + i, **kw) for i in range(4)]
     for i in range(init_steps + warmup):
         tr.train_step(batches[i % 4])
-    timer = _lib.KernelTimer(["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input"])
-    _lib.TIMER = timer
+    names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input"]
+    timer = _lib.KernelTimer(names)
+    graphed = tr.use_graph   # (False if the capture failed: Trainer falls back to eager launches with a warning)
+    if not graphed:
+        _lib.TIMER = timer
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -173,9 +172,22 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     _lib.TIMER = None
+    out = {"kind": kind, "rays": rays, "samples": samples, "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": rays / dt,
+           "launch_mode": "hipGraph replay of forward+backward" if graphed else "eager"}
+    if graphed:   # the event-bracketed eager loop for the grid kernels' durations (and the eager step time next to the replayed one)
+        tr.use_graph = False
+        for i in range(2):
+            tr.train_step(batches[i % 4])
+        _lib.TIMER = timer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.train_step(batches[i % 4])
+        torch.cuda.synchronize()
+        out["eager_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+        _lib.TIMER = None
     us, tags = timer.elapsed_us(), timer.tags
     N = rays * samples
-    out = {"kind": kind, "rays": rays, "samples": samples, "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": rays / dt}
     dyn = tr.cfg.dynamic_xyz_encoder
     D4, L4, F4 = dyn.n_input_dims, dyn.n_levels, dyn.n_features_per_level
     f4 = [u for u, tg in zip(us["emer_hashgrid_fwd"], tags["emer_hashgrid_fwd"]) if tg == (D4, L4, F4)]
@@ -266,7 +278,7 @@ def main():
 
     trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
                       use_graph=args.graph, table_dtype=args.table_dtype)
-    trainer.step_count = args.start_step
+    trainer.set_step(args.start_step)
     # advance the proposal schedule to its state at start_step
     fn = trainer.requires_grad_fn
     for s in range(args.start_step):
@@ -409,24 +421,37 @@ def main():
     clustered = None
     if rank == 0 and args.table_init is None and not args.no_second_state:
         t2 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_init=0.3)
-        t2.step_count = args.start_step
+        t2.set_step(args.start_step)
         for s_ in range(args.start_step):
             t2.requires_grad_fn(s_)
         for _ in range(18):
             t2.train_step(next_batch())
         clustered = _lib.KernelTimer(grid_names)
         _lib.TIMER = clustered
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
         for _ in range(12):
             t2.train_step(next_batch())
         torch.cuda.synchronize()
+        clustered_ms = (time.perf_counter() - t_c) / 12 * 1e3   # eager launches with the grid kernels bracketed by events
         _lib.TIMER = None
+        if world == 1:   # ... and the same state in the headline's launch mode
+            t2.use_graph = args.graph
+            for _ in range(8):
+                t2.train_step(next_batch())
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            for _ in range(12):
+                t2.train_step(next_batch())
+            torch.cuda.synchronize()
+            clustered_ms = {"eager_instrumented": clustered_ms, "hipgraph" if t2.use_graph else "eager": (time.perf_counter() - t_c) / 12 * 1e3}
         del t2
     # BASELINE configs[1] names fp16 tables; the headline runs the reference's fp32.  A third short run with half-precision tables
     # (fp32 master cast per call, fp32 gradient accumulation) reports the grid pair of THAT mode next to it.
     fp16_state = None
     if rank == 0 and world == 1 and args.table_dtype == "f32" and args.kind == "static" and not args.no_fp16_state:
         t3 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_dtype="f16")
-        t3.step_count = args.start_step
+        t3.set_step(args.start_step)
         for s_ in range(args.start_step):
             t3.requires_grad_fn(s_)
         for _ in range(18):
@@ -452,7 +477,7 @@ def main():
         # ... and configs[4] (flow + feature head) at its 2048-ray shard
         for kind_, rays_ in (("dynamic", args.rays), ("flow", args.rays), ("flow", max(args.rays // 4, 256)), ("feature", max(args.rays // 4, 256))):
             try:
-                secondary.append(measure_config(kind_, rays_, args.samples, dev, steps=ss, warmup=4, init_steps=14))
+                secondary.append(measure_config(kind_, rays_, args.samples, dev, steps=ss, warmup=4, init_steps=14, use_graph=args.graph))
             except Exception as e:  # reporting only
                 secondary.append({"kind": kind_, "rays": rays_, "error": repr(e)})
     if world > 1:
@@ -487,7 +512,7 @@ def main():
             b2 = [u for u, tg in zip(us2["emer_hashgrid_bwd_params_sliced"], tg2["emer_hashgrid_bwd_params_sliced"]) if tg == (D, L, F)]
             if f2 and b2:
                 fa, ba = sum(f2) / len(f2), sum(b2) / len(b2)
-                roof2 = {"table_init": 0.3, "bound": "hbm", "kernel": "emer_hashgrid_bwd_params_sliced", "avg_us": ba,
+                roof2 = {"table_init": 0.3, "ms_per_step": clustered_ms, "bound": "hbm", "kernel": "emer_hashgrid_bwd_params_sliced", "avg_us": ba,
                          "achieved": bwd_b * N / (ba * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bwd_b * N / (ba * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "grid_encode_plus_bwd": {"fwd_avg_us": fa, "bwd_avg_us": ba,
@@ -539,8 +564,9 @@ def main():
             k0 = L * F
             n_out = trainer.model.base_mlp[2].out_features
             dgrad_neck, wgrad_neck = 2.0 * N * (64 * 64 + 64 * k0), 2.0 * N * (64 * n_out + 64 * k0)
-            flops = {"emer_neck_fwd": (2.0 * N * (k0 * 64 + 64 * n_out), 6.0),
-                     "emer_neck_bwd": (dgrad_neck, 6.0),
+            # (no "emer_neck_fwd" entry: in the static step the main neck runs inside emer_field_fwd, and the emer_neck_fwd launches
+            # that remain are the proposal nets' 8 -> 64 -> 1 density MLPs on exact-fp32 matrix instructions)
+            flops = {"emer_neck_bwd": (dgrad_neck, 6.0),
                      "emer_neck_bwd_fused": (dgrad_neck + wgrad_neck, None),
                      "emer_rgb_head_fwd": (2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),
                      "emer_field_fwd": (2.0 * N * (k0 * 64 + 64 * 64) + 2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),  # neck + rgb head in one launch

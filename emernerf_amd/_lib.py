@@ -65,6 +65,9 @@ SIGNATURES = {
     "emer_ray_epilogue_bwd": [_P, _P, _P, _P, _P, c_int64, _P, _P, _P],
     "emer_pixel_loss_fwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],
     "emer_pixel_loss_bwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P, _P],
+    "emer_reg_losses_fwd": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P],
+    "emer_reg_losses_bwd": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, _P, _P, c_int64, c_float, _P, c_float,
+                            _P, _P, _P, _P, _P, _P],
     "emer_lidar_loss": [_P, _P, _P, _P, c_int64, c_int32, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],

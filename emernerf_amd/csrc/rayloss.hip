@@ -173,6 +173,104 @@ __global__ __launch_bounds__(256) void lidar_loss_kernel(const float *__restrict
     if (lane == 0) loss_rays[r] = l + scale * acc;
 }
 
+// ------------------------------------------------------------------------------------------------ regularisers
+// The mean-type regularisers of the dynamic / flow / feature models:
+//   dynamic-density sparsity  c * mean(dynamic_density [R,S])                 loss/base.py:394-398 ("sparsity", no mask),
+//   shadow sparsity           c * mean(shadow_ratio [R,1])                    same class (train_emernerf.py:689-694),
+//   feature L2                c * mean((dino_feat - features)^2 [R,E])        loss/base.py:83-146 (train_emernerf.py:676-682),
+//   flow cycle consistency    c * mean((ff + fpb)^2 + (bf + bpf)^2 [R,S,3])   train_emernerf.py:700-716 (ff / bf detached there:
+//                                                                              gradients go to the two predictions only).
+// The reference evaluates each as a chain of elementwise torch ops, a mean and a scalar multiply-add (~25 launches with their
+// autograd twins); here all four are one streaming pass each way.  Fixed summation order: per-thread strided sums, wave / block
+// tree, per-block partials summed by one workgroup in double.
+struct RegArgs {
+    const float *dyn; int64_t n_dyn; float c_dyn;
+    const float *shadow; int64_t n_shadow; float c_shadow;
+    const float *feat, *feat_gt; int64_t n_feat; float c_feat;
+    const float *ff, *fpb, *bf, *bpf; int64_t n_flow; float c_cycle;
+};
+
+constexpr int kRegThreads = 256;
+
+__global__ __launch_bounds__(kRegThreads) void reg_losses_fwd_kernel(const RegArgs a, float *__restrict__ partials) {
+    const int64_t tid = (int64_t)blockIdx.x * kRegThreads + threadIdx.x, stride = (int64_t)gridDim.x * kRegThreads;
+    float l = 0.0f;
+    if (a.dyn) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < a.n_dyn; i += stride) s += a.dyn[i];
+        l += a.c_dyn / (float)a.n_dyn * s;
+    }
+    if (a.shadow) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < a.n_shadow; i += stride) s += a.shadow[i];
+        l += a.c_shadow / (float)a.n_shadow * s;
+    }
+    if (a.feat) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < a.n_feat; i += stride) { const float d = a.feat[i] - a.feat_gt[i]; s += d * d; }
+        l += a.c_feat / (float)a.n_feat * s;
+    }
+    if (a.fpb) {
+        float s = 0.0f;
+        for (int64_t i = tid; i < a.n_flow; i += stride) {
+            const float u = a.ff[i] + a.fpb[i], v = a.bf[i] + a.bpf[i];
+            s += u * u + v * v;
+        }
+        l += a.c_cycle / (float)a.n_flow * s;
+    }
+    __shared__ float part[kRegThreads / 64];
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kRegThreads / 64; ++w) t += part[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// out[0] = (base ? base[0] : 0) + sum(partials[0..n)), one workgroup, fixed order, double accumulation
+__global__ __launch_bounds__(256) void reg_losses_finish_kernel(const float *__restrict__ partials, int32_t n, const float *__restrict__ base,
+                                                                float *__restrict__ out) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((base ? (double)base[0] : 0.0) + ((part[0] + part[1]) + (part[2] + part[3])));
+}
+
+// gradients of the four terms times up = upstream[0] * grad_scale; every output pointer may be null
+__global__ __launch_bounds__(kRegThreads) void reg_losses_bwd_kernel(const RegArgs a, const float *__restrict__ upstream, float grad_scale,
+                                                                     float *__restrict__ d_dyn, float *__restrict__ d_shadow,
+                                                                     float *__restrict__ d_feat, float *__restrict__ d_fpb,
+                                                                     float *__restrict__ d_bpf) {
+    const int64_t tid = (int64_t)blockIdx.x * kRegThreads + threadIdx.x, stride = (int64_t)gridDim.x * kRegThreads;
+    const float up = (upstream ? upstream[0] : 1.0f) * grad_scale;
+    if (d_dyn) {
+        const float g = up * (a.c_dyn / (float)a.n_dyn);
+        for (int64_t i = tid; i < a.n_dyn; i += stride) d_dyn[i] = g;
+    }
+    if (d_shadow) {
+        const float g = up * (a.c_shadow / (float)a.n_shadow);
+        for (int64_t i = tid; i < a.n_shadow; i += stride) d_shadow[i] = g;
+    }
+    if (d_feat) {
+        const float g = up * (2.0f * a.c_feat / (float)a.n_feat);
+        for (int64_t i = tid; i < a.n_feat; i += stride) d_feat[i] = g * (a.feat[i] - a.feat_gt[i]);
+    }
+    if (d_fpb || d_bpf) {
+        const float g = up * (2.0f * a.c_cycle / (float)a.n_flow);
+        for (int64_t i = tid; i < a.n_flow; i += stride) {
+            if (d_fpb) d_fpb[i] = g * (a.ff[i] + a.fpb[i]);
+            if (d_bpf) d_bpf[i] = g * (a.bf[i] + a.bpf[i]);
+        }
+    }
+}
+
 }  // namespace emer
 
 using namespace emer;
@@ -232,4 +330,53 @@ extern "C" int emer_lidar_loss(const float *depth, const float *lidar_ranges, co
     if (int rc = check_launch("lidar_loss")) return rc;
     if (loss_out) return emer_reduce_sum(workspace, n_rays, 0, loss_out, stream);
     return EMER_OK;
+}
+
+static inline RegArgs make_reg_args(const float *dyn, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
+                                    const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *ff, const float *fpb,
+                                    const float *bf, const float *bpf, int64_t n_flow, float c_cycle) {
+    return RegArgs{dyn, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, ff, fpb, bf, bpf, n_flow, c_cycle};
+}
+static inline uint32_t reg_blocks(const RegArgs &a) {
+    int64_t n = 1;
+    if (a.dyn && a.n_dyn > n) n = a.n_dyn;
+    if (a.shadow && a.n_shadow > n) n = a.n_shadow;
+    if (a.feat && a.n_feat > n) n = a.n_feat;
+    if (a.fpb && a.n_flow > n) n = a.n_flow;
+    const int64_t b = ceil_div(n, (int64_t)kRegThreads * 4);   // >= 4 elements per thread; at most 1024 blocks
+    return (uint32_t)(b < 1 ? 1 : b > EMER_REG_MAX_BLOCKS ? EMER_REG_MAX_BLOCKS : b);
+}
+static bool reg_args_ok(const RegArgs &a) {
+    return (!a.dyn || a.n_dyn >= 1) && (!a.shadow || a.n_shadow >= 1) && (!a.feat || (a.feat_gt && a.n_feat >= 1)) &&
+           (!a.fpb || (a.ff && a.bf && a.bpf && a.n_flow >= 1));
+}
+
+extern "C" int emer_reg_losses_fwd(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
+                                   const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *fwd_flow,
+                                   const float *fwd_pred_bwd_flow, const float *bwd_flow, const float *bwd_pred_fwd_flow, int64_t n_flow,
+                                   float c_cycle, const float *base, float *workspace, float *loss_out, void *stream) {
+    const RegArgs a = make_reg_args(dyn_density, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, fwd_flow,
+                                    fwd_pred_bwd_flow, bwd_flow, bwd_pred_fwd_flow, n_flow, c_cycle);
+    EMER_REQUIRE(reg_args_ok(a), "reg_losses_fwd: a term's companion pointer is null or its count is < 1");
+    EMER_REQUIRE(workspace && loss_out, "reg_losses_fwd: null pointer");
+    const uint32_t blocks = reg_blocks(a);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(reg_losses_fwd_kernel, dim3(blocks), dim3(kRegThreads), 0, st, a, workspace);
+    hipLaunchKernelGGL(reg_losses_finish_kernel, dim3(1), dim3(256), 0, st, workspace, (int32_t)blocks, base, loss_out);
+    return check_launch("reg_losses_fwd");
+}
+
+extern "C" int emer_reg_losses_bwd(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
+                                   const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *fwd_flow,
+                                   const float *fwd_pred_bwd_flow, const float *bwd_flow, const float *bwd_pred_fwd_flow, int64_t n_flow,
+                                   float c_cycle, const float *upstream, float grad_scale, float *d_dyn_density, float *d_shadow,
+                                   float *d_feat, float *d_fwd_pred_bwd_flow, float *d_bwd_pred_fwd_flow, void *stream) {
+    const RegArgs a = make_reg_args(dyn_density, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, fwd_flow,
+                                    fwd_pred_bwd_flow, bwd_flow, bwd_pred_fwd_flow, n_flow, c_cycle);
+    EMER_REQUIRE(reg_args_ok(a), "reg_losses_bwd: a term's companion pointer is null or its count is < 1");
+    EMER_REQUIRE((!d_dyn_density || n_dyn >= 1) && (!d_shadow || n_shadow >= 1) && (!d_feat || feat) &&
+                 ((!d_fwd_pred_bwd_flow && !d_bwd_pred_fwd_flow) || fwd_pred_bwd_flow), "reg_losses_bwd: gradient requested for an absent term");
+    hipLaunchKernelGGL(reg_losses_bwd_kernel, dim3(reg_blocks(a)), dim3(kRegThreads), 0, as_stream(stream), a, upstream, grad_scale,
+                       d_dyn_density, d_shadow, d_feat, d_fwd_pred_bwd_flow, d_bwd_pred_fwd_flow);
+    return check_launch("reg_losses_bwd");
 }

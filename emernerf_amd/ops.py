@@ -125,14 +125,30 @@ def lm_to_rm(enc_lm: Tensor) -> Tensor:
 CHECK_FINITE = os.environ.get("EMER_CHECK_FINITE") == "1"
 
 
+DEFERRED_FINITE: list = []   # (grid name, N, any-bad flag, flat index of the first bad (level, sample)) recorded during a graph capture
+
+
+def check_deferred_finite(entries) -> None:
+    """Raise FloatingPointError if a replayed graph's recorded checks (see _check_finite_grid_grad) saw a non-finite gradient."""
+    for name, n, flag, first in entries:
+        if bool(flag):
+            i = int(first)
+            raise FloatingPointError(f"non-finite gradient entering the {name} hash-grid backward at (level, sample) [{i // n}, {i % n}] "
+                                     "(first offender; hipGraph replay)")
+
+
 def _check_finite_grid_grad(dlm: Tensor, desc: GridDesc) -> None:
     """Debug aid (EMER_CHECK_FINITE=1, the analogue of the reference's optim.check_nan, loss/base.py:77-79).  The owner-computes
     backward reduces runs of equal cells with 0/1-masked multiply-adds, so ONE non-finite entry of the incoming gradient
     contaminates other table entries of its wave (0 x inf = NaN; upstream's atomics keep it in the sample's own cells): looking
     at the table gradient afterwards points at the wrong entries.  This check names the offending (level, sample) pairs BEFORE
-    the scatter; it costs one reduction over the gradient and a host read, so it is off by default (and skipped while a hipGraph
-    is being captured: a host read is not capturable -- run the step eagerly, ``Trainer(use_graph=False)``, to use it)."""
+    the scatter; it costs one reduction over the gradient and a host read, so it is off by default.  While a hipGraph is being
+    captured the verdict is left on the device and read after each replay (``check_deferred_finite``)."""
     if torch.cuda.is_current_stream_capturing():
+        # a host read cannot be captured: the verdict stays on the device (tensors of the graph's pool, rewritten by every replay)
+        # and the owner of the graph reads it after g.replay() (check_deferred_finite; Trainer does when CHECK_FINITE is on)
+        per = (~torch.isfinite(dlm)).any(dim=-1).view(-1)                      # [L * N]
+        DEFERRED_FINITE.append((f"D{desc.n_dims}/L{desc.n_levels}/F{desc.n_features}", dlm.shape[1], per.any(), per.to(torch.uint8).argmax()))
         return
     bad = ~torch.isfinite(dlm)
     if bool(bad.any()):
@@ -612,6 +628,80 @@ def pixel_loss(rgb: Tensor, opacity: Optional[Tensor], pixels: Tensor, sky_mask:
     no ``loss * scale`` launch, nor its backward, is needed)."""
     _check_cuda(rgb, opacity, pixels, sky_mask)
     return _PixelLossFn.apply(rgb, opacity, pixels, sky_mask, w_rgb, w_sky, grad_scale)
+
+
+REG_MAX_BLOCKS = 1024  # EMER_REG_MAX_BLOCKS
+
+
+class _RegLossesFn(torch.autograd.Function):
+    """base + the mean-type regularisers (dynamic-density / shadow sparsity, feature L2, flow cycle) as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, base: Optional[Tensor], dyn: Optional[Tensor], shadow: Optional[Tensor], feat: Optional[Tensor], feat_gt: Optional[Tensor],
+                ff: Optional[Tensor], fpb: Optional[Tensor], bf: Optional[Tensor], bpf: Optional[Tensor], coefs, grad_scale: float):
+        c_dyn, c_shadow, c_feat, c_cycle = (float(c) for c in coefs)
+        ts = [None if t is None else _f32c(t) for t in (dyn, shadow, feat, feat_gt, ff, fpb, bf, bpf)]
+        dyn_c, sh_c, ft_c, gt_c, ff_c, fpb_c, bf_c, bpf_c = ts
+        ref = next(t for t in ts if t is not None)
+        if ft_c is not None:
+            assert gt_c is not None and gt_c.numel() == ft_c.numel(), "feature loss: prediction / target size mismatch"
+        if fpb_c is not None:
+            assert all(t is not None and t.numel() == fpb_c.numel() for t in (ff_c, bf_c, bpf_c)), "flow cycle loss: size mismatch"
+        n = lambda t: 0 if t is None else t.numel()
+        bc = None if base is None else _f32c(base).reshape(1)
+        with torch.cuda.device(ref.device):
+            ws = torch.empty((REG_MAX_BLOCKS,), device=ref.device, dtype=torch.float32)
+            loss = torch.empty((), device=ref.device, dtype=torch.float32)
+            ctx.args = (n(dyn_c), c_dyn, n(sh_c), c_shadow, n(ft_c), c_feat, n(fpb_c), c_cycle)
+            _lib.call("emer_reg_losses_fwd", _ptr(dyn_c), n(dyn_c), c_dyn, _ptr(sh_c), n(sh_c), c_shadow, _ptr(ft_c), _ptr(gt_c), n(ft_c), c_feat,
+                      _ptr(ff_c), _ptr(fpb_c), _ptr(bf_c), _ptr(bpf_c), n(fpb_c), c_cycle, _ptr(bc), _ptr(ws), _ptr(loss), _stream(ref))
+        # the sparsity terms' gradients are constants: only the tensors a gradient READS are saved
+        ctx.save_for_backward(ft_c, gt_c, ff_c, fpb_c, bf_c, bpf_c)
+        ctx.present = (dyn_c is not None, sh_c is not None)
+        ctx.shapes = tuple(None if t is None else t.shape for t in (dyn, shadow, feat, fpb, bpf))
+        ctx.grad_scale, ctx.dev = float(grad_scale), ref.device
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        ft_c, gt_c, ff_c, fpb_c, bf_c, bpf_c = ctx.saved_tensors
+        n_dyn, c_dyn, n_sh, c_shadow, n_ft, c_feat, n_fl, c_cycle = ctx.args
+        ni = ctx.needs_input_grad
+        gc = _f32c(g).reshape(1)
+        with torch.cuda.device(ctx.dev):
+            new = lambda shape: torch.empty(shape, device=ctx.dev, dtype=torch.float32)
+            d_dyn = new(ctx.shapes[0]) if ctx.present[0] and ni[1] else None
+            d_sh = new(ctx.shapes[1]) if ctx.present[1] and ni[2] else None
+            d_ft = new(ctx.shapes[2]) if ft_c is not None and ni[3] else None
+            d_fpb = new(ctx.shapes[3]) if fpb_c is not None and ni[6] else None
+            d_bpf = new(ctx.shapes[4]) if bpf_c is not None and ni[8] else None
+            if any(t is not None for t in (d_dyn, d_sh, d_ft, d_fpb, d_bpf)):
+                # absent-term pointers: the sparsity terms are described by their counts alone (gradient = constant)
+                _lib.call("emer_reg_losses_bwd", _ptr(d_dyn), n_dyn if d_dyn is not None else 0, c_dyn, _ptr(d_sh), n_sh if d_sh is not None else 0,
+                          c_shadow, _ptr(ft_c), _ptr(gt_c), n_ft, c_feat, _ptr(ff_c), _ptr(fpb_c), _ptr(bf_c), _ptr(bpf_c), n_fl, c_cycle,
+                          _ptr(gc), ctx.grad_scale, _ptr(d_dyn), _ptr(d_sh), _ptr(d_ft), _ptr(d_fpb), _ptr(d_bpf), _stream(gc))
+        gb = g if ni[0] else None
+        return gb, d_dyn, d_sh, d_ft, None, None, d_fpb, None, d_bpf, None, None
+
+
+def reg_losses(base: Optional[Tensor] = None, dynamic_density: Optional[Tensor] = None, shadow_ratio: Optional[Tensor] = None,
+               feat: Optional[Tensor] = None, feat_gt: Optional[Tensor] = None, forward_flow: Optional[Tensor] = None,
+               forward_pred_backward_flow: Optional[Tensor] = None, backward_flow: Optional[Tensor] = None,
+               backward_pred_forward_flow: Optional[Tensor] = None, c_dyn: float = 0.01, c_shadow: float = 0.01, c_feat: float = 0.5,
+               c_cycle: float = 0.005, grad_scale: float = 1.0) -> Tensor:
+    """``base + c_dyn mean(dynamic_density) + c_shadow mean(shadow_ratio) + c_feat mse(feat, feat_gt) + c_cycle mean((ff + fpb)^2 +
+    (bf + bpf)^2)`` as a 0-dim tensor: loss/base.py:394-398 (sparsity), :83-146 (feature L2), train_emernerf.py:700-716 (cycle;
+    forward_flow / backward_flow are constants, as the reference detaches them).  Absent terms are None.  ``grad_scale`` multiplies
+    the regularisers' GRADIENTS only (``base`` passes its gradient through unscaled: its own kernel already folded the scale)."""
+    present = [t for t in (dynamic_density, shadow_ratio, feat, forward_pred_backward_flow) if t is not None]
+    if not present:
+        if base is None:
+            raise ValueError("reg_losses: no term given")
+        return base
+    _check_cuda(*[t for t in (base, dynamic_density, shadow_ratio, feat, feat_gt, forward_flow, forward_pred_backward_flow, backward_flow,
+                              backward_pred_forward_flow) if t is not None])
+    return _RegLossesFn.apply(base, dynamic_density, shadow_ratio, feat, feat_gt, forward_flow, forward_pred_backward_flow, backward_flow,
+                              backward_pred_forward_flow, (c_dyn, c_shadow, c_feat, c_cycle), grad_scale)
 
 
 class _LidarLossFn(torch.autograd.Function):

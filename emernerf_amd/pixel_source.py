@@ -136,6 +136,17 @@ class PixelSource:
             self._next_seed()
         return img, y, x
 
+    def _support_ok(self, num_rays: int, img_candidate_indices=None) -> bool:
+        """True when the cached count of positive cells of the WHOLE error buffer already proves that ``num_rays`` cells can be
+        drawn without replacement (candidate subsets fall back to the per-call check)."""
+        if img_candidate_indices is not None:
+            return False
+        ver = self.pixel_error_maps._version
+        cache = getattr(self, "_support_cache", None)
+        if cache is None or cache[0] != ver or cache[2] is not self.pixel_error_maps:
+            cache = self._support_cache = (ver, int((self.pixel_error_maps > 0).sum()), self.pixel_error_maps)
+        return num_rays <= cache[1]
+
     # ---------------------------------------------------------------------------------------------------- rays
     def _gather(self, img_idx: Tensor, y: Tensor, x: Tensor) -> Dict[str, Tensor]:
         n, dev = img_idx.numel(), self.device
@@ -164,7 +175,9 @@ class PixelSource:
         if self.buffer_ratio > 0 and self.pixel_error_buffered:
             n_roi = int(num_rays * self.buffer_ratio)
             ri, ry, rx = self.sample_uniform_rays(num_rays - n_roi, candidate_indices, advance=False)
-            bi, by, bx = self.sample_important_rays(n_roi, candidate_indices, advance=False)
+            # support of the error buffer: one device->host read when the buffer is built / updated (cached), none per step
+            bi, by, bx = self.sample_important_rays(n_roi, candidate_indices, advance=False,
+                                                    check_support=not self._support_ok(n_roi, candidate_indices))
             img_idx, y, x = torch.cat([ri, bi]), torch.cat([ry, by]), torch.cat([rx, bx])
         else:
             img_idx, y, x = self.sample_uniform_rays(num_rays, candidate_indices, advance=False)
@@ -179,6 +192,7 @@ class PixelSource:
             self._all = (yy.reshape(-1).contiguous(), xx.reshape(-1).contiguous())
         y, x = self._all
         out = self._gather(torch.full((H * W,), int(img_idx), dtype=torch.int64, device=dev), y, x)
+        out["direction_norm"] = out.pop("direction_norms")   # the reference's render dict spells this key in the singular (:836)
         return {k: v.reshape(H, W, -1).squeeze(-1) if k in ("normed_timestamps", "img_idx", "cam_idx", "sky_masks") else v.reshape(H, W, -1)
                 for k, v in out.items()}
 

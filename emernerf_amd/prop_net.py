@@ -42,7 +42,10 @@ class PropNetEstimator(AbstractEstimator):
         # Tests replace this hook to replay the oracle's draws.  None (default): ONE torch.rand call per sampling() for all of
         # its resampling rounds.
         self.jitter_fn: Optional[Callable[[int, torch.device], Tensor]] = None
-        self._unit = None  # cached [n_rays, 2] edges (0, 1) of the trivial level-0 histogram
+        # [n_rays, 2] edges (0, 1) of the trivial level-0 histogram, one persistent constant per (n_rays, device): a captured
+        # hipGraph has the tensor's address baked into its first importance_sample launch, so an entry is NEVER freed or
+        # replaced (an eval chunk or a lidar step with another ray count adds an entry; 8 bytes per ray)
+        self._unit = {}
 
     # ------------------------------------------------------------------------------------------ sampling (:89-179)
     @torch.no_grad()
@@ -55,9 +58,15 @@ class PropNetEstimator(AbstractEstimator):
         dev = self.device
         planes = (float(near_plane), float(far_plane), sampling_type)
         # level 0 resamples the trivial histogram on [0, 1]
-        if self._unit is None or self._unit.shape[0] != n_rays or self._unit.device != dev:
-            self._unit = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()
-        edges = cdfs = self._unit  # read-only constant: no launch per call
+        key = (int(n_rays), str(dev))
+        unit = self._unit.get(key)
+        if unit is None:
+            if torch.cuda.is_available() and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                # first sight of this ray count inside a capture: allocate from the graph's pool (kept alive by the graph)
+                unit = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()
+            else:
+                unit = self._unit[key] = torch.arange(2, device=dev, dtype=torch.float32).expand(n_rays, 2).contiguous()
+        edges = cdfs = unit  # read-only constant: no launch per call
         jitters = None
         if stratified and self.jitter_fn is None:
             jitters = iter(torch.rand((len(prop_samples) + 1, n_rays), device=dev).unbind(0))

@@ -445,7 +445,8 @@ class RadianceField(nn.Module):
         x_fwd = torch.cat([fwd_pos, fwd_t.to(fwd_pos.dtype)], dim=-1).reshape(-1, D4)
         x_bwd = torch.cat([bwd_pos, bwd_t.to(bwd_pos.dtype)], dim=-1).reshape(-1, D4)
         # (3) dynamic table: one evaluation of 3N samples, one neck
-        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0), skip_dx_rows=N)  # the current positions carry no gradient
+        # the current positions carry no gradient in a training step (inputs of the model); a caller that asks for one gets it
+        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0), skip_dx_rows=0 if x_cur.requires_grad else N)
         geo3, sem3, _ = fused.neck(enc3, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
         # temporal aggregation (:595-613) per feature half, straight from the 3N-row batch: one launch each way, no [., 128]
         # concatenation and no 3N-row cat in the backward

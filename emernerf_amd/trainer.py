@@ -223,6 +223,7 @@ class Trainer:
                  world_size: int = 1, table_init: Optional[float] = None, use_graph: bool = False, table_dtype: str = "f32",
                  dp_mode: Optional[str] = None):
         self.device = torch.device(device)
+        self.kind = kind
         torch.manual_seed(seed)  # identical initial parameters on every rank
         self.cfg = model_config(kind, num_cams=3 if kind == "feature" else 1)
         self.rcfg = render_config(num_samples, prop_samples)
@@ -258,6 +259,9 @@ class Trainer:
         import os as _os
         self.dp_mode = dp_mode or _os.environ.get("EMER_DP_MODE", "allreduce")
         assert self.dp_mode in ("allreduce", "rs_ag"), self.dp_mode
+        # test hook, decided ONCE (a per-call fallback would let one rank issue all_reduce while its peers sit in reduce_scatter):
+        # a backend without reduce-scatter can emulate it with an all-reduce when the environment says so explicitly
+        self._rs_emulate = _os.environ.get("EMER_DP_RS_EMULATE") == "1"
         self.dp_debug = _os.environ.get("EMER_DP_DEBUG") == "1"   # check the ordering assumption of the early bucket (no overlap then)
         self.comm_events = None    # bench.py: list of (start, end) HIP events around the EXPOSED part of the exchange
         self.flat = FlatParams({"main": [self.model], "prop": self.props[-1:], "prop_idle": self.props[:-1]}, self.device,
@@ -286,48 +290,63 @@ class Trainer:
         self._prop_work = None  # async all-reduce of the trained proposal net's range (launched right after ITS backward)
         self._hold_buckets = False  # graph warm-up / capture: no collectives from inside the forward+backward
         self._one = torch.ones((), device=self.device, dtype=torch.float32)
-        if world_size > 1:
+        # the exchange runs when there is more than one rank -- or when EMER_DP_FORCE=1 asks for it on a single rank (a 1-GPU box can
+        # then execute the real RCCL collectives of both modes, trivially: tests/test_multi_gpu.py)
+        self._dp_on = world_size > 1 or _os.environ.get("EMER_DP_FORCE") == "1"
+        if self._dp_on:
+            assert dist.is_initialized(), "data-parallel exchange needs an initialised torch.distributed process group"
             self.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = self._launch_early_bucket
         self.model.train(); self.estimator.train()
         for p in self.props:
             p.train()
 
-    def _extra_losses(self, results, data) -> Optional[Tensor]:
-        """The regularisers of the dynamic / flow / feature models (None for the static model)."""
-        terms = []
-        if "dynamic_density" in results["extras"]:
-            terms.append(0.01 * results["extras"]["dynamic_density"].mean())
-        if "shadow_ratio" in results:
-            terms.append(0.01 * results["shadow_ratio"].mean())
-        if "dino_feat" in results and "features" in data:  # feature supervision: l2, coefficient 0.5 (default_config.yaml:141-143)
-            terms.append(0.5 * F.mse_loss(results["dino_feat"], data["features"]))
-        if "forward_flow" in results["extras"]:
-            ex = results["extras"]
-            terms.append(0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
-                                       + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean())
-        if not terms:
-            return None
-        total = terms[0]
-        for t in terms[1:]:
-            total = total + t
-        return total
+    def set_step(self, step: int, ticks_per_iter: int = 1) -> None:
+        """Fast-forward (or restore on resume) the iteration counter AND the LR-schedule ticks that go with it:
+        ``ticks_per_iter`` = 2 when every iteration also takes a lidar step (train_emernerf.py:745,826), else 1.  The proposal
+        schedule keeps its own ``since_last`` state."""
+        self.step_count = int(step)
+        self.sched_ticks = int(step) * int(ticks_per_iter)
+
+    def state_dict(self) -> Dict[str, object]:
+        """Optimizer-side state of this rank (parameters live in the modules' own state_dicts)."""
+        return {"m": self.m, "v": self.v, "opt_steps": dict(self.opt_steps), "step_count": self.step_count,
+                "sched_ticks": self.sched_ticks, "since_last": self.requires_grad_fn.since_last}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.opt_steps = dict(sd["opt_steps"])
+        self.step_count, self.sched_ticks = int(sd["step_count"]), int(sd["sched_ticks"])
+        self.requires_grad_fn.since_last = int(sd["since_last"])
+
+    def _with_regularisers(self, base: Tensor, results, data, grad_scale: float = 1.0) -> Tensor:
+        """``base`` + the regularisers of the dynamic / flow / feature models (``base`` itself for the static model): dynamic-density
+        and shadow sparsity (loss/base.py:394-398, coefficient 0.01 each, default_config.yaml:144-152), feature L2 (coefficient 0.5,
+        :141-143) and the flow cycle loss (train_emernerf.py:700-716: 0.5 * mean * 0.01) -- ONE kernel each way
+        (``ops.reg_losses``: row N4 of SURVEY.md section 8f) instead of ~25 elementwise torch launches."""
+        ex = results["extras"]
+        flows = "forward_flow" in ex
+        feat = "dino_feat" in results and "features" in data
+        return ops.reg_losses(base, dynamic_density=ex.get("dynamic_density"), shadow_ratio=results.get("shadow_ratio"),
+                              feat=results["dino_feat"] if feat else None, feat_gt=data["features"] if feat else None,
+                              forward_flow=ex["forward_flow"] if flows else None,
+                              forward_pred_backward_flow=ex["forward_pred_backward_flow"] if flows else None,
+                              backward_flow=ex["backward_flow"] if flows else None,
+                              backward_pred_forward_flow=ex["backward_pred_forward_flow"] if flows else None,
+                              c_dyn=0.01, c_shadow=0.01, c_feat=0.5, c_cycle=0.01 * 0.5, grad_scale=grad_scale)
 
     def losses(self, results, data) -> Tensor:
         """rgb L2 (loss/base.py:83-146, coef 1) + opacity-based sky BCE (loss/base.py:149-185, coef 0.001) + the regularisers."""
         loss = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001)  # one launch
-        extra = self._extra_losses(results, data)
-        return loss if extra is None else loss + extra
+        return self._with_regularisers(loss, results, data)
 
     def _scaled_losses(self, results, data):
-        """(tensor to back-propagate, plain loss value): the loss scale is folded into the pixel-loss backward kernel, so the
-        static step needs no ``loss * scale`` launch, no backward of it, and -- with the persistent ``self._one`` as the
-        seed -- no ones_like fill."""
+        """(tensor to back-propagate, plain loss value): the loss scale is folded into the backward kernels of the pixel loss and of
+        the regularisers, so a step needs no ``loss * scale`` launch, no backward of it, and -- with the persistent ``self._one`` as
+        the seed -- no ones_like fill.  The VALUE of the returned tensor is the plain (unscaled) loss."""
         pix = ops.pixel_loss(results["rgb"], results["opacity"], data["pixels"], data["sky_masks"], w_rgb=1.0, w_sky=0.001,
                              grad_scale=self.loss_scale)
-        extra = self._extra_losses(results, data)
-        if extra is None:
-            return pix, pix.detach()
-        return pix + extra * self.loss_scale, (pix + extra).detach()
+        total = self._with_regularisers(pix, results, data, grad_scale=self.loss_scale)
+        return total, total.detach()
 
     def lidar_losses(self, results, data, step: int) -> Tensor:
         """Depth + line-of-sight supervision of the lidar step (train_emernerf.py:770-808 with
@@ -342,8 +361,8 @@ class Trainer:
             w_sight = 0.1 * (0.5 ** ((step - start) // 5000))  # train_emernerf.py:620-628
         loss = ops.lidar_loss(results["depth"], results["extras"]["weights"], data["lidar_ranges"], results["extras"]["t_vals"],
                               eps, 80.0, 1.0, w_sight)
-        if "dynamic_density" in results["extras"]:
-            loss = loss + 0.01 * results["extras"]["dynamic_density"].mean()
+        if "dynamic_density" in results["extras"]:  # the dynamic regulariser also supervises lidar rays (train_emernerf.py:797-802)
+            loss = ops.reg_losses(loss, dynamic_density=results["extras"]["dynamic_density"], c_dyn=0.01)
         return loss
 
     def lidar_step(self, data: Dict[str, Tensor]) -> Dict[str, float]:
@@ -381,13 +400,13 @@ class Trainer:
         encoder of the forward pass): every MLP / embedding gradient of the main model is enqueued by now, so their
         (small) all-reduce starts here and runs on RCCL's stream while the grid backward -- the longest kernel of the
         step -- computes the table gradient.  Only the table bucket is exposed at the end of the backward."""
-        if self.world_size > 1 and self.dp_mode == "rs_ag":
+        if self._dp_on and self.dp_mode == "rs_ag":
             return  # one reduce-scatter per group after the backward
-        if self.world_size > 1 and self.dp_debug and not self._early_done and not self._hold_buckets:
+        if self._dp_on and self.dp_debug and not self._early_done and not self._hold_buckets:
             # debug: record what the early ranges hold NOW instead of reducing them; _exchange_grads checks nothing wrote later
             self._early_snapshot = [self.flat.grads[a:b].clone() for a, b in self._early_ranges]
             return
-        if self.world_size > 1 and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
+        if self._dp_on and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()  # weight gradients written on the side stream (off by default) must be complete
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
             self._early_done = True
@@ -396,9 +415,9 @@ class Trainer:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
         is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
         starts here and is hidden completely.  Eager launches only (a collective cannot be captured into the step's graph)."""
-        if self.world_size > 1 and self.dp_mode == "rs_ag":
+        if self._dp_on and self.dp_mode == "rs_ag":
             return
-        if self.world_size > 1 and self._prop_work is None and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
+        if self._dp_on and self._prop_work is None and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()
             self.flat.finish_grads("prop")
             a, b = self.flat.ranges["prop"]
@@ -418,22 +437,22 @@ class Trainer:
                     f"gradient range [{lo}, {hi}) was written after the early bucket would have been launched"
             self._early_snapshot = None
         ev0 = ev1 = None
-        if self.world_size > 1 and self.comm_events is not None:
+        if self._dp_on and self.comm_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if self.world_size > 1 and self.dp_mode == "rs_ag":
+        if self._dp_on and self.dp_mode == "rs_ag":
             self._rs_shards = {}
             for grp in (["main", "prop"] if prop_grad else ["main"]):
                 a, b = self.flat.ranges[grp]
                 n = (b - a) // self.world_size
                 r = dist.get_rank()
                 shard = self.flat.grads[a + r * n: a + (r + 1) * n]
-                try:
-                    dist.reduce_scatter_tensor(shard, self.flat.grads[a:b])
-                except (RuntimeError, NotImplementedError):  # gloo (CPU-side tests): no reduce-scatter; same result, more bytes
+                if self._rs_emulate:   # EMER_DP_RS_EMULATE=1, test mode only: same result, more bytes
                     dist.all_reduce(self.flat.grads[a:b])
+                else:                  # in place: the output shard is a slice of the input; errors propagate (no per-rank fallback)
+                    dist.reduce_scatter_tensor(shard, self.flat.grads[a:b])
                 self._rs_shards[grp] = (a + r * n, a + (r + 1) * n)
-        elif self.world_size > 1:
+        elif self._dp_on:
             a, b = self.flat.ranges["main"]
             if prop_grad and self._prop_work is None:
                 b = self.flat.ranges["prop"][1]  # main and the trained proposal net are adjacent in the flat buffer
@@ -451,13 +470,13 @@ class Trainer:
             ev1.record()
             self.comm_events.append((ev0, ev1))
         self._early_done, self._early_work, self._prop_work = False, [], None
-        if self.world_size > 1:
+        if self._dp_on:
             self.model.xyz_encoder.tcnn_encoding.params._emer_pending_evals = 0
 
     def _adam(self, group: str, lr: float):
         a, b = self.flat.ranges[group]
         self.opt_steps[group] += 1
-        if self.world_size > 1 and self.dp_mode == "rs_ag":
+        if self._dp_on and self.dp_mode == "rs_ag":
             # this rank owns 1/W of the group: update its shard (the only part of m / v it ever touches), then everyone
             # gathers the updated parameters
             lo, hi = self._rs_shards[group]
@@ -504,12 +523,16 @@ class Trainer:
                     self._forward_backward(sd, prop_grad)
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
+            ops.DEFERRED_FINITE.clear()
             with torch.cuda.graph(g):
                 out = self._forward_backward(sd, prop_grad)
-            self._graphs[prop_grad] = (g, out)
+            self._graphs[prop_grad] = (g, out, list(ops.DEFERRED_FINITE))   # EMER_CHECK_FINITE=1: device-side verdicts of this graph
+            ops.DEFERRED_FINITE.clear()
             self._hold_buckets = False
-        g, out = self._graphs[prop_grad]
+        g, out, finite_checks = self._graphs[prop_grad]
         g.replay()
+        if finite_checks:
+            ops.check_deferred_finite(finite_checks)   # one host read per replay, debug mode only
         return out
 
     def train_step(self, data: Dict[str, Tensor]) -> Dict[str, float]:
@@ -518,6 +541,8 @@ class Trainer:
         if self.use_graph:
             try:
                 loss = self._graphed_forward_backward(data, prop_grad)
+            except FloatingPointError:  # EMER_CHECK_FINITE=1: a replayed step saw a non-finite gradient -- not a capture problem
+                raise
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, once
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({e!r}); continuing with eager launches")

@@ -248,6 +248,31 @@ int emer_pixel_loss_fwd(const float *rgb, const float *pixels, const float *opac
 int emer_pixel_loss_bwd(const float *rgb, const float *pixels, const float *opacity, const float *sky_mask,
                         int64_t n_rays, float w_rgb, float w_sky, const float *upstream, float *d_rgb,
                         float *d_opacity, void *stream);
+/* Mean-type regularisers of the dynamic / flow / feature models in one pass:
+ *   loss = (base ? base[0] : 0)
+ *        + c_dyn    * mean(dyn_density[0..n_dyn))                       dynamic-density sparsity, loss/base.py:394-398 (called at
+ *                                                                       train_emernerf.py:683-688; lidar step :797-802)
+ *        + c_shadow * mean(shadow[0..n_shadow))                         shadow sparsity, same class (train_emernerf.py:689-694)
+ *        + c_feat   * mean((feat - feat_gt)^2 over n_feat)              feature L2, loss/base.py:83-146 (train_emernerf.py:676-682)
+ *        + c_cycle  * mean((fwd_flow + fwd_pred_bwd_flow)^2 + (bwd_flow + bwd_pred_fwd_flow)^2 over n_flow)
+ *                                                                       flow cycle consistency, train_emernerf.py:700-716
+ *                                                                       (the reference's 0.5 * 0.01 enters through c_cycle).
+ * A term is absent when its first pointer (dyn_density / shadow / feat / fwd_pred_bwd_flow) is NULL.  workspace: at least
+ * EMER_REG_MAX_BLOCKS floats; loss_out [1]; fixed summation order (bit-reproducible). */
+#define EMER_REG_MAX_BLOCKS 1024
+int emer_reg_losses_fwd(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow,
+                        float c_shadow, const float *feat, const float *feat_gt, int64_t n_feat, float c_feat,
+                        const float *fwd_flow, const float *fwd_pred_bwd_flow, const float *bwd_flow,
+                        const float *bwd_pred_fwd_flow, int64_t n_flow, float c_cycle, const float *base, float *workspace,
+                        float *loss_out, void *stream);
+/* Gradients of the four terms, each multiplied by upstream[0] (NULL: 1) * grad_scale; every output may be NULL.  fwd_flow /
+ * bwd_flow receive no gradient (detached in the reference). */
+int emer_reg_losses_bwd(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow,
+                        float c_shadow, const float *feat, const float *feat_gt, int64_t n_feat, float c_feat,
+                        const float *fwd_flow, const float *fwd_pred_bwd_flow, const float *bwd_flow,
+                        const float *bwd_pred_fwd_flow, int64_t n_flow, float c_cycle, const float *upstream,
+                        float grad_scale, float *d_dyn_density, float *d_shadow, float *d_feat,
+                        float *d_fwd_pred_bwd_flow, float *d_bwd_pred_fwd_flow, void *stream);
 /* Lidar-ray supervision (train_emernerf.py:770-808): depth loss (loss/base.py:188-271, "l2", normalised by max_depth,
  * mean over rays with 0.01 < range < max_depth) + line-of-sight loss (loss/base.py:430-464: empty-space and near-surface
  * terms with margin epsilon, times the fraction of rays with range > 0).

@@ -316,6 +316,24 @@ def render(field_out: Dict[str, Tensor], t_starts: Tensor, t_ends: Tensor) -> Di
     return res
 
 
+def pixel_step_loss(res: Dict[str, Tensor], data: Dict[str, Tensor]) -> Tensor:
+    """The pixel-ray losses of train_emernerf.py:655-716 with configs/default_config.yaml's coefficients: rgb L2 (1), opacity-based
+    sky BCE (0.001), dynamic-density and shadow sparsity (0.01 each, loss/base.py:394-398), feature L2 (0.5), flow cycle
+    consistency (0.5 * mean * 0.01)."""
+    loss = F.mse_loss(res["rgb"], data["pixels"]) + 0.001 * F.binary_cross_entropy(res["opacity"].squeeze(-1), 1 - data["sky_masks"].float())
+    ex = res["extras"]
+    if "dynamic_density" in ex:
+        loss = loss + 0.01 * ex["dynamic_density"].mean()
+    if "shadow_ratio" in res:
+        loss = loss + 0.01 * res["shadow_ratio"].mean()
+    if "dino_feat" in res and "features" in data:
+        loss = loss + 0.5 * F.mse_loss(res["dino_feat"], data["features"])
+    if "forward_flow" in ex:
+        loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
+                                    + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
+    return loss
+
+
 # ---------------------------------------------------------------------------------- whole path
 class RefPath:
     """Holds parameters (reference names) and evaluates render_rays / one training step on CPU."""
@@ -363,14 +381,15 @@ class RefPath:
                             training, return_density_only=(prefix == "lidar_"), noise_fn=noise_fn, cam_embedding=self.cam_embedding)
         return render(fo, t0, t1)
 
-    def train_step(self, data, opt_main, opt_prop, num_samples, prop_samples, jitters=None, loss_scale=1024.0, prop_grad=True):
-        """One pixel-ray optimizer step (train_emernerf.py:634-745) with rgb L2 + opacity sky loss."""
-        res = self.render_rays(data, num_samples, prop_samples, jitters=jitters, requires_grad=prop_grad)
+    def train_step(self, data, opt_main, opt_prop, num_samples, prop_samples, jitters=None, loss_scale=1024.0, prop_grad=True,
+                   noise_fn=None):
+        """One pixel-ray optimizer step (train_emernerf.py:634-745): rgb L2 + opacity sky loss + the regularisers of the
+        dynamic / flow / feature models."""
+        res = self.render_rays(data, num_samples, prop_samples, jitters=jitters, requires_grad=prop_grad, noise_fn=noise_fn)
         if prop_grad:
             pl = prop_loss(self.cache, res["extras"]["trans"], loss_scale)
             opt_prop.zero_grad(); pl.backward(); opt_prop.step()
-        loss = F.mse_loss(res["rgb"], data["pixels"]) + 0.001 * F.binary_cross_entropy(
-            res["opacity"].squeeze(-1), 1 - data["sky_masks"].float())
+        loss = pixel_step_loss(res, data)
         opt_main.zero_grad()
         (loss * loss_scale).backward()
         opt_main.step()

@@ -349,6 +349,73 @@ def run_render_pixels_case(kind: str, seed: int, n_images: int = 3, hw=(6, 10), 
     return out
 
 
+# ------------------------------------------------------------------------------ N2: ray generation / training batches
+def run_pixel_source_case(seed: int = 1200, n_imgs: int = 6, hw=(12, 20), num_cams: int = 3, n_train: int = 96):
+    """datasets/base/pixel_source.py UNMODIFIED (loaded by file path; stubs only for imports that have nothing to do with the
+    path: omegaconf, PIL-free here, third_party.feature_extractor): ``get_rays`` (:39-76) on seeded pixels / cameras,
+    ``ScenePixelSource.get_train_rays`` (:666-731; its torch.randint pixel draws are recorded with the batch) and
+    ``get_render_rays`` (:733-826) on a tiny synthetic log."""
+    import importlib.util
+    import types
+    from oracle import ref_shims
+    ref_shims.install()
+    fe = types.ModuleType("third_party.feature_extractor")
+    fe.delete_features = fe.extract_and_save_features = lambda *a, **k: None
+    sys.modules["third_party.feature_extractor"] = fe
+    spec = importlib.util.spec_from_file_location("ref_pixel_source", os.path.join(ref_shims.REFERENCE_ROOT, "datasets", "base", "pixel_source.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Source(mod.ScenePixelSource):   # the abstract hooks read files; the tensors are set directly instead
+        def create_all_filelist(self):
+            pass
+
+        def load_calibrations(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    H, W = hw
+    src = Source.__new__(Source)
+    src.device = torch.device("cpu")
+    src._downscale_factor = src._old_downscale_factor = 1.0
+    src.images = torch.rand(n_imgs, H, W, 3, generator=g)
+    src.sky_masks = (torch.rand(n_imgs, H, W, generator=g) < 0.2).float()
+    src.dynamic_masks, src.features = None, None
+    c2w = torch.eye(4).repeat(n_imgs, 1, 1)
+    for i in range(n_imgs):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        c2w[i, :3, :3] = q
+        c2w[i, :3, 3] = torch.randn(3, generator=g) * 10
+    src.cam_to_worlds = c2w
+    K = torch.tensor([[0.9 * W, 0.0, W / 2 + 0.3], [0.0, 0.8 * W, H / 2 - 0.2], [0.0, 0.0, 1.0]]).repeat(n_imgs, 1, 1)
+    K[:, 0, 0] += torch.rand(n_imgs, generator=g)
+    src.intrinsics = K
+    src._normalized_timestamps = (torch.arange(n_imgs) // num_cams).float() / max(n_imgs // num_cams - 1, 1)
+    src.cam_ids = torch.arange(n_imgs) % num_cams
+    src.pixel_error_buffered = False
+    # HEIGHT / WIDTH / buffer_ratio are read-only properties over data_cfg (:947-991)
+    src.data_cfg = ref_shims.ns(load_size=[H, W], num_cams=num_cams, sampler=dict(buffer_ratio=0.0, buffer_downscale=4))
+    out = {}
+    for k in ("images", "sky_masks", "cam_to_worlds", "intrinsics", "normalized_timestamps", "cam_ids"):
+        out["src/" + k] = getattr(src, k).numpy()
+    # get_rays on its own: one camera per ray, pixel coordinates incl. the image corners
+    n = 64
+    x = torch.randint(0, W, (n,), generator=g); y = torch.randint(0, H, (n,), generator=g)
+    x[:4], y[:4] = torch.tensor([0, W - 1, 0, W - 1]), torch.tensor([0, 0, H - 1, H - 1])
+    cam = torch.randint(0, n_imgs, (n,), generator=g)
+    o, d, nr = mod.get_rays(x, y, c2w[cam], K[cam])
+    out.update({"get_rays/x": x.numpy(), "get_rays/y": y.numpy(), "get_rays/cam": cam.numpy(), "get_rays/origins": o.numpy(),
+                "get_rays/viewdirs": d.numpy(), "get_rays/direction_norm": nr.numpy()})
+    torch.manual_seed(seed + 1)
+    batch = src.get_train_rays(n_train, candidate_indices=[0, 2, 3, 5])
+    for k, v in batch.items():
+        out["train/" + k] = v.numpy()
+    rr = src.get_render_rays(4)
+    for k, v in rr.items():
+        out["render4/" + k] = v.numpy()
+    return out
+
+
 RENDER_PIXELS_CASES = {
     "render_pixels_static": dict(kind="static", seed=800),
     "render_pixels_flow": dict(kind="flow", seed=900),
@@ -364,6 +431,11 @@ def main():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB; keys {sorted({k.split('/')[1] for k in out if k.startswith('res/')})}")
+    if not only or "pixel_source" in only:
+        out = run_pixel_source_case()
+        path = os.path.join(HERE, "pixel_source.npz")
+        np.savez_compressed(path, **out)
+        print(f"pixel_source: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB")
     for name, kw in CASES.items():
         if only and name not in only:
             continue

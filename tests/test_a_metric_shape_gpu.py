@@ -222,24 +222,9 @@ def test_heads_metric_rows(hip_lib):
 
 # ------------------------------------------------------------------------------------------ whole step
 def _ref_from_trainer(oracle, tr):
-    from oracle.ref_path import RefPath
-    from emernerf_amd.trainer import AABB, PROP_KW
-    c = tr.cfg
-    x = c.xyz_encoder
-    grids = {"model/xyz_encoder": oracle.grid_meta_from_encoder_args(3, x.n_levels, x.base_resolution, x.max_resolution,
-                                                                       x.log2_hashmap_size, x.n_features_per_level)}
-    if tr.model.dynamic_xyz_encoder is not None:
-        d = c.dynamic_xyz_encoder
-        grids["model/dynamic_xyz_encoder"] = oracle.grid_meta_from_encoder_args(4, d.n_levels, d.base_resolution, d.max_resolution,
-                                                                                d.log2_hashmap_size, d.n_features_per_level)
-    if tr.model.flow_xyz_encoder is not None:
-        grids["model/flow_xyz_encoder"] = oracle.grid_meta_from_encoder_args(*GRIDS["flow_xyzt"][:1], *GRIDS["flow_xyzt"][1:])  # radiance_field.py:916-923
-    for i, kw in enumerate(PROP_KW):
-        grids[f"prop{i}/xyz_encoder"] = oracle.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
-                                                                           kw["log2_hashmap_size"], kw["n_features_per_level"])
-    ms = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
-    ps = [{k: v.detach().cpu() for k, v in p.state_dict().items()} for p in tr.props]
-    return RefPath(ms, ps, grids, AABB, time_diff=1 / c.num_train_timesteps)
+    """oracle/ref_path.RefPath holding copies of the trainer's parameters (reference state_dict names)."""
+    from oracle.train_parity import ref_from_trainer
+    return ref_from_trainer(tr)
 
 
 @pytest.mark.parametrize("kind", ["static", "dynamic", "flow", "feature"])
@@ -251,18 +236,22 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
     feature sky head, three cameras).  Same losses as Trainer.losses.  The flow case runs the batched
     xyzt evaluations (3N dynamic, N + 2N flow) with input gradients through both grids."""
     import torch.nn.functional as Fn
-    from oracle.ref_path import prop_loss
+    from oracle.ref_path import pixel_step_loss, prop_loss
     from emernerf_amd.trainer import Trainer, synthetic_rays
     dev = _dev()
     R, S = (1024 if kind in ("flow", "feature") else 2048), 128
     tr = Trainer(kind=kind, device=dev, num_samples=S, prop_samples=(128, 64), table_init=0.3, seed=7)
+    if kind in ("dynamic", "flow", "feature"):
+        # With +-0.3 tables static + dynamic density saturates every ray (opacity 0.9999 .. 1, measured on the oracle), where the
+        # sky term -log(1 - opacity) and its gradient 1 / (1 - opacity) are decided by the last bits of a sum.  The sky loss stays
+        # ON: the density biases are lowered by 3 instead (opacity 0.3 .. 0.8 over these rays), so that the sky-BCE gradient
+        # through a static + dynamic opacity is compared at scale.
+        with torch.no_grad():
+            tr.model.base_mlp[2].bias[0] -= 3.0
+            tr.model.dynamic_base_mlp[2].bias[0] -= 3.0
     ref = _ref_from_trainer(oracle, tr)
     data = synthetic_rays(R, dev, seed=77, **(dict(num_cams=3, feature_dim=64) if kind == "feature" else {}))
-    if kind in ("dynamic", "flow", "feature"):
-        # static + dynamic density saturates every ray (opacity rounds to exactly 1), where the sky term -log(1 - opacity)
-        # and its gradient 1 / (1 - opacity) are decided by the last bit of a sum: covered by the static case; here the
-        # dynamic / shadow branches are what is being compared
-        data["sky_masks"].zero_()
+    assert float(data["sky_masks"].sum()) > 0.1 * R
     cpu = {k: v.cpu() for k, v in data.items()}
     g = torch.Generator().manual_seed(9)
     jit = [torch.rand(R, generator=g) for _ in range(3)]
@@ -274,23 +263,15 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
     torch.cuda.synchronize()
 
     res = ref.render_rays(cpu, S, [128, 64], jitters=jit, requires_grad=True, noise_fn=lambda like: noise)
+    if kind != "static":
+        assert float(res["opacity"].max()) < 0.9999, "rays must not saturate (the sky term is part of this comparison)"
     pl = prop_loss(ref.cache, res["extras"]["trans"], 1024.0)
     pl.backward()
-    loss = Fn.mse_loss(res["rgb"], cpu["pixels"]) + 0.001 * Fn.binary_cross_entropy(res["opacity"].squeeze(-1), 1 - cpu["sky_masks"].float())
-    if "dynamic_density" in res["extras"]:
-        loss = loss + 0.01 * res["extras"]["dynamic_density"].mean()
-    if "shadow_ratio" in res:
-        loss = loss + 0.01 * res["shadow_ratio"].mean()
-    if "dino_feat" in res and "features" in cpu:  # feature supervision: l2, coefficient 0.5 (default_config.yaml:141-143)
-        loss = loss + 0.5 * Fn.mse_loss(res["dino_feat"], cpu["features"])
-    if "forward_flow" in res["extras"]:  # flow cycle consistency, as Trainer.losses (train_emernerf.py:700-716)
-        ex = res["extras"]
-        loss = loss + 0.01 * 0.5 * ((ex["forward_flow"].detach() + ex["forward_pred_backward_flow"]) ** 2
-                                    + (ex["backward_flow"].detach() + ex["backward_pred_forward_flow"]) ** 2).mean()
+    loss = pixel_step_loss(res, cpu)   # the reference's expressions (train_emernerf.py:655-716), oracle/ref_path.py
     (loss * 1024.0).backward()
     np.testing.assert_allclose(float(loss_hip), float(loss), rtol=1e-4)
 
-    checked = 0
+    checked, worst = 0, (0.0, "")
     gmax = max(float(v.grad.abs().max()) for v in ref.t.values() if v.grad is not None and v.numel() < 100000)  # (MLP weights)
     for prefix, mod in [("model/", tr.model)] + [(f"prop{i}/", p) for i, p in enumerate(tr.props)]:
         for k, q in mod.named_parameters():
@@ -304,7 +285,9 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
             # 2e-3 of the parameter's own gradient scale; gradients that are ~1e-5 of the step's largest (the sky head
             # behind a factor (1 - opacity) on saturated rays) get an absolute floor instead
             assert err <= 2e-3 * scale + 1e-6 * gmax, f"{prefix + k}: max err {err:.3e} vs scale {scale:.3e}"
+            worst = max(worst, (err / (scale + 1e-3 * gmax), prefix + k))
             checked += 1
+    print(f"\n[{kind}] worst gradient error / (own scale + 1e-3 gmax): {worst[0]:.2e} at {worst[1]}")
     assert checked >= 15
 
 

@@ -103,14 +103,19 @@ def test_render_rays_matches_reference(hip_lib, case):
         if k == "median_depth":  # index-valued (the sample at which the accumulated weight crosses one half)
             g, w = results[k].detach().cpu().numpy().reshape(-1), gold["out/" + k].reshape(-1)
             same = np.isclose(g, w, rtol=1e-4)
-            assert same.mean() > 0.9, k
-            tv = gold["extras/t_vals"]
-            if tv.shape[0] == g.shape[0] and not same.all():
-                # a ray that disagrees may only have slipped to the NEIGHBOURING sample (cumulative weight within rounding
-                # of one half at the boundary): compare sample indices, not depths
+            assert same.mean() >= 0.97, f"{k}: only {same.mean():.3f} of the rays agree"
+            tv, wt = gold["extras/t_vals"], gold["extras/weights"]
+            if not same.all():
+                # a ray that disagrees may only have slipped to the NEIGHBOURING sample, and only where the recorded cumulative
+                # weight sits within rounding of one half at that boundary (sample indices are compared, not depths)
+                assert tv.shape[0] == g.shape[0], "median depth differs on a chunked render whose extras cover the last chunk only"
                 ig = np.abs(tv - g[:, None]).argmin(1)
                 iw = np.abs(tv - w[:, None]).argmin(1)
                 assert (np.abs(ig - iw)[~same] <= 1).all(), f"{k}: a ray moved by more than one sample"
+                cw = np.cumsum(wt.astype(np.float64), axis=1)
+                lo = np.minimum(ig, iw)
+                edge = np.abs(cw[np.arange(len(lo)), lo] - 0.5)
+                assert (edge[~same] <= 1e-5).all(), f"{k}: a ray slipped although its cumulative weight is {edge[~same].max():.2e} away from 0.5"
             continue
         _check("out/" + k, results[k], gold["out/" + k])
     for k in sorted(ex_keys):
@@ -187,9 +192,67 @@ def test_render_pixels_matches_reference_loop(hip_lib, case):
         for j in range(2):
             got, want = np.asarray(out[k][j]), gold[f"res/{k}/{j}"]
             assert got.shape == want.shape, (k, got.shape, want.shape)
-            if k == "median_depths":  # index-valued: tolerate a one-sample slip on a few rays
-                assert np.isclose(got, want, rtol=1e-4).mean() > 0.9, k
+            if k == "median_depths":
+                # index-valued: a pixel may slip to the NEIGHBOURING sample when its cumulative weight crosses one half within
+                # rounding; the loop does not return the samples, so the neighbour rule is checked on this path's own eval-mode
+                # samples of the same image (sample placement is bit-exact against the oracle: tests/test_kernels_gpu.py)
+                same = np.isclose(got, want, rtol=1e-4)
+                assert same.mean() >= 0.97, f"{k}[{j}]: only {same.mean():.3f} of the pixels agree"
+                if not same.all():
+                    from emernerf_amd.render_utils import render_rays
+                    big = G.render_cfg([24, 16], 16, chunk=1 << 20)
+                    with torch.no_grad():
+                        one = render_rays(radiance_field=model, proposal_estimator=est, proposal_networks=props, data_dict=images[[0, 2][j]],
+                                          cfg=big, return_decomposition=True)
+                    tv = one["extras"]["t_vals"].reshape(-1, 16).cpu().numpy()
+                    ig = np.abs(tv - got.reshape(-1, 1)).argmin(1)
+                    iw = np.abs(tv - want.reshape(-1, 1)).argmin(1)
+                    assert (np.abs(ig - iw)[~same.reshape(-1)] <= 1).all(), f"{k}[{j}]: a pixel moved by more than one sample"
                 continue
             scale = max(float(np.abs(want).max()), 1.0)
             err = np.abs(got - want)
             assert (err <= 2e-5 * scale + 1e-4 * np.abs(want)).all(), f"{k}[{j}]: max err {err.max():.3e}"
+
+
+def test_pixel_source_matches_reference_recording(hip_lib):
+    """N2 against a recording of the reference's own datasets/base/pixel_source.py (tests/golden/make_golden.py::run_pixel_source_case):
+    ``get_rays`` (:39-76) on recorded pixels / cameras, the batch ``get_train_rays`` (:666-731) assembled for the pixels IT drew
+    (its torch.randint draws are part of the recording; our sampler draws its own), and ``get_render_rays`` (:733-826) of one image,
+    key for key.  Origins, pixel coordinates, gathered colours / masks / ids: bit-exact; directions: 2e-7 (the reference normalises
+    with ``/ (norm + 1e-8)`` in torch's evaluation order)."""
+    from emernerf_amd.pixel_source import PixelSource, get_rays
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(HERE, "golden", "pixel_source.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    src = PixelSource(t("src/images"), t("src/cam_to_worlds"), t("src/intrinsics"), t("src/sky_masks"), t("src/normalized_timestamps"), t("src/cam_ids"))
+    H, W = src.HEIGHT, src.WIDTH
+    # get_rays
+    cam = t("get_rays/cam")
+    o, d, n = get_rays(t("get_rays/x"), t("get_rays/y"), src.cam_to_worlds[cam], src.intrinsics[cam])
+    np.testing.assert_array_equal(o.cpu().numpy(), z["get_rays/origins"])
+    np.testing.assert_allclose(d.cpu().numpy(), z["get_rays/viewdirs"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(n.cpu().numpy(), z["get_rays/direction_norm"], rtol=2e-7)
+    # the training batch of the recorded pixel draws
+    pc = z["train/pixel_coords"]
+    y, x = np.rint(pc[:, 0] * H).astype(np.int64), np.rint(pc[:, 1] * W).astype(np.int64)
+    got = src._gather(t("train/img_idx"), torch.from_numpy(y).to(dev), torch.from_numpy(x).to(dev))
+    want_keys = {k.split("/", 1)[1] for k in z.files if k.startswith("train/")}
+    assert set(got.keys()) == want_keys, (sorted(got.keys()), sorted(want_keys))
+    for k in want_keys:
+        a, b = got[k].cpu().numpy(), z["train/" + k]
+        assert a.shape == b.shape and a.dtype == b.dtype, (k, a.shape, b.shape, a.dtype, b.dtype)
+        if k in ("viewdirs", "direction_norms"):
+            np.testing.assert_allclose(a, b, rtol=2e-7, atol=2e-7, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=k)
+    # every pixel of image 4, image-shaped
+    rr = src.get_render_rays(4)
+    want_keys = {k.split("/", 1)[1] for k in z.files if k.startswith("render4/")}
+    assert set(rr.keys()) == want_keys, (sorted(rr.keys()), sorted(want_keys))
+    for k in want_keys:
+        a, b = rr[k].cpu().numpy(), z["render4/" + k]
+        assert a.shape == b.shape and a.dtype == b.dtype, (k, a.shape, b.shape, a.dtype, b.dtype)
+        if k in ("viewdirs", "direction_norm"):
+            np.testing.assert_allclose(a, b, rtol=2e-7, atol=2e-7, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=k)

@@ -518,6 +518,70 @@ def test_pixel_loss_matches_torch(hip_lib, R):
     np.testing.assert_allclose(od.grad.cpu().numpy(), o2.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("R,S,E,terms", [(64, 16, 8, "dsfc"), (8192, 128, 64, "dsfc"), (777, 33, 5, "dc"), (1000, 64, 64, "f"),
+                                          (3, 1, 1, "ds"), (4096, 128, 64, "c")])
+def test_reg_losses_match_the_reference_expressions(hip_lib, R, S, E, terms):
+    """emer_reg_losses_fwd/bwd (row N4) vs the reference's own expressions evaluated by torch in fp64: dynamic-density and
+    shadow sparsity ``coef * x.mean()`` (loss/base.py:394-398 with default_config.yaml's 0.01), feature L2 ``0.5 * mse``
+    (loss/base.py:83-146), flow cycle ``0.01 * 0.5 * ((ff.detach() + fpb) ** 2 + (bf.detach() + bpf) ** 2).mean()``
+    (train_emernerf.py:700-716), added to a base scalar; gradients scaled by the trainer's loss scale; the detached flows get none."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R * 7 + S)
+    base = torch.rand((), generator=g)
+    dyn, sh = torch.rand(R, S, generator=g) * 3, torch.rand(R, 1, generator=g)
+    ft, gt = torch.randn(R, E, generator=g), torch.rand(R, E, generator=g)
+    ff, fpb, bf, bpf = (torch.randn(R, S, 3, generator=g) * 0.3 for _ in range(4))
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in dict(base=base, dyn=dyn, sh=sh, ft=ft, ff=ff, fpb=fpb, bf=bf, bpf=bpf).items()}
+    kw = {}
+    if "d" in terms:
+        kw["dynamic_density"] = leaves["dyn"]
+    if "s" in terms:
+        kw["shadow_ratio"] = leaves["sh"]
+    if "f" in terms:
+        kw.update(feat=leaves["ft"], feat_gt=gt.to(dev))
+    if "c" in terms:
+        kw.update(forward_flow=leaves["ff"], forward_pred_backward_flow=leaves["fpb"], backward_flow=leaves["bf"],
+                  backward_pred_forward_flow=leaves["bpf"])
+    scale = 1024.0
+    out = ops.reg_losses(leaves["base"], grad_scale=scale, **kw)
+    out.backward()
+    ref = {k: v.double().clone().requires_grad_(True) for k, v in dict(base=base, dyn=dyn, sh=sh, ft=ft, ff=ff, fpb=fpb, bf=bf, bpf=bpf).items()}
+    reg = torch.zeros((), dtype=torch.float64)
+    if "d" in terms:
+        reg = reg + 0.01 * ref["dyn"].mean()
+    if "s" in terms:
+        reg = reg + 0.01 * ref["sh"].mean()
+    if "f" in terms:
+        reg = reg + 0.5 * torch.nn.functional.mse_loss(ref["ft"], gt.double())
+    if "c" in terms:
+        reg = reg + 0.01 * 0.5 * ((ref["ff"].detach() + ref["fpb"]) ** 2 + (ref["bf"].detach() + ref["bpf"]) ** 2).mean()
+    (ref["base"] + reg * scale).backward()   # the base passes its gradient through unscaled (its own kernel folded the scale)
+    np.testing.assert_allclose(float(out), float(ref["base"] + reg), rtol=3e-6)
+    used = {"base"} | ({"dyn"} if "d" in terms else set()) | ({"sh"} if "s" in terms else set()) | ({"ft"} if "f" in terms else set()) \
+        | ({"fpb", "bpf"} if "c" in terms else set())
+    for k, leaf in leaves.items():
+        if k in used:
+            np.testing.assert_allclose(leaf.grad.cpu().numpy(), ref[k].grad.numpy(), rtol=2e-6, atol=1e-12, err_msg=k)
+        else:
+            assert leaf.grad is None, f"{k} must not receive a gradient"
+    # run-to-run bit-stable (fixed summation order)
+    again = ops.reg_losses(leaves["base"].detach(), grad_scale=scale, **{k: v.detach() for k, v in kw.items()})
+    assert torch.equal(again, out.detach())
+
+
+def test_reg_losses_argument_errors(hip_lib):
+    from emernerf_amd import _lib, ops
+    dev = _dev()
+    with pytest.raises(ValueError):
+        ops.reg_losses()
+    with pytest.raises(AssertionError):
+        ops.reg_losses(None, feat=torch.zeros(4, 3, device=dev), feat_gt=torch.zeros(4, 2, device=dev))
+    with pytest.raises(_lib.EmerError):
+        ops.reg_losses(None, dynamic_density=torch.zeros(4, 3))   # CPU tensor: there is no fallback
+    assert float(ops.reg_losses(torch.full((), 2.5, device=dev))) == 2.5   # no term present: the base itself
+
+
 # ------------------------------------------------------------------------------------ training-ray generation
 def _ref_get_rays(x, y, c2w, K):
     """datasets/base/pixel_source.py:39-76 restated (the reference module cannot travel to the GPU box)."""

@@ -109,6 +109,57 @@ def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, 
     assert int(bad.sum()) <= max(10, int(touched.sum()) // 2000), f"{int(bad.sum())} of {int(touched.sum())} updates differ"
 
 
+def _rccl_worker(rank, port, out_dir, dp_mode):
+    """One rank, backend "nccl" (= RCCL on ROCm), EMER_DP_FORCE=1: the trainer takes its data-parallel path and the REAL collectives
+    run -- async all_reduce buckets, or the in-place reduce_scatter_tensor (output shard aliasing its input) and
+    all_gather_into_tensor of the rs_ag mode -- trivially, on a communicator of size one."""
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["EMER_DP_FORCE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    assert dist.get_backend() == "nccl"
+    tr = _make(1, "static", dp_mode)
+    assert tr._dp_on
+    seen = []
+    for name in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: lambda *a, **k: (seen.append(n), o(*a, **k))[1])(orig, name))
+    data, jit, noise = _data(0, 2 * R_HALF, "pixel")
+    for _ in range(2):
+        _step(tr, data, jit, noise, "pixel")
+    torch.cuda.synchronize()
+    want = {"allreduce": {"all_reduce"}, "rs_ag": {"reduce_scatter_tensor", "all_gather_into_tensor"}}[dp_mode]
+    assert set(seen) == want, seen
+    torch.save({"params": tr.flat.params.cpu(), "ranges": dict(tr.flat.ranges)}, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dp_mode", ["allreduce", "rs_ag"])
+def test_real_rccl_collectives_execute_on_one_rank(hip_lib, tmp_path, dp_mode):
+    """``reduce_scatter_tensor`` had never executed on any backend.  On this one-GPU box RCCL can only form a communicator
+    of one rank, so the exchange is numerically the identity -- which makes the check exact: two steps through the real RCCL calls
+    equal two steps of the plain single-GPU trainer (group padding of rs_ag aside), update for update."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path), dp_mode), nprocs=1, join=True)
+    got = torch.load(tmp_path / "rccl.pt")
+    tr = _make(1, "static")
+    before = tr.flat.params.cpu().clone()
+    data, jit, noise = _data(0, 2 * R_HALF, "pixel")
+    for _ in range(2):
+        _step(tr, data, jit, noise, "pixel")
+    torch.cuda.synchronize()
+    p = got["params"]
+    if p.numel() != tr.flat.numel:
+        p = torch.cat([p[a:a + (d - c)] for (a, _), (c, d) in zip(got["ranges"].values(), tr.flat.ranges.values())])
+    # (the owner-computes grid backward is reproducible to an ulp, not bitwise: compare the UPDATES as the two-rank test does)
+    du, dv = p - before, tr.flat.params.cpu() - before
+    touched = dv.abs() > 0
+    assert int(touched.sum()) > 100000
+    bad = (du - dv).abs() > 1e-3 * dv.abs().clamp_min(1e-12)
+    assert int(bad.sum()) <= max(10, int(touched.sum()) // 2000), f"{int(bad.sum())} of {int(touched.sum())} updates differ"
+
+
 def test_bench_runs_with_two_ranks(hip_lib, tmp_path):
     """bench.py's N > 1 path end to end on this one-GPU box: two ranks share cuda:0 and exchange through gloo (test hooks;
     on a multi-GPU node the same code runs over RCCL).  Guards the contract that EVERY rank takes every step that contains

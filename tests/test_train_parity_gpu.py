@@ -1,0 +1,63 @@
+"""K-step TRAINING parity (second half of BASELINE.json's metric: "PSNR vs ref").
+
+Every other gradient test compares ONE step.  Here the HIP trainer and the CPU oracle train from identical parameters for K
+optimizer steps on rays coloured by a fixed synthetic ground-truth field -- proposal schedule (both step types), LR warm-up,
+Adam with eps = 1e-15 and the never-unscaled x1024 loss scale, in-place table gradients, hipGraph replay -- and must stay
+together: per-step loss, parameters after K steps, and the PSNR of an evaluation render of each against the ground truth
+(datasets/metrics.py:31-46; train_emernerf.py:634-745).  The oracle side uses torch's own Adam / ChainedScheduler exactly as
+builders.py:50-89,114-142 constructs them.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _run(kind, K, use_graph, table_init):
+    from oracle.train_parity import cotrain
+    key = (kind, K, use_graph, table_init)
+    if key not in _CACHE:
+        _CACHE[key] = cotrain(kind, torch.device("cuda:0"), K=K, rays=512, samples=64, prop_samples=(64, 32), num_iters=200,
+                              table_init=table_init, use_graph=use_graph)
+    return _CACHE[key]
+
+
+@pytest.mark.parametrize("kind,K,use_graph,table_init", [("static", 30, False, 0.3), ("static", 30, True, 0.3), ("static", 30, False, None),
+                                                         ("dynamic", 10, False, 0.3)])
+def test_k_step_training_stays_with_the_oracle(hip_lib, oracle, kind, K, use_graph, table_init):
+    """512 rays x 64 samples (proposal rounds 64 + 32), K steps, num_iters = 200 (so that the K steps cross the LR warm-up:
+    0.01 -> 1 over 20 steps) and a proposal schedule that reaches its one-in-six steady state inside K.  ``table_init`` None = tcnn's
+    +-1e-4 initialisation (the reference's step 0), 0.3 = spatially varying tables."""
+    r = _run(kind, K, use_graph, table_init)
+    assert r["launch_mode"] == ("hipgraph" if use_graph else "eager"), "graph capture fell back to eager launches"
+    assert any(r["prop_flags"]) and not all(r["prop_flags"]), "K steps must contain both step types"
+    hl, rl = np.array(r["hip_losses"]), np.array(r["ref_losses"])
+    assert np.isfinite(hl).all() and np.isfinite(rl).all()
+    assert hl[-5:].mean() < hl[:5].mean(), "training must reduce the loss"
+    print(f"\n[{kind} K={K} graph={use_graph} init={table_init}] loss {hl[0]:.5f} -> {hl[-1]:.5f}; max rel loss diff {r['loss_max_rel_diff']:.2e}; "
+          f"PSNR vs GT hip {r['hip_psnr_vs_gt_db']:.4f} dB / oracle {r['ref_psnr_vs_gt_db']:.4f} dB; travel {r['travel']:.3e}, "
+          f"param l2 diff {r['param_l2_diff']:.3e}, max abs {r['param_max_abs_diff']:.3e}")
+    # (1) the loss trajectory, step by step
+    assert r["loss_max_rel_diff"] <= 1e-3, f"per-step loss differs by {r['loss_max_rel_diff']:.3e} relative"
+    # (2) PSNR against the ground truth after K steps: both paths within 0.05 dB of each other
+    assert abs(r["hip_psnr_vs_gt_db"] - r["ref_psnr_vs_gt_db"]) <= 0.05
+    # (3) the parameters after K steps: the two trajectories' distance is a small fraction of the distance travelled ...
+    assert r["param_l2_diff"] <= 2e-2 * r["travel"], f"parameters differ by {r['param_l2_diff'] / r['travel']:.3e} of the distance travelled"
+    # ... and no MLP / embedding parameter is further apart than a few of Adam's (sign-sized) steps at the final learning rate
+    lr_end = 0.01
+    for name, st in r["param_stats"].items():
+        if not name.endswith("tcnn_encoding.params"):
+            assert st["max_abs_diff"] <= 3 * lr_end, f"{name}: {st['max_abs_diff']:.3e}"
+
+
+def test_graph_and_eager_training_agree(hip_lib, oracle):
+    """The hipGraph-replayed and the eager run of the K-step job end at the same PSNR and the same losses (both were compared with
+    the oracle above; this pins them on each other at a tighter bar)."""
+    a, b = _run("static", 30, False, 0.3), _run("static", 30, True, 0.3)
+    assert max(abs(x - y) / abs(x) for x, y in zip(a["hip_losses"], b["hip_losses"])) <= 2e-4
+    assert abs(a["hip_psnr_vs_gt_db"] - b["hip_psnr_vs_gt_db"]) <= 0.02

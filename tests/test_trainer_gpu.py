@@ -31,6 +31,54 @@ def test_graph_replay_equals_eager(hip_lib):
     assert float((pe - pg).abs().max()) <= 2e-4 * float(pe.abs().max())
 
 
+def test_finite_check_works_under_graph_replay(hip_lib, monkeypatch):
+    """EMER_CHECK_FINITE=1 with the default launch mode: the check cannot read the host inside a capture, so its verdict stays on
+    the device and is read after every replay; a non-finite pixel (hence a non-finite gradient entering the grid backward) raises."""
+    from emernerf_amd import ops
+    monkeypatch.setattr(ops, "CHECK_FINITE", True)
+    tr, data = _make(True)
+    for _ in range(3):
+        tr.train_step(data)
+    assert tr.use_graph and tr._graphs, "the step must be replayed from a graph"
+    assert all(len(v[2]) >= 1 for v in tr._graphs.values()), "the capture must have recorded the deferred checks"
+    bad = {k: v.clone() for k, v in data.items()}
+    bad["pixels"][7, 1] = float("inf")
+    with pytest.raises(FloatingPointError, match="hash-grid backward"):
+        for _ in range(2):
+            tr.train_step(bad)
+
+
+def test_graph_step_survives_a_render_with_another_ray_count(hip_lib):
+    """a captured step graph has the address of the sampler's level-0 histogram baked in; an evaluation chunk or a lidar
+    step with another ray count on the same estimator must not free or replace that tensor.  graph step, render 100 rays, graph
+    step == the same three calls with eager launches."""
+    from emernerf_amd.render_utils import render_rays
+    from emernerf_amd.trainer import synthetic_rays
+    eager, data = _make(False)
+    graph, _ = _make(True)
+    other = synthetic_rays(100, torch.device("cuda:0"), seed=9)
+    for tr in (eager, graph):
+        tr.set_step(1000)
+        for s in range(1000):
+            tr.requires_grad_fn(s)
+    jit100 = torch.full((100,), 0.37, device="cuda:0")
+    jit512 = torch.full((512,), 0.37, device="cuda:0")
+    for tr in (eager, graph):
+        tr.estimator.jitter_fn = lambda n, d: jit512 if n == 512 else jit100
+        for _ in range(3):
+            tr.train_step(data)
+        with torch.no_grad():
+            render_rays(radiance_field=tr.model, proposal_estimator=tr.estimator, proposal_networks=tr.props, data_dict=other, cfg=tr.rcfg)
+        # churn the allocator: if the constant had been freed, this is where its memory would be reused
+        junk = [torch.full((512, 2), 7.0, device="cuda:0") for _ in range(64)]
+        for _ in range(3):
+            tr.train_step(data)
+        del junk
+    assert graph.use_graph
+    pe, pg = eager.flat.params, graph.flat.params
+    assert float((pe - pg).abs().max()) <= 2e-4 * float(pe.abs().max())
+
+
 def test_render_pixels_loop(hip_lib):
     """emernerf_amd.video_utils.render_pixels (reference: radiance_fields/video_utils.py:50-468) over a synthetic split:
     reference key names, image shapes, chunked rendering == one-shot rendering of the same rays."""

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emernerf_amd.trainer import Trainer, synthetic_rays
 dev = torch.device("cuda:0")
 tr = Trainer(kind="static", device=dev)
-tr.step_count = 1001
+tr.set_step(1001)
 for s in range(1001):
     tr.requires_grad_fn(s)
 data = synthetic_rays(8192, dev, seed=1000)
