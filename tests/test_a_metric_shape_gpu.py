@@ -282,9 +282,10 @@ def test_full_step_gradients_vs_oracle(hip_lib, oracle, kind):
                 continue
             scale = float(want.abs().max())
             err = float((got - want).abs().max())
-            # 2e-3 of the parameter's own gradient scale; gradients that are ~1e-5 of the step's largest (the sky head
-            # behind a factor (1 - opacity) on saturated rays) get an absolute floor instead
-            assert err <= 2e-3 * scale + 1e-6 * gmax, f"{prefix + k}: max err {err:.3e} vs scale {scale:.3e}"
+            # 4e-4 of the parameter's own gradient scale (+ 1e-3 of the step's largest MLP gradient: parameters whose whole gradient
+            # is that small are compared on that floor); measured on MI355X: 4e-5 .. 8e-5 over the four models (hinge flips of a
+            # few pre-activations within an ulp of zero among 10^5 .. 10^6 rows)
+            assert err <= 4e-4 * (scale + 1e-3 * gmax), f"{prefix + k}: max err {err:.3e} vs scale {scale:.3e}"
             worst = max(worst, (err / (scale + 1e-3 * gmax), prefix + k))
             checked += 1
     print(f"\n[{kind}] worst gradient error / (own scale + 1e-3 gmax): {worst[0]:.2e} at {worst[1]}")

@@ -72,7 +72,7 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
     assert out["prop_grad"], "the test step must exercise the proposal-net range of the exchange"
     assert calls["prop"] == 1 and calls["early"] == 1, f"buckets not launched exactly once: {calls}"
     torch.cuda.synchronize()
-    torch.save(tr.flat.params.cpu(), os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"params": tr.flat.params.cpu(), "ranges": dict(tr.flat.ranges)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -86,7 +86,8 @@ def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, 
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(port, str(tmp_path), kind, mode, dp_mode, debug), nprocs=2, join=True)
-    p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    p0, p1 = r0["params"], r1["params"]
     assert torch.equal(p0, p1), "replicas diverged after one step"
     tr = _make(1, kind)
     before = tr.flat.params.cpu().clone()
@@ -96,9 +97,7 @@ def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, 
     single = tr.flat.params.cpu()
     n = single.numel()   # (rs_ag pads the groups of the 2-rank buffer: compare group by group)
     if p0.numel() != n:
-        two = _make(2, kind, dp_mode)
-        p0 = torch.cat([p0[a:a + (d - c)] for (a, _), (c, d) in zip(two.flat.ranges.values(), tr.flat.ranges.values())])
-        del two
+        p0 = torch.cat([p0[a:a + (d - c)] for (a, _), (c, d) in zip(r0["ranges"].values(), tr.flat.ranges.values())])
     # Adam's first steps move every touched parameter by ~lr: compare the UPDATES (fp32 reduction order differs)
     du, dv = p0 - before, single - before
     touched = dv.abs() > 0

@@ -43,11 +43,14 @@ def test_k_step_training_stays_with_the_oracle(hip_lib, oracle, kind, K, use_gra
           f"PSNR vs GT hip {r['hip_psnr_vs_gt_db']:.4f} dB / oracle {r['ref_psnr_vs_gt_db']:.4f} dB; travel {r['travel']:.3e}, "
           f"param l2 diff {r['param_l2_diff']:.3e}, max abs {r['param_max_abs_diff']:.3e}")
     # (1) the loss trajectory, step by step
-    assert r["loss_max_rel_diff"] <= 1e-3, f"per-step loss differs by {r['loss_max_rel_diff']:.3e} relative"
-    # (2) PSNR against the ground truth after K steps: both paths within 0.05 dB of each other
-    assert abs(r["hip_psnr_vs_gt_db"] - r["ref_psnr_vs_gt_db"]) <= 0.05
+    # (measured on MI355X: 1e-7 .. 3e-6)
+    assert r["loss_max_rel_diff"] <= 5e-5, f"per-step loss differs by {r['loss_max_rel_diff']:.3e} relative"
+    # (2) PSNR against the ground truth after K steps: both paths within 0.005 dB of each other (measured: equal to 4 decimals)
+    assert abs(r["hip_psnr_vs_gt_db"] - r["ref_psnr_vs_gt_db"]) <= 0.005
     # (3) the parameters after K steps: the two trajectories' distance is a small fraction of the distance travelled ...
-    assert r["param_l2_diff"] <= 2e-2 * r["travel"], f"parameters differ by {r['param_l2_diff'] / r['travel']:.3e} of the distance travelled"
+    # (measured: 6e-5 with +-0.3 tables, 2e-4 dynamic, 1e-3 from tcnn's +-1e-4 initialisation, where most table entries' gradients
+    # are rounding-sized and Adam's first steps are sign-sized)
+    assert r["param_l2_diff"] <= 5e-3 * r["travel"], f"parameters differ by {r['param_l2_diff'] / r['travel']:.3e} of the distance travelled"
     # ... and no MLP / embedding parameter is further apart than a few of Adam's (sign-sized) steps at the final learning rate
     lr_end = 0.01
     for name, st in r["param_stats"].items():
