@@ -309,7 +309,7 @@ def main():
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
-                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd",
+                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd", "emer_rgb_head_bwd_fused",
                               "emer_rmlp_fwd", "emer_rmlp_bwd", "emer_contract_bwd", "emer_blend_accumulate_fwd", "emer_blend_accumulate_bwd",
                               "emer_prop_loss", "emer_ray_epilogue_fwd", "emer_ray_epilogue_bwd", "emer_pixel_loss_fwd", "emer_pixel_loss_bwd",
                               "emer_trunc_exp_fwd", "emer_trunc_exp_bwd", "emer_ray_inputs_fwd", "emer_embed_grad", "emer_ray_pre_fwd",
@@ -570,14 +570,22 @@ def main():
                      "emer_neck_bwd_fused": (dgrad_neck + wgrad_neck, None),
                      "emer_rgb_head_fwd": (2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),
                      "emer_field_fwd": (2.0 * N * (k0 * 64 + 64 * 64) + 2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),  # neck + rgb head in one launch
-                     "emer_rgb_head_bwd": (2.0 * N * (3 * 64 + 3 * 64 * 64), 6.0)}
+                     "emer_rgb_head_bwd": (2.0 * N * (3 * 64 + 3 * 64 * 64), 6.0),
+                     # [r4] data gradients + the weight gradients of the per-sample column blocks (dW1 [64][128], dW0 [64][64]); executed: six
+                     # partial products, the transposer (3 instructions per 16 x 16 operand tile, 16 tiles) and K = 16 weight-gradient steps
+                     # (the instruction issues at the K = 32 rate: x 2), or K = 32 steps with EMER_RGBW_PAIR=1
+                     "emer_rgb_head_bwd_fused": (2.0 * N * (3 * 64 + 3 * 64 * 64) + 2.0 * N * (64 * 128 + 64 * 64), None)}
             for kn, (fl, mult) in flops.items():
                 v = [u for u in breakdown.elapsed_us().get(kn, [])]
                 if kn.startswith("emer_neck"):  # main-field launches only (the proposal nets are the short ones; in the static step the forward runs inside emer_field_fwd)
                     v = sorted(v)[-max(1, breakdown_steps):]
                 if v:
                     t = sum(v) / len(v)
-                    ex = fl * mult if mult is not None else 6.0 * dgrad_neck + 12.0 * wgrad_neck + 3.0 * 2.0 * N * 16 * (3 * 64 + k0)
+                    if kn == "emer_rgb_head_bwd_fused":
+                        pair = os.environ.get("EMER_RGBW_PAIR", "0") == "1"
+                        ex = 6.0 * 2.0 * N * (3 * 64 * 64) + (6.0 if pair else 12.0) * 2.0 * N * (64 * 128 + 64 * 64) + 3.0 * 2.0 * N * 32 * (4 * 64)
+                    else:
+                        ex = fl * mult if mult is not None else 6.0 * dgrad_neck + 12.0 * wgrad_neck + 3.0 * 2.0 * N * 16 * (3 * 64 + k0)
                     mfma[kn] = {"avg_us": t, "achieved": fl / (t * 1e-6) / 1e12, "executed": ex / (t * 1e-6) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": ex / (t * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                                 "vs_fp32_matrix_peak": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}

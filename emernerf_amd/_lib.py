@@ -89,6 +89,9 @@ SIGNATURES = {
     "emer_density_bwd_fused": [_P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P],
     "emer_field_fwd": [_P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P],
+    "emer_rgb_head_bwd_fused_supported": [c_int32],
+    "emer_rgb_head_bwd_fused": [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64,
+                                _P, c_int32, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
@@ -113,6 +116,7 @@ INT64_FUNCTIONS = {
     "emer_linear_bwd_workspace": [c_int64, c_int32, c_int32],
     "emer_neck_bwd_fused_workspace": [c_int32, c_int32, c_int64, c_int32],
     "emer_rgb_head_bwd_workspace": [c_int64],
+    "emer_rgb_head_bwd_fused_workspace": [c_int64, c_int32],
     "emer_density_bwd_fused_workspace": [c_int32, c_int32, c_int64],
 }
 

@@ -46,6 +46,10 @@ int reserve_lds(const void *kernel, size_t bytes, const char *what);
 int launch_dw_reduce(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
                      float *dbias, hipStream_t st);
 
+// ... with column blocks of the [n][k] partial scattered to dw[row * ld_dw + dst[s] + (column - col[s])]; no bias part
+int launch_dw_reduce_cols(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
+                          int32_t n_segs, const int32_t *col, const int32_t *width, const int32_t *dst, hipStream_t st);
+
 // Measurement hook (emer_profile_next): a pair of caller-owned HIP events that the NEXT instrumented launch of this thread
 // records immediately before / after its kernel (hipExtLaunchKernelGGL), so bench.py times the kernel itself and not
 // the host's enqueue latency around it.  One-shot; both null when not armed.

@@ -320,6 +320,20 @@ int launch_dw_reduce(const float *partials, int32_t n_blocks, int64_t stride, in
     return check_launch("dw_reduce");
 }
 
+// The same for a partial whose column blocks go to different places: block s = columns col[s] .. col[s] + width[s] - 1 of the [n][k]
+// partial lands at dw[row * ld_dw + dst[s] ..]; no bias part.
+int launch_dw_reduce_cols(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
+                          int32_t n_segs, const int32_t *col, const int32_t *width, const int32_t *dst, hipStream_t st) {
+    DwDst d = dw_dst_identity(k);
+    d.ld = ld_dw;
+    d.n = n_segs;
+    for (int i = 0; i < n_segs && i < EMER_CHAIN_MAX_SEGS; ++i) { d.col[i] = col[i]; d.width[i] = width[i]; d.dst[i] = dst[i]; }
+    const int64_t extent = (int64_t)n * k;
+    hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(extent, 256), dw_reduce_splits(n_blocks, extent)), dim3(256), 0, st, partials,
+                       n_blocks, stride, (int64_t)n * k, dw, (float *)nullptr, d, extent);
+    return check_launch("dw_reduce_cols");
+}
+
 static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,
                          int64_t ldy, int64_t M, int32_t N, int32_t K, int act, float *aux, hipStream_t st,
                          const float *ya = nullptr, int64_t ldya = 0, int act_a = 0, const float *d_aux = nullptr,

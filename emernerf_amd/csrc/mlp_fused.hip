@@ -1104,6 +1104,446 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
     }
 }
 
+// ----------------------------------------------------------------- rgb backward with the layer-0 / layer-1 weight gradients [r4]
+// rgb_bwd_kernel's data-gradient chain INCLUDING dW1[:, a1 | geo] = dpre1^T [a1 | geo] and dW0[:, geo] = dpre0^T geo: dpre1 and dpre0 never
+// reach memory (the round-3 step wrote 512 B per sample of them and streamed 1280 B per sample back through two weight-gradient
+// launches: 1.9 of the step's 8.4 GB).  What made this "not feasible" at four waves per SIMD is the accumulator count -- 48 tiles of
+// 16 x 16 = 192 registers -- so the kernel runs ONE wave per SIMD (256-lane workgroups, one per CU, up to 512 registers per lane) and
+// does by hand what the other waves of a SIMD do for the four-wave kernels:
+//   * inputs of the next tile are in flight while this one is in the matrix pipe: a2 / a1 go global -> LDS directly
+//     (global_load_lds_dwordx4, lane-major staging as in neck_bwdw_kernel), geo rides in registers;
+//   * four output tiles are interleaved in every chain GEMM (tgemm4), so that consecutive matrix instructions never wait for their own
+//     accumulator; the 48 dW accumulators are independent by construction;
+//   * rows come onto the reduction index through the matrix core (to_rows), and TWO 16-row tiles are paired per dW step: the K = 32
+//     instruction's reduction index enumerates (tile 0: rows 4 g .. 4 g + 3 | tile 1: rows 4 g .. 4 g + 3) on lane group g -- any
+//     bijection of k is a valid GEMM as long as both operands use it -- so an operand is the concatenation of the two tiles' transposer
+//     outputs and the legacy K = 16 instruction (same issue cost, half the work) is not needed.  Tile 0's B operands (a1, geo) wait in
+//     12 KB of wave-private LDS while tile 1 runs through the chain.
+// Per 16 rows: 148 chain + 48 transposer + 144 dW instructions (rgb_bwd_kernel: 148, plus two streaming launches over 1.4 GB).
+// Requires an even number of tiles per ray (S % 32 == 0); other shapes stay on rgb_bwd_kernel + the streamed weight gradients.
+constexpr int kRWThreads = 256;
+
+struct RgbBwdWArgs {
+    const float *dout, *out;            // [n][3]
+    const float *a1, *a2;               // [n][64] saved activations
+    const float *geo; int64_t ld_geo;   // [n][>= 64] the head's per-sample input
+    int32_t tiles_per_ray; int64_t n_rays;
+    WSrc w2t, w1at, w1gt, w0gt;         // transposed views, as RgbBwdArgs
+    float *dgeo;                        // [n][64]
+    float *s1, *s0;                     // [rays][64] sums of dpre1 / dpre0 over the samples of each ray
+    float *partials; int64_t stride;    // per workgroup: dW1 [64][128] (columns: a1 0..63 | geo 64..127) | dW0 [64][64] (geo) | dW2 [3][64] | db2 [3] | pad
+};
+
+struct SwP { u32x4 h, m, l; };  // K = 32 operand of a dW step: one 16-feature tile x (16 rows of tile 0 | 16 rows of tile 1)
+__device__ __forceinline__ SwP pair_rows(const SwT &t0, const SwT &t1) {
+    return SwP{u32x4{t0.h[0], t0.h[1], t1.h[0], t1.h[1]}, u32x4{t0.m[0], t0.m[1], t1.m[0], t1.m[1]}, u32x4{t0.l[0], t0.l[1], t1.l[0], t1.l[1]}};
+}
+
+// acc[p] += W[16 p ..][:] . in for FOUR output tiles at once, the four accumulators interleaved term by term
+template <int KS>
+__device__ __forceinline__ void tgemm4(const W3 w, const Opd<KS> &b, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 fh[4], fm[4], fl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const u32x4 *f = w.p + (p * w.ks + s) * 64;
+            fl[p] = f[2 * w.plane]; fh[p] = f[0]; fm[p] = f[w.plane];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fl[p], b.h[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.l[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.m[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.h[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.m[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.h[s], acc[p]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[p][b0 + i] += A[p]^T B[i] over the 32 paired rows, NB B tiles at a time: 4 NB independent accumulators per term
+template <int NB, int NBT>
+__device__ __forceinline__ void dw_pairs(f32x4 (&acc)[4][NBT], int b0, const SwP (&a)[4], const SwP (&b)[NB]) {
+#define EMER_DWP(X, Y)                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                        \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) acc[p][b0 + i] = EMER_MF(a[p].X, b[i].Y, acc[p][b0 + i]);
+    EMER_DWP(l, h) EMER_DWP(h, l) EMER_DWP(m, m) EMER_DWP(m, h) EMER_DWP(h, m) EMER_DWP(h, h)
+#undef EMER_DWP
+}
+
+// Sum the four waves' weight-gradient accumulators through LDS (the weights are dead) and write one coalesced partial per workgroup.
+__device__ __forceinline__ void rgb_bwdw_epilogue(const RgbBwdWArgs &a, f32x4 (&acc1)[4][8], f32x4 (&acc0)[4][4], float (&w2acc)[3], float b2acc,
+                                                  int wave, int m, int g) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch targets the staging buffers, not the reduction area; drain it anyway
+    __syncthreads();
+    constexpr int P1 = 132, P0 = 68;   // row pitches (floats): the four lane groups of a store hit different banks
+    float *r1 = reinterpret_cast<float *>(smem), *r0 = r1 + 64 * P1, *r2 = r0 + 64 * P0;   // dW1 [64][P1] | dW0 [64][P0] | 4 x 196
+    for (int w = 0; w < kRWThreads / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = r1 + (16 * p + 4 * g + r) * P1 + 16 * b + m;
+                        *q = (w == 0) ? acc1[p][b][r] : *q + acc1[p][b][r];
+                    }
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = r0 + (16 * p + 4 * g + r) * P0 + 16 * b + m;
+                        *q = (w == 0) ? acc0[p][b][r] : *q + acc0[p][b][r];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2[wave * 196 + c * 64 + 16 * (m >> 2) + 4 * g + (m & 3)] = w2acc[c];
+    b2acc = row16_sum(b2acc);
+    if (m == 0 && g < 3) r2[wave * 196 + 192 + g] = b2acc;
+    __syncthreads();
+    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
+    for (int i = threadIdx.x; i < 64 * 128; i += kRWThreads) part[i] = r1[(i >> 7) * P1 + (i & 127)];
+    for (int i = threadIdx.x; i < 64 * 64; i += kRWThreads) part[64 * 128 + i] = r0[(i >> 6) * P0 + (i & 63)];
+    if ((int)threadIdx.x < 195) {
+        float t = 0.0f;
+        for (int w = 0; w < kRWThreads / 64; ++w) t += r2[w * 196 + threadIdx.x];
+        part[64 * 128 + 64 * 64 + threadIdx.x] = t;
+    }
+}
+
+#ifndef EMER_RGBW_TG4
+#define EMER_RGBW_TG4 0
+#endif
+#ifndef EMER_RGBW_TGPAIR
+#define EMER_RGBW_TGPAIR true
+#endif
+#if EMER_RGBW_TG4
+#define EMER_TG(W, B, ACC) tgemm4<2>(W, B, ACC)
+#else
+#define EMER_TG(W, B, ACC) tgemm<2, 4, EMER_RGBW_TGPAIR>(W, B, ACC)
+#endif
+__global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw_kernel(const RgbBwdWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
+    stage_w3(w1al, 4, 2, a.w1at);
+    stage_w3(w1gl, 4, 2, a.w1gt);
+    stage_w3(w0l, 4, 2, a.w0gt);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w0p = w3_at(w0l, 4, 2, lane);
+    const SelE sel = make_sel(lane);
+    float w2a[4];   // W2^T (64 x 3) in four registers, as in rgb_bwd_kernel
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
+    // per wave: staging of the next tile's a2 | a1 (2 x 4 KB, lane-major) and the parked B operands of a pair's first tile (12 KB)
+    float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);
+    u32x2 *park = reinterpret_cast<u32x2 *>(stg + 2048) + lane;   // entry (3 b + term) at park[(3 b + term) * 64]
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+
+    f32x4 acc1[4][8], acc0[4][4];   // dW1 [64][128], dW0 [64][64] as 16 x 16 tiles: lane (j, g), register r = dW[16 p + 4 g + r][16 b + j]
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { zero<8>(acc1[p]); zero<4>(acc0[p]); }
+    float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
+
+    const int tpr = a.tiles_per_ray;
+    const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
+    f32x4 gn[4];   // the next tile's geo rows (registers: needed only at the end of a tile)
+    float yn = 0.0f, dn = 0.0f;   // ... and its sigmoid output / incoming gradient entry (lane (m, g): channel min(g, 2) of row m)
+    const unsigned lo3c = (unsigned)(3 * m + (g < 3 ? g : 2));
+    // tile sequence of this wave: (ray, j) -> (ray, j + 1) ... -> (ray + n_waves, 0); loads are unconditional (past the end the last tile is
+    // read again) and go out right after the previous tile's staging buffer has been read
+    auto issue = [&](int64_t ray, int j) {
+        const int64_t row0 = (ray * tpr + j) * 16;
+        const float *p2 = a.a2 + row0 * 64, *p1 = a.a1 + row0 * 64, *pg = a.geo + row0 * a.ld_geo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p2 + (lo64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p1 + (lo64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gn[p] = *reinterpret_cast<const f32x4 *>(pg + (log + 16u * p));
+        yn = (a.out + row0 * 3)[lo3c];
+        dn = (a.dout + row0 * 3)[lo3c];
+    };
+    if (wave_id < a.n_rays) issue(wave_id, 0);
+    for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
+        // per-ray sums of dpre1 / dpre0 ride on the transposer (its fp32 output, summed over the lane's four rows): lane (j, g) holds the
+        // partial of feature 16 p + j over rows 4 g .. 4 g + 3 of every tile of the ray
+        float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int jp = 0; jp < tpr; jp += 2) {
+            SwT A1t[4], A0t[4];   // first tile of the pair: transposed dpre1 / dpre0 (registers); its a1 / geo operands wait in LDS
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int j = jp + half;
+                float *dgeo = a.dgeo + ((ray * tpr + j) * 16) * 64;
+                // ---- this tile's inputs (issued one tile ago); then the next tile's go out
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                f32x4 m2[4], m1[4], x[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    m2[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
+                    m1[p] = *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane);
+                    x[p] = gn[p];
+                }
+                const float d2 = g < 3 ? dn * yn * (1.0f - yn) : 0.0f;   // sigmoid'; lane (m, g): channel g of row m
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging buffer has been read: it may be overwritten
+                {
+                    int64_t nr = ray; int nj = j + 1;
+                    if (nj == tpr) { nj = 0; nr = ray + n_waves; }
+                    if (nr >= a.n_rays) { nr = ray; nj = j; }
+                    issue(nr, nj);
+                }
+                // ---- a1 (0..3) and geo (4..7) tiles with the rows on the reduction index (B operands of the dW products).  First tile of a
+                // pair: now, straight into LDS (nothing else is live yet); second tile: after its chain, when the chain's registers are free
+                if (half == 0) {
+                    Opd<2> bo;
+                    make_opd<4>(m1, bo);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { const SwT t = to_rows<2>(bo, p, sel); park[(3 * p + 0) * 64] = t.h; park[(3 * p + 1) * 64] = t.m; park[(3 * p + 2) * 64] = t.l; if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                    make_opd<4>(x, bo);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { const SwT t = to_rows<2>(bo, p, sel); park[(3 * (4 + p) + 0) * 64] = t.h; park[(3 * (4 + p) + 1) * 64] = t.m; park[(3 * (4 + p) + 2) * 64] = t.l; if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- the data-gradient chain (rgb_bwd_kernel's), four output tiles interleaved
+                b2acc += d2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dc = __shfl(d2, 16 * c + m, 64);
+                    w2acc[c] += row16_reduce_scatter(m2, dc, m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                Opd<2> d1o, d0o;
+                {
+                    f32x4 d1[4];
+                    zero<4>(d1);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
+                    relu_mask<4>(d1, m2);
+                    make_opd<4>(d1, d1o);
+                }
+                // B operands of the pair for one group of four tiles (bg 0: a1, bg 1: geo): tile 0's half from LDS, tile 1's through the transposer
+                // (two tiles at a time: tiles 2 h, 2 h + 1 of the group are k-step h of the group's split operand)
+                auto pair_b = [&](int bg, int h, SwP (&Bp)[2]) {
+                    f32x4 v[2];
+                    v[0] = bg == 0 ? m1[2 * h] : x[2 * h]; v[1] = bg == 0 ? m1[2 * h + 1] : x[2 * h + 1];
+                    Opd<1> bo;
+                    make_opd<2>(v, bo);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int b = 4 * bg + 2 * h + i;
+                        SwT t0;
+                        t0.h = park[(3 * b + 0) * 64]; t0.m = park[(3 * b + 1) * 64]; t0.l = park[(3 * b + 2) * 64];
+                        Bp[i] = pair_rows(t0, to_rows<1>(bo, i, sel));
+                    }
+                };
+                if (half == 0) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { A1t[p] = to_rows<2>(d1o, p, sel, &s1c[p]); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                } else {
+                    // ---- dW1 += (dpre1 of both tiles)^T [a1 | geo] of both tiles: 32 output tiles x six K = 32 products, sixteen independent
+                    // accumulators per term.  Done HERE, before the rest of the chain: the first tile's dpre1 operands die early
+                    SwP Ap[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { Ap[p] = pair_rows(A1t[p], to_rows<2>(d1o, p, sel, &s1c[p])); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int bh = 0; bh < 4; ++bh) {
+                        SwP Bp[2];
+                        pair_b(bh >> 1, bh & 1, Bp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        dw_pairs<2, 8>(acc1, 2 * bh, Ap, Bp);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                {
+                    f32x4 d0[4];
+                    zero<4>(d0);
+                    EMER_TG(w1ap, d1o, d0);
+                    relu_mask<4>(d0, m1);
+                    make_opd<4>(d0, d0o);
+                }
+                {
+                    f32x4 dg[4];
+                    zero<4>(dg);
+                    EMER_TG(w1gp, d1o, dg);
+                    EMER_TG(w0p, d0o, dg);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo + (lo64 + 16u * p)) = dg[p];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 0) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { A0t[p] = to_rows<2>(d0o, p, sel, &s0c[p]); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                } else {
+                    // ---- dW0 += (dpre0 of both tiles)^T geo of both tiles
+                    SwP Ap[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { Ap[p] = pair_rows(A0t[p], to_rows<2>(d0o, p, sel, &s0c[p])); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        SwP Bp[2];
+                        pair_b(1, h, Bp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        dw_pairs<2, 4>(acc0, 2 * h, Ap, Bp);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            s1c[p] += __shfl_xor(s1c[p], 16, 64); s1c[p] += __shfl_xor(s1c[p], 32, 64);
+            s0c[p] += __shfl_xor(s0c[p], 16, 64); s0c[p] += __shfl_xor(s0c[p], 32, 64);
+            if (g == 0) { a.s1[ray * 64 + 16 * p + m] = s1c[p]; a.s0[ray * 64 + 16 * p + m] = s0c[p]; }
+        }
+    }
+    rgb_bwdw_epilogue(a, acc1, acc0, w2acc, b2acc, wave, m, g);
+}
+
+// The same backward with the dW products on the K = 16 instruction, one 16-row tile at a time (no state carried between tiles, no parked
+// operands: 484 matrix instructions per tile instead of 340, but half the live registers).  Any S % 16 == 0.
+__global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
+    stage_w3(w1al, 4, 2, a.w1at);
+    stage_w3(w1gl, 4, 2, a.w1gt);
+    stage_w3(w0l, 4, 2, a.w0gt);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w0p = w3_at(w0l, 4, 2, lane);
+    const SelE sel = make_sel(lane);
+    float w2a[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
+    float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);   // a2 | a1 of the next tile (same LDS footprint as the paired kernel)
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    f32x4 acc1[4][8], acc0[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { zero<8>(acc1[p]); zero<4>(acc0[p]); }
+    float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
+    const int tpr = a.tiles_per_ray;
+    const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
+    const unsigned lo3c = (unsigned)(3 * m + (g < 3 ? g : 2));
+    f32x4 gn[4];
+    float yn = 0.0f, dn = 0.0f;
+    auto issue = [&](int64_t ray, int j) {
+        const int64_t row0 = (ray * tpr + j) * 16;
+        const float *p2 = a.a2 + row0 * 64, *p1 = a.a1 + row0 * 64, *pg = a.geo + row0 * a.ld_geo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p2 + (lo64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p1 + (lo64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gn[p] = *reinterpret_cast<const f32x4 *>(pg + (log + 16u * p));
+        yn = (a.out + row0 * 3)[lo3c];
+        dn = (a.dout + row0 * 3)[lo3c];
+    };
+    if (wave_id < a.n_rays) issue(wave_id, 0);
+    for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
+        float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < tpr; ++j) {
+            float *dgeo = a.dgeo + ((ray * tpr + j) * 16) * 64;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            f32x4 m2[4], m1[4], x[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                m2[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
+                m1[p] = *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane);
+                x[p] = gn[p];
+            }
+            const float d2 = g < 3 ? dn * yn * (1.0f - yn) : 0.0f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                int64_t nr = ray; int nj = j + 1;
+                if (nj == tpr) { nj = 0; nr = ray + n_waves; }
+                if (nr >= a.n_rays) { nr = ray; nj = j; }
+                issue(nr, nj);
+            }
+            b2acc += d2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dc = __shfl(d2, 16 * c + m, 64);
+                w2acc[c] += row16_reduce_scatter(m2, dc, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Opd<2> d1o, d0o;
+            {
+                f32x4 d1[4];
+                zero<4>(d1);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
+                relu_mask<4>(d1, m2);
+                make_opd<4>(d1, d1o);
+            }
+            {
+                f32x4 d0[4];
+                zero<4>(d0);
+                EMER_TG(w1ap, d1o, d0);
+                relu_mask<4>(d0, m1);
+                make_opd<4>(d0, d0o);
+            }
+            {
+                f32x4 dg[4];
+                zero<4>(dg);
+                EMER_TG(w1gp, d1o, dg);
+                EMER_TG(w0p, d0o, dg);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo + (lo64 + 16u * p)) = dg[p];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- dW1 += dpre1^T [a1 | geo], dW0 += dpre0^T geo on this tile's 16 rows
+            SwT Bt[8];
+            {
+                Opd<2> bo;
+                make_opd<4>(m1, bo);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Bt[p] = to_rows<2>(bo, p, sel);
+                make_opd<4>(x, bo);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) Bt[4 + p] = to_rows<2>(bo, p, sel);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                SwT As[1];
+                As[0] = to_rows<2>(d1o, p, sel, &s1c[p]);
+                dw_tiles<1, 8>(*reinterpret_cast<f32x4 (*)[1][8]>(&acc1[p]), As, Bt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                SwT As[1];
+                As[0] = to_rows<2>(d0o, p, sel, &s0c[p]);
+                dw_tiles<1, 4>(*reinterpret_cast<f32x4 (*)[1][4]>(&acc0[p]), As, *reinterpret_cast<const SwT (*)[4]>(&Bt[4]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            s1c[p] += __shfl_xor(s1c[p], 16, 64); s1c[p] += __shfl_xor(s1c[p], 32, 64);
+            s0c[p] += __shfl_xor(s0c[p], 16, 64); s0c[p] += __shfl_xor(s0c[p], 32, 64);
+            if (g == 0) { a.s1[ray * 64 + 16 * p + m] = s1c[p]; a.s0[ray * 64 + 16 * p + m] = s0c[p]; }
+        }
+    }
+    rgb_bwdw_epilogue(a, acc1, acc0, w2acc, b2acc, wave, m, g);
+}
+
 // ------------------------------------------------------------------------ density MLP backward with its weight gradients
 // Backward of density_fwd_kernel (narrow input, L F <= 16) INCLUDING dW0, db0, dW1, db1 -- the proposal network's step.  The
 // hidden layer is recomputed from the encoding (two k-steps of the fp32 matrix instruction), the gradient of the single
@@ -1697,6 +2137,68 @@ extern "C" int emer_rgb_head_bwd(const float *dout, const float *out, const floa
     if (int rc = check_launch("rgb_head_bwd")) return rc;
     if (dw2) return launch_dw_reduce(workspace, (int32_t)grid, 196, 3, 64, dw2, ld_dw2, db2, as_stream(stream));
     return EMER_OK;
+}
+
+// ---- rgb head backward with the weight gradients of layers 0 / 1 (per-sample column blocks) and 2 fused [r4] -------------------------
+static inline uint32_t rgb_bwdw_grid(int64_t n_rays) {
+    int64_t blocks = (n_rays + kRWThreads / 64 - 1) / (kRWThreads / 64);
+    if (blocks > 256) blocks = 256;   // persistent: one 4-wave workgroup per CU (one wave per SIMD)
+    return (uint32_t)(blocks < 1 ? 1 : blocks);
+}
+static constexpr int64_t kRgbBwdWStride = 64 * 128 + 64 * 64 + 196;
+// 1 when emer_rgb_head_bwd_fused covers the shape (whole 16-row tiles per ray, as emer_rgb_head_bwd)
+extern "C" int emer_rgb_head_bwd_fused_supported(int32_t samples_per_ray) {
+    return (samples_per_ray >= 16 && samples_per_ray % 16 == 0) ? 1 : 0;
+}
+
+extern "C" int64_t emer_rgb_head_bwd_fused_workspace(int64_t n_rays, int32_t samples_per_ray) {
+    if (n_rays <= 0 || !emer_rgb_head_bwd_fused_supported(samples_per_ray)) return 0;
+    return (int64_t)rgb_bwdw_grid(n_rays) * kRgbBwdWStride;
+}
+// Backward of emer_rgb_head_fwd INCLUDING the weight gradients of the per-sample column blocks: writes dgeo [n][64] and the per-ray
+// sums s1 / s0 [rays][64] of dpre1 / dpre0 (what the per-ray operands need: emer_ray_wgrad, emer_ray_pre_bwd); ACCUMULATES (+=)
+//   dw1[:, 0:64] += dpre1^T a1,  dw1[:, 64 + kh : 128 + kh] += dpre1^T geo   (dw1 [64][ld_dw1 >= 128 + kh], torch layout of layers.1.weight),
+//   dw0[:, kh : kh + 64] += dpre0^T geo                                        (dw0 [64][ld_dw0 >= 64 + kh]),
+//   dw2 [3][ld_dw2 >= 64] += dpre2^T a2,  db2 [3] += column sums of dpre2.
+// Neither dpre1 nor dpre0 (nor dpre2) is written.  geo [n][ld_geo] is the forward's input.
+extern "C" int emer_rgb_head_bwd_fused(const float *dout, const float *out, const float *a1, const float *a2, const float *geo, int64_t ld_geo,
+                                       int64_t n_rays, int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1, const float *w2,
+                                       float *dgeo, float *s1, float *s0, float *workspace, float *dw0, int64_t ld_dw0, float *dw1,
+                                       int64_t ld_dw1, float *dw2, int64_t ld_dw2, float *db2, int32_t pair_tiles, void *stream) {
+    EMER_REQUIRE(n_rays >= 0 && kh >= 0, "rgb_head_bwd_fused: bad sizes");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(emer_rgb_head_bwd_fused_supported(samples_per_ray), "rgb_head_bwd_fused: samples_per_ray must be a multiple of 16 (got %d)", samples_per_ray);
+    EMER_REQUIRE(dout && out && a1 && a2 && geo && w0 && w1 && w2 && dgeo && s1 && s0 && workspace && dw0 && dw1 && dw2 && db2,
+                 "rgb_head_bwd_fused: null pointer");
+    EMER_REQUIRE(ld_geo >= 64 && ld_geo % 4 == 0 && ld_dw0 >= 64 + kh && ld_dw1 >= 128 + kh && ld_dw2 >= 64, "rgb_head_bwd_fused: bad leading dimension");
+    EMER_REQUIRE(n_rays * samples_per_ray * ld_geo < ((int64_t)1 << 40), "rgb_head_bwd_fused: batch too large");
+    RgbBwdWArgs a;
+    a.dout = dout; a.out = out; a.a1 = a1; a.a2 = a2; a.geo = geo; a.ld_geo = ld_geo; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
+    const int64_t k0 = kh + 64, k1 = 64 + k0;
+    a.w2t = WSrc{w2, 1, 64, 64, 3};
+    a.w1at = WSrc{w1, 1, k1, 64, 64};
+    a.w1gt = WSrc{w1 + 64 + kh, 1, k1, 64, 64};
+    a.w0gt = WSrc{w0 + kh, 1, k0, 64, 64};
+    a.dgeo = dgeo; a.s1 = s1; a.s0 = s0; a.partials = workspace; a.stride = kRgbBwdWStride;
+    const size_t lds = (size_t)(3 * w3_units(4, 2)) * 16 + (size_t)(kRWThreads / 64) * (2048 + 3072) * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    const uint32_t grid = rgb_bwdw_grid(n_rays);
+    // pair_tiles: two row tiles per weight-gradient step (K = 32 products, 340 instead of 484 matrix instructions per tile; needs an even
+    // number of tiles per ray and more registers than the compiler currently fits without spilling a few accumulators) / one tile per step
+    if (pair_tiles && samples_per_ray % 32 == 0) {
+        if (int rc = set_lds(rgb_bwdw_kernel, lds, "rgb_head_bwd_fused")) return rc;
+        hipLaunchKernelGGL(rgb_bwdw_kernel, dim3(grid), dim3(kRWThreads), lds, st, a);
+    } else {
+        if (int rc = set_lds(rgb_bwdw16_kernel, lds, "rgb_head_bwd_fused")) return rc;
+        hipLaunchKernelGGL(rgb_bwdw16_kernel, dim3(grid), dim3(kRWThreads), lds, st, a);
+    }
+    if (int rc = check_launch("rgb_head_bwd_fused")) return rc;
+    // the workgroups' partials -> the parameters' gradients (+=): dW1's two column blocks land 0.. and 64 + kh.., dW0's at kh..
+    const int32_t c1[2] = {0, 64}, w1c[2] = {64, 64}, d1c[2] = {0, 64 + kh};
+    if (int rc = launch_dw_reduce_cols(workspace, (int32_t)grid, kRgbBwdWStride, 64, 128, dw1, ld_dw1, 2, c1, w1c, d1c, st)) return rc;
+    const int32_t c0[1] = {0}, w0c[1] = {64}, d0c[1] = {kh};
+    if (int rc = launch_dw_reduce_cols(workspace + 64 * 128, (int32_t)grid, kRgbBwdWStride, 64, 64, dw0, ld_dw0, 1, c0, w0c, d0c, st)) return rc;
+    return launch_dw_reduce(workspace + 64 * 128 + 64 * 64, (int32_t)grid, kRgbBwdWStride, 3, 64, dw2, ld_dw2, db2, st);
 }
 
 // floats of workspace emer_rgb_head_bwd needs when it also produces dw2 / db2

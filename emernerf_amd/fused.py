@@ -17,6 +17,7 @@ the shapes every shipped config uses: ``emer_neck_*``, ``emer_rgb_head_*``) and 
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes
 from ctypes import c_int32, c_int64, c_void_p
 from typing import Optional, Tuple
@@ -192,6 +193,8 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
 
 
 FUSED_WGRAD = True   # weight gradients inside the backward kernels where the library has them (emer_neck_bwd_fused); False: separate pass
+FUSED_RGB_WGRAD = os.environ.get("EMER_FUSE_RGB_WGRAD", "1") != "0"   # ... of the rgb head's layers 0 / 1 too (emer_rgb_head_bwd_fused) [r4]
+RGB_WGRAD_PAIR = os.environ.get("EMER_RGBW_PAIR", "0") == "1"         # its variant that pairs two row tiles per weight-gradient step
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
 
 
@@ -588,9 +591,6 @@ class _RgbHeadFn(torch.autograd.Function):
         assert H == _r4(H)
         dev = g.device
         if ctx.fast:
-            dpre2 = torch.empty((N, C), device=dev, dtype=torch.float32)
-            dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
-            dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
             dgeo = torch.empty((N, NG), device=dev, dtype=torch.float32)
             s1 = torch.empty((R, H), device=dev, dtype=torch.float32)
             s0 = torch.empty((R, H), device=dev, dtype=torch.float32)
@@ -601,6 +601,24 @@ class _RgbHeadFn(torch.autograd.Function):
             tb1, rb1 = _target(sb1, (H,), dev)
             tw0, rw0 = _target(sw0, (H, K0), dev)
             tb0, rb0 = _target(sb0, (H,), dev)
+            n_ws = int(_lib.load().emer_rgb_head_bwd_fused_workspace(R, S)) if (FUSED_WGRAD and FUSED_RGB_WGRAD) else 0
+            if n_ws > 0:
+                # [r4] the weight gradients of the per-sample column blocks of layers 0 / 1 (and layer 2) inside the backward kernel:
+                # dpre1 / dpre0 never reach memory and the two streamed weight-gradient launches are gone
+                ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
+                with torch.cuda.device(dev):
+                    _lib.call("emer_rgb_head_bwd_fused", _p(_c(dout)), _p(out), _p(a1), _p(a2), _p(g), g.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2),
+                              _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2), tw2.stride(0), _p(tb2),
+                              1 if RGB_WGRAD_PAIR else 0, _stream(g))
+                ray_wgrad([(s1, [(hr, Kh, H)], tw1, tb1), (s0, [(hr, Kh, 0)], tw0, tb0)], g)
+                dhray = torch.empty((R, Kh), device=dev, dtype=torch.float32)
+                with torch.cuda.device(dev):
+                    _lib.call("emer_ray_pre_bwd", _p(s0), _p(s1), H, R, Kh, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dhray), Kh,
+                              _stream(g))
+                return dhray, dgeo, None, rw0, rb0, rw1, rb1, rw2, rb2, None
+            dpre2 = torch.empty((N, C), device=dev, dtype=torch.float32)
+            dpre1 = torch.empty((N, H), device=dev, dtype=torch.float32)
+            dpre0 = torch.empty((N, H), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
                 # the output layer's weight gradient (3 x 64 + 3 numbers) rides along in the backward kernel, where a2 and
                 # dpre2 are in registers: a separate pass would re-read 280 MB for it

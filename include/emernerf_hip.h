@@ -479,6 +479,23 @@ int emer_rgb_head_bwd(const float *dout, const float *out, const float *a1, cons
                       const float *w2, float *dpre2, float *dpre1, float *dpre0, float *dgeo, float *s1,
                       float *s0, float *workspace, float *dw2, int64_t ld_dw2, float *db2, void *stream);
 
+/* The same backward INCLUDING the weight gradients of the per-sample column blocks of layers 0 / 1 (autograd of
+ * mlp.py:38-46 for radiance_field.py:130-143,622-658): neither dpre1 nor dpre0 reaches memory and no separate weight-gradient
+ * pass reads them back.  Writes dgeo [n][64] and s1 / s0 [rays][64]; ACCUMULATES (+=)
+ *   dw1[:, 0:64] += dpre1^T a1,  dw1[:, 64 + kh : 128 + kh] += dpre1^T geo   (dw1 [64][ld_dw1 >= 128 + kh]: layers.1.weight),
+ *   dw0[:, kh : kh + 64] += dpre0^T geo                                        (dw0 [64][ld_dw0 >= 64 + kh]: layers.0.weight),
+ *   dw2 [3][ld_dw2 >= 64] += dpre2^T a2,  db2 [3] += column sums of dpre2.
+ * The per-ray column blocks (hray) and b0 / b1 follow from s1 / s0 (emer_ray_wgrad, emer_ray_pre_bwd).  geo [n][ld_geo] is the
+ * forward's input.  samples_per_ray % 16 == 0; workspace: emer_rgb_head_bwd_fused_workspace(n_rays, samples_per_ray) floats.
+ * pair_tiles != 0 (and samples_per_ray % 32 == 0): the variant that pairs two 16-row tiles per weight-gradient step. */
+int emer_rgb_head_bwd_fused_supported(int32_t samples_per_ray);
+int64_t emer_rgb_head_bwd_fused_workspace(int64_t n_rays, int32_t samples_per_ray);
+int emer_rgb_head_bwd_fused(const float *dout, const float *out, const float *a1, const float *a2, const float *geo,
+                            int64_t ld_geo, int64_t n_rays, int32_t samples_per_ray, int32_t kh, const float *w0,
+                            const float *w1, const float *w2, float *dgeo, float *s1, float *s0, float *workspace,
+                            float *dw0, int64_t ld_dw0, float *dw1, int64_t ld_dw1, float *dw2, int64_t ld_dw2,
+                            float *db2, int32_t pair_tiles, void *stream);
+
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */
 int emer_trunc_exp_fwd(const float *x, int64_t x_stride, float *y, int64_t n, void *stream);

@@ -151,10 +151,15 @@ def test_hashgrid_sliced_is_run_to_run_stable(hip_lib, oracle):
 
 
 # ------------------------------------------------------------------------------------------ fused heads
-def test_heads_metric_rows(hip_lib):
+@pytest.mark.parametrize("rgbw", ["tile", "paired", "streamed"])
+def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):
     """neck / rgb head forward, data gradients and weight gradients at 1 048 576 rows (8192 rays x 128 samples)
-    against fp64 torch evaluated on the GPU, every row and every weight gradient compared."""
+    against fp64 torch evaluated on the GPU, every row and every weight gradient compared.  ``rgbw``: the rgb head's layer-0 / 1
+    weight gradients inside the backward kernel (one 16-row tile per step -- the default -- or two paired tiles per step) or as the
+    round-3 streamed passes."""
     from emernerf_amd import fused
+    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", rgbw != "streamed")
+    monkeypatch.setattr(fused, "RGB_WGRAD_PAIR", rgbw == "paired")
     dev = _dev()
     g = torch.Generator().manual_seed(3)
     R, S, Kh, L, Fe = 8192, 128, 49, 16, 2

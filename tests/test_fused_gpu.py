@@ -106,11 +106,16 @@ def test_density_mlp(hip_lib, monkeypatch, L, N, Fe, fusedw):
         _close("density_nograd", fused.density_mlp(*[v.detach() for v in t]), d_ref)
 
 
-@pytest.mark.parametrize("fusedw", [True, False])  # output layer's weight gradient inside the backward kernel / separate pass
-@pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64), (5000, 16, 49, 64, 64)])
+# weight gradients: all inside the backward kernel (one row tile per step / two paired tiles per step), only the output layer's
+# inside it (round 3: layers 0 / 1 streamed), or every one as a separate pass
+@pytest.mark.parametrize("fusedw", ["all", "all_paired", "w2_only", False])
+@pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64), (5000, 16, 49, 64, 64),
+                                          (1031, 32, 49, 64, 64), (2, 96, 17, 64, 192)])
 def test_rgb_head(hip_lib, monkeypatch, R, S, Kh, NG, ld, fusedw):
     from emernerf_amd import fused
-    monkeypatch.setattr(fused, "FUSED_WGRAD", fusedw)
+    monkeypatch.setattr(fused, "FUSED_WGRAD", bool(fusedw))
+    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", fusedw in ("all", "all_paired"))
+    monkeypatch.setattr(fused, "RGB_WGRAD_PAIR", fusedw == "all_paired")
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(R * S + Kh)
     N, H, K0 = R * S, 64, Kh + NG
