@@ -662,9 +662,14 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
     };
     struct Raw { f32x4 d[4], x[KT0]; float dd, de; };
     if (t_begin < t_end) issue(t_begin);
+    // [r4] denc of a tile is stored at the START of the next tile, behind that tile's wait: stores count in vmcnt like loads here, so a
+    // store issued mid-tile would still be in flight at the next `s_waitcnt vmcnt(0)` and the wave would sit out its acknowledgement
+    f32x4 dep[KT0];
+    int64_t tile_prev = -1;
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         Raw cur;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs have landed (issued one tile ago)
+        if (tile_prev >= 0) st_lm_t<KT0, F>(a.denc + tile_prev * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, tile_prev * 16 + m < a.n, g, dep);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             cur.d[p] = a.d0 ? *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -735,7 +740,9 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             f32x4 de[KT0];
             zero<KT0>(de);
             tgemm<2, KT0, false>(w0p, dao, de);
-            st_lm_t<KT0, F>(a.denc + tile * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, ok, g, de);
+#pragma unroll
+            for (int b = 0; b < KT0; ++b) dep[b] = de[b];
+            tile_prev = tile;
             {   // dW0 += dPre0^T enc
                 SwT xs[KT0];
 #pragma unroll
@@ -750,6 +757,7 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             }
         }
     }
+    if (tile_prev >= 0) st_lm_t<KT0, F>(a.denc + tile_prev * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, tile_prev * 16 + m < a.n, g, dep);
     // ---- sum the waves through LDS (the weights are dead: the buffer takes their place), one coalesced partial per workgroup
     __syncthreads();
     float *red = reinterpret_cast<float *>(smem);   // dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
@@ -1166,6 +1174,44 @@ __device__ __forceinline__ void tgemm4(const W3 w, const Opd<KS> &b, f32x4 (&acc
     }
 }
 
+// The same without scheduling barriers (one fragment set per k-step): for sections whose instruction mix is laid out with
+// sched_group_barrier pipelines (EMER_PIPE) instead
+template <int KS>
+__device__ __forceinline__ void tgemm4_free(const W3 w, const Opd<KS> &b, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 fh[4], fm[4], fl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const u32x4 *f = w.p + (p * w.ks + s) * 64;
+            fl[p] = f[2 * w.plane]; fh[p] = f[0]; fm[p] = f[w.plane];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fl[p], b.h[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.l[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.m[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.h[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.m[s], acc[p]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.h[s], acc[p]);
+    }
+}
+// N times { NM matrix instructions, NV vector instructions }: the instruction mix of a section, for the scheduler (it may only pick
+// instructions whose operands are ready, so a pattern that asks for more of a kind than the section holds just ends early)
+#ifdef EMER_USE_PIPE
+#define EMER_PIPE(N, NM, NV)                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) {          \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);       \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);       \
+    }
+#else
+#define EMER_PIPE(N, NM, NV)
+#endif
+
 // acc[p][b0 + i] += A[p]^T B[i] over the 32 paired rows, NB B tiles at a time: 4 NB independent accumulators per term
 template <int NB, int NBT>
 __device__ __forceinline__ void dw_pairs(f32x4 (&acc)[4][NBT], int b0, const SwP (&a)[4], const SwP (&b)[NB]) {
@@ -1414,8 +1460,41 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw_kernel(const RgbBwdWAr
     rgb_bwdw_epilogue(a, acc1, acc0, w2acc, b2acc, wave, m, g);
 }
 
-// The same backward with the dW products on the K = 16 instruction, one 16-row tile at a time (no state carried between tiles, no parked
-// operands: 484 matrix instructions per tile instead of 340, but half the live registers).  Any S % 16 == 0.
+// The same backward one 16-row tile at a time (no state carried between tiles, no parked operands, half the live registers), with the dW
+// products on v_mfma_f32_32x32x16_bf16: its reduction index is 16 long -- one row tile -- and one instruction covers a 32 x 32 block of
+// dW (four of the 16 x 16 tiles) in 32.5 cycles, where four K = 16 instructions of the 16 x 16 shape cost 79.  The operand of a 32-feature
+// block -- lane (i, kg): feature i of the block, eight rows -- is two transposer outputs (lane (j, g): rows 4 g .. 4 g + 3 of feature j)
+// after ONE v_permlane16_swap_b32 per register: lanes 16-31 / 48-63 take the second tile's rows 0-3 / 8-11 from lanes 0-15 / 32-47 and
+// give the first tile's rows 4-7 / 12-15 back, which leaves lane (i, kg) with rows 8 kg .. 8 kg + 7 of its feature.
+// Per tile: 148 chain + 48 transposer (16 x 16 x 32) + 72 dW (32 x 32 x 16) instructions.  Any S % 16 == 0.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+#define EMER_MF32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+// two 16-feature tiles (rows on the reduction index) -> the operand of their 32-feature block
+__device__ __forceinline__ SwP block32(const SwT &ta, const SwT &tb) {
+    SwP o;
+#define EMER_SWAP(T)                                                                      \
+    {                                                                                     \
+        const auto r0 = __builtin_amdgcn_permlane16_swap(ta.T[0], tb.T[0], false, false); \
+        const auto r1 = __builtin_amdgcn_permlane16_swap(ta.T[1], tb.T[1], false, false); \
+        o.T = u32x4{r0[0], r1[0], r0[1], r1[1]};                                          \
+    }
+    EMER_SWAP(h) EMER_SWAP(m) EMER_SWAP(l)
+#undef EMER_SWAP
+    return o;
+}
+// acc[q] += A^T B[q] over the tile's 16 rows for NQ 32-feature blocks of B: six partial products, NQ independent accumulators per term
+template <int NQ>
+__device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const SwP (&b)[NQ]) {
+#define EMER_DWB(X, Y) _Pragma("unroll") for (int q = 0; q < NQ; ++q) acc[q] = EMER_MF32(a.X, b[q].Y, acc[q]);
+    EMER_DWB(l, h) EMER_DWB(h, l) EMER_DWB(m, m) EMER_DWB(m, h) EMER_DWB(h, m) EMER_DWB(h, h)
+#undef EMER_DWB
+}
+
+#ifndef EMER_RGBW_NOSB
+#define EMER_RGBW_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EMER_RGBW_SB()
+#endif
 __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
@@ -1432,9 +1511,19 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
     float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);   // a2 | a1 of the next tile (same LDS footprint as the paired kernel)
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
-    f32x4 acc1[4][8], acc0[4][4];
+    // dW1 [64][128] and dW0 [64][64] as 32 x 32 blocks: lane (j, h), register r = dW[32 P + 8 (r >> 2) + 4 h + (r & 3)][32 Q + j]
+    f32x16 acc1[2][4], acc0[2][2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { zero<8>(acc1[p]); zero<4>(acc0[p]); }
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[P][Q][r] = 0.0f;
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[P][Q][r] = 0.0f;
+    }
     float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
     const int tpr = a.tiles_per_ray;
     const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
@@ -1455,11 +1544,21 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
         dn = (a.dout + row0 * 3)[lo3c];
     };
     if (wave_id < a.n_rays) issue(wave_id, 0);
+    // dgeo of a tile is STORED AT THE START OF THE NEXT TILE, right behind that tile's wait for its inputs: on this part stores count in
+    // vmcnt like loads, so a store issued mid-tile is still in flight at the next `s_waitcnt vmcnt(0)` and the wave sits out its write
+    // acknowledgement (measured: 90 of 420 us); issued behind the wait it has a whole tile to drain.  The values stay where the matrix
+    // pipe left them (accumulator registers) in the meantime.
+    f32x4 dgp[4];
+    float *dgeo_prev = nullptr;
     for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
         float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int j = 0; j < tpr; ++j) {
             float *dgeo = a.dgeo + ((ray * tpr + j) * 16) * 64;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (dgeo_prev) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
+            }
             f32x4 m2[4], m1[4], x[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1475,13 +1574,10 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
                 if (nr >= a.n_rays) { nr = ray; nj = j; }
                 issue(nr, nj);
             }
-            b2acc += d2;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float dc = __shfl(d2, 16 * c + m, 64);
-                w2acc[c] += row16_reduce_scatter(m2, dc, m);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // Order of the tile body.  One wave per SIMD: whatever overlaps, overlaps inside this instruction stream, so every GEMM of the
+            // chain (matrix pipe, few vector instructions) is written next to vector work that does not depend on it -- the output layer's
+            // weight gradient next to the first GEMM, the split + transposition of the B operands (a1, geo) next to the two GEMMs of dgeo --
+            // and the scheduler is free to interleave inside a section (EMER_RGBW_SB() closes a section).
             Opd<2> d1o, d0o;
             {
                 f32x4 d1[4];
@@ -1491,48 +1587,60 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
                 relu_mask<4>(d1, m2);
                 make_opd<4>(d1, d1o);
             }
+            EMER_RGBW_SB();
+            f32x4 dg[4];
+            zero<4>(dg);
             {
                 f32x4 d0[4];
                 zero<4>(d0);
-                EMER_TG(w1ap, d1o, d0);
+                tgemm4_free<2>(w1ap, d1o, d0);
+                b2acc += d2;   // (independent of the GEMM: dW2 / db2 ride along)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float dc = __shfl(d2, 16 * c + m, 64);
+                    w2acc[c] += row16_reduce_scatter(m2, dc, m);
+                }
+                EMER_PIPE(24, 2, 10)
+                EMER_RGBW_SB();
+                // dgeo's first half does not depend on d0: it runs while d0 is masked and split
+                tgemm4_free<2>(w1gp, d1o, dg);
                 relu_mask<4>(d0, m1);
                 make_opd<4>(d0, d0o);
+                EMER_PIPE(24, 2, 8)
             }
+            EMER_RGBW_SB();
+            SwP Bq[4];   // a1 features 0-31, 32-63; geo features 0-31, 32-63 (rows on the reduction index, 32-feature blocks)
             {
-                f32x4 dg[4];
-                zero<4>(dg);
-                EMER_TG(w1gp, d1o, dg);
-                EMER_TG(w0p, d0o, dg);
+                tgemm4_free<2>(w0p, d0o, dg);
+                {
+                    Opd<2> bo;
+                    make_opd<4>(m1, bo);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo + (lo64 + 16u * p)) = dg[p];
+                    for (int q = 0; q < 2; ++q) Bq[q] = block32(to_rows<2>(bo, 2 * q, sel), to_rows<2>(bo, 2 * q + 1, sel));
+                    make_opd<4>(x, bo);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) Bq[2 + q] = block32(to_rows<2>(bo, 2 * q, sel), to_rows<2>(bo, 2 * q + 1, sel));
+                }
+                EMER_PIPE(36, 2, 16)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dgp[p] = dg[p];
+                dgeo_prev = dgeo;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- dW1 += dpre1^T [a1 | geo], dW0 += dpre0^T geo on this tile's 16 rows
-            SwT Bt[8];
-            {
-                Opd<2> bo;
-                make_opd<4>(m1, bo);
+            EMER_RGBW_SB();
+            // ---- dW1 += dpre1^T [a1 | geo], dW0 += dpre0^T geo on this tile's 16 rows, as 32 x 32 blocks
 #pragma unroll
-                for (int p = 0; p < 4; ++p) Bt[p] = to_rows<2>(bo, p, sel);
-                make_opd<4>(x, bo);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) Bt[4 + p] = to_rows<2>(bo, p, sel);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                SwT As[1];
-                As[0] = to_rows<2>(d1o, p, sel, &s1c[p]);
-                dw_tiles<1, 8>(*reinterpret_cast<f32x4 (*)[1][8]>(&acc1[p]), As, Bt);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int P = 0; P < 2; ++P) {
+                const SwT t0 = to_rows<2>(d1o, 2 * P, sel, &s1c[2 * P]), t1 = to_rows<2>(d1o, 2 * P + 1, sel, &s1c[2 * P + 1]);
+                const SwP A = block32(t0, t1);
+                dw_blocks<4>(acc1[P], A, Bq);
             }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                SwT As[1];
-                As[0] = to_rows<2>(d0o, p, sel, &s0c[p]);
-                dw_tiles<1, 4>(*reinterpret_cast<f32x4 (*)[1][4]>(&acc0[p]), As, *reinterpret_cast<const SwT (*)[4]>(&Bt[4]));
-                __builtin_amdgcn_sched_barrier(0);
+            for (int P = 0; P < 2; ++P) {
+                const SwT t0 = to_rows<2>(d0o, 2 * P, sel, &s0c[2 * P]), t1 = to_rows<2>(d0o, 2 * P + 1, sel, &s0c[2 * P + 1]);
+                const SwP A = block32(t0, t1);
+                dw_blocks<2>(acc0[P], A, *reinterpret_cast<const SwP (*)[2]>(&Bq[2]));
             }
+            EMER_RGBW_SB();
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1541,7 +1649,51 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
             if (g == 0) { a.s1[ray * 64 + 16 * p + m] = s1c[p]; a.s0[ray * 64 + 16 * p + m] = s0c[p]; }
         }
     }
-    rgb_bwdw_epilogue(a, acc1, acc0, w2acc, b2acc, wave, m, g);
+    if (dgeo_prev) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
+    }
+    // ---- sum the four waves through LDS (the weights are dead), one coalesced partial per workgroup (the paired kernel's layout)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int P1 = 132, P0 = 68;
+    float *r1 = reinterpret_cast<float *>(smem), *r0 = r1 + 64 * P1, *r2 = r0 + 64 * P0;
+    const int j32 = lane & 31, h32 = lane >> 5;
+    for (int w = 0; w < kRWThreads / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+#pragma unroll
+                for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *q = r1 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * P1 + 32 * Q + j32;
+                        *q = (w == 0) ? acc1[P][Q][r] : *q + acc1[P][Q][r];
+                    }
+#pragma unroll
+                for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *q = r0 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * P0 + 32 * Q + j32;
+                        *q = (w == 0) ? acc0[P][Q][r] : *q + acc0[P][Q][r];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2[wave * 196 + c * 64 + 16 * (m >> 2) + 4 * g + (m & 3)] = w2acc[c];
+    b2acc = row16_sum(b2acc);
+    if (m == 0 && g < 3) r2[wave * 196 + 192 + g] = b2acc;
+    __syncthreads();
+    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
+    for (int i = threadIdx.x; i < 64 * 128; i += kRWThreads) part[i] = r1[(i >> 7) * P1 + (i & 127)];
+    for (int i = threadIdx.x; i < 64 * 64; i += kRWThreads) part[64 * 128 + i] = r0[(i >> 6) * P0 + (i & 63)];
+    if ((int)threadIdx.x < 195) {
+        float t = 0.0f;
+        for (int w = 0; w < kRWThreads / 64; ++w) t += r2[w * 196 + threadIdx.x];
+        part[64 * 128 + 64 * 64 + threadIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------ density MLP backward with its weight gradients

@@ -41,6 +41,17 @@ def head_backward_us(mode: str, R=8192, S=128, Kh=49, reps=12):
 
 
 if __name__ == "__main__":
+    if "--lib" in sys.argv:   # time one mode on another build of the library (tools/build_variant.sh <tag> ...): fresh process per build
+        i = sys.argv.index("--lib")
+        tag, mode = sys.argv[i + 1], (sys.argv[i + 2] if len(sys.argv) > i + 2 else "tile")
+        import emernerf_amd._lib as L
+        import emernerf_amd._build as B
+        if tag != "base":
+            L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libemernerf_{tag}.so")
+            B.build = lambda *a, **k: L.LIB_PATH
+        r = [head_backward_us(mode) for _ in range(2)]
+        print(json.dumps({"lib": tag, "mode": mode, "median_us": [round(x["median_us"], 1) for x in r], "min_us": [round(x["min_us"], 1) for x in r]}))
+        sys.exit(0)
     res = {"head_backward": {m: head_backward_us(m) for m in ("streamed", "tile", "paired", "streamed", "tile", "paired")[:3]}}
     res["head_backward_again"] = {m: head_backward_us(m) for m in ("paired", "tile", "streamed")}
     if "--bench" in sys.argv:
