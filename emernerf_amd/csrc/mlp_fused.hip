@@ -591,6 +591,30 @@ __device__ __forceinline__ void dw_tiles(f32x4 (&acc)[NA][NB], const SwT (&a)[NA
 #undef EMER_DW_PASS
 }
 
+struct SwP { u32x4 h, m, l; };  // eight reduction-index entries per lane and term: the operand of a K = 32 (16 x 16) or K = 16 (32 x 32) dW step
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+#define EMER_MF32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+// two 16-feature tiles (rows on the reduction index) -> the operand of their 32-feature block
+__device__ __forceinline__ SwP block32(const SwT &ta, const SwT &tb) {
+    SwP o;
+#define EMER_SWAP(T)                                                                      \
+    {                                                                                     \
+        const auto r0 = __builtin_amdgcn_permlane16_swap(ta.T[0], tb.T[0], false, false); \
+        const auto r1 = __builtin_amdgcn_permlane16_swap(ta.T[1], tb.T[1], false, false); \
+        o.T = u32x4{r0[0], r1[0], r0[1], r1[1]};                                          \
+    }
+    EMER_SWAP(h) EMER_SWAP(m) EMER_SWAP(l)
+#undef EMER_SWAP
+    return o;
+}
+// acc[q] += A^T B[q] over the tile's 16 rows for NQ 32-feature blocks of B: six partial products, NQ independent accumulators per term
+template <int NQ>
+__device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const SwP (&b)[NQ]) {
+#define EMER_DWB(X, Y) _Pragma("unroll") for (int q = 0; q < NQ; ++q) acc[q] = EMER_MF32(a.X, b[q].Y, acc[q]);
+    EMER_DWB(l, h) EMER_DWB(h, l) EMER_DWB(m, m) EMER_DWB(m, h) EMER_DWB(h, m) EMER_DWB(h, h)
+#undef EMER_DWB
+}
+
 constexpr int kWThreads = 512;  // fused backward: 8 waves, ONE workgroup per CU = 2 waves per SIMD (<= 256 registers); the weights (48-72 KB) are
                                 // staged once per CU and leave room for 7-10 KB of per-wave staging
 
@@ -621,13 +645,25 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2, lane), w0fp = w3_at(w0fl, 4, KS0, lane);
     const SelE sel = make_sel(lane);
-    f32x4 aw1[4][4], aw0[4][KT0];   // dW1 [64][64], dW0 [64][K0P] as 16x16 tiles
+    // [r4] dW1 [64][64] and dW0 [64][K0P] as 32 x 32 blocks on v_mfma_f32_32x32x16_bf16 (one instruction per block and partial product
+    // where the 16 x 16 x 16 shape needed four at the same issue cost each; operands: two transposer outputs joined by v_permlane16_swap,
+    // see block32): lane (j, h), register r = dW[32 P + 8 (r >> 2) + 4 h + (r & 3)][32 Q + j]
+    constexpr int QB = (KT0 + 1) / 2;   // 32-feature blocks of the encoding (the last one half empty when KT0 is odd)
+    f32x16 bw1[2][2], bw0[2][QB];
     float ab1[4], ab0[4];           // bias gradients: this lane's rows 4 g .. 4 g + 3 of feature 16 p + m
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        zero<4>(aw1[p]); zero<KT0>(aw0[p]);
-        ab1[p] = 0.0f; ab0[p] = 0.0f;
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bw1[P][Q][r] = 0.0f;
+#pragma unroll
+        for (int Q = 0; Q < QB; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bw0[P][Q][r] = 0.0f;
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ab1[p] = 0.0f; ab0[p] = 0.0f; }
     // Each wave owns a contiguous range of 16-row tiles.  With two waves per SIMD nothing else hides the HBM latency, so the
     // inputs of tile t + 1 are in flight while tile t is in the matrix pipe -- WITHOUT holding them in registers (the
     // accumulators leave none: a register prefetch was spilled to scratch by the compiler, i.e. loaded, waited for and
@@ -683,7 +719,7 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             const bool ok = row < a.n;
             const float fix = ok ? cur.dd * fminf(cur.de, 3269017.3724721107f) : 0.0f;
             // enc tile -> operand of dW0 (xs) and, through the first layer, h1: operand of dW1 (hs) and relu'(h1) as 16 bits
-            SwT hs[4];
+            SwP hq[2];   // h1 features 0-31, 32-63 with the rows on the reduction index
             unsigned relu_bits = 0u;
             {
 #pragma unroll
@@ -710,7 +746,7 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
                 Opd<2> ho;
                 make_opd<4>(h, ho);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) hs[p] = to_rows<2>(ho, p, sel);
+                for (int q = 0; q < 2; ++q) hq[q] = block32(to_rows<2>(ho, 2 * q, sel), to_rows<2>(ho, 2 * q + 1, sel));
             }
             f32x4 da[4];
             zero<4>(da);
@@ -724,10 +760,9 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
                 make_opd<4>(cur.d, dop);
                 tgemm<2, 4, false>(w1p, dop, da);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {   // dW1 rows 16 p .. += d^T h1, one row block of tiles at a time
-                    SwT ds[1];
-                    ds[0] = to_rows<2>(dop, p, sel, &ab1[p]);
-                    dw_tiles<1, 4>(*reinterpret_cast<f32x4 (*)[1][4]>(&aw1[p]), ds, hs);
+                for (int P = 0; P < 2; ++P) {   // dW1 rows 32 P .. += d^T h1
+                    const SwT t0 = to_rows<2>(dop, 2 * P, sel, &ab1[2 * P]), t1 = to_rows<2>(dop, 2 * P + 1, sel, &ab1[2 * P + 1]);
+                    dw_blocks<2>(bw1[P], block32(t0, t1), hq);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -744,14 +779,19 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
             for (int b = 0; b < KT0; ++b) dep[b] = de[b];
             tile_prev = tile;
             {   // dW0 += dPre0^T enc
-                SwT xs[KT0];
+                SwP xq[QB];
 #pragma unroll
-                for (int b = 0; b < KT0; ++b) { xs[b].h = park[(3 * b + 0) * 64]; xs[b].m = park[(3 * b + 1) * 64]; xs[b].l = park[(3 * b + 2) * 64]; }
+                for (int q = 0; q < QB; ++q) {
+                    SwT xa, xb;
+                    xa.h = park[(3 * (2 * q) + 0) * 64]; xa.m = park[(3 * (2 * q) + 1) * 64]; xa.l = park[(3 * (2 * q) + 2) * 64];
+                    if (2 * q + 1 < KT0) { xb.h = park[(3 * (2 * q + 1) + 0) * 64]; xb.m = park[(3 * (2 * q + 1) + 1) * 64]; xb.l = park[(3 * (2 * q + 1) + 2) * 64]; }
+                    else { xb.h = u32x2{0u, 0u}; xb.m = u32x2{0u, 0u}; xb.l = u32x2{0u, 0u}; }
+                    xq[q] = block32(xa, xb);
+                }
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    SwT ds[1];
-                    ds[0] = to_rows<2>(dao, p, sel, &ab0[p]);
-                    dw_tiles<1, KT0>(*reinterpret_cast<f32x4 (*)[1][KT0]>(&aw0[p]), ds, xs);
+                for (int P = 0; P < 2; ++P) {
+                    const SwT t0 = to_rows<2>(dao, 2 * P, sel, &ab0[2 * P]), t1 = to_rows<2>(dao, 2 * P + 1, sel, &ab0[2 * P + 1]);
+                    dw_blocks<QB>(bw0[P], block32(t0, t1), xq);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -767,29 +807,34 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
         ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64);
         ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64);
     }
+    const int j32 = lane & 31, h32 = lane >> 5;
     for (int w = 0; w < kWThreads / 64; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int P = 0; P < 2; ++P) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int Q = 0; Q < 2; ++Q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float *q = r1 + (16 * p + 4 * g + r) * 64 + 16 * b + m;
-                        *q = (w == 0) ? aw1[p][b][r] : *q + aw1[p][b][r];
+                    for (int r = 0; r < 16; ++r) {
+                        float *q = r1 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * 64 + 32 * Q + j32;
+                        *q = (w == 0) ? bw1[P][Q][r] : *q + bw1[P][Q][r];
                     }
 #pragma unroll
-                for (int b = 0; b < KT0; ++b)
+                for (int Q = 0; Q < QB; ++Q)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float *q = r0 + (16 * p + 4 * g + r) * K0P + 16 * b + m;
-                        *q = (w == 0) ? aw0[p][b][r] : *q + aw0[p][b][r];
+                    for (int r = 0; r < 16; ++r) {
+                        if (32 * Q + j32 < K0P) {   // (the upper half of an odd last block has no column in the K0P-wide buffer)
+                            float *q = r0 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * K0P + 32 * Q + j32;
+                            *q = (w == 0) ? bw0[P][Q][r] : *q + bw0[P][Q][r];
+                        }
                     }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
                 if (g == 0) {
                     rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
                     rb0[16 * p + m] = (w == 0) ? ab0[p] : rb0[16 * p + m] + ab0[p];
                 }
-            }
         }
         __syncthreads();
     }
@@ -1142,7 +1187,6 @@ struct RgbBwdWArgs {
     float *partials; int64_t stride;    // per workgroup: dW1 [64][128] (columns: a1 0..63 | geo 64..127) | dW0 [64][64] (geo) | dW2 [3][64] | db2 [3] | pad
 };
 
-struct SwP { u32x4 h, m, l; };  // K = 32 operand of a dW step: one 16-feature tile x (16 rows of tile 0 | 16 rows of tile 1)
 __device__ __forceinline__ SwP pair_rows(const SwT &t0, const SwT &t1) {
     return SwP{u32x4{t0.h[0], t0.h[1], t1.h[0], t1.h[1]}, u32x4{t0.m[0], t0.m[1], t1.m[0], t1.m[1]}, u32x4{t0.l[0], t0.l[1], t1.l[0], t1.l[1]}};
 }
@@ -1199,6 +1243,26 @@ __device__ __forceinline__ void tgemm4_free(const W3 w, const Opd<KS> &b, f32x4 
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.h[s], acc[p]);
     }
+}
+// One software-pipeline stage of a chain GEMM for the one-wave kernels: the A fragments of two output tiles at one k-step (six
+// ds_read_b128), loaded ONE STAGE AHEAD of the twelve matrix instructions that use them -- with a single wave per SIMD nothing else
+// covers the LDS latency of a read issued right in front of its use (measured: ~2500 of 14000 cycles per tile sat in s_waitcnt).
+struct Frag6 { u32x4 l[2], h[2], m[2]; };
+__device__ __forceinline__ void ld_frag6(Frag6 &f, const W3 w, int s, int pp) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const u32x4 *q = w.p + ((2 * pp + i) * w.ks + s) * 64;
+        f.l[i] = q[2 * w.plane]; f.h[i] = q[0]; f.m[i] = q[w.plane];
+    }
+}
+template <int KS>
+__device__ __forceinline__ void mma_frag6(const Frag6 &f, const Opd<KS> &b, int s, f32x4 &a0, f32x4 &a1) {
+    a0 = EMER_MF(f.l[0], b.h[s], a0); a1 = EMER_MF(f.l[1], b.h[s], a1);
+    a0 = EMER_MF(f.h[0], b.l[s], a0); a1 = EMER_MF(f.h[1], b.l[s], a1);
+    a0 = EMER_MF(f.m[0], b.m[s], a0); a1 = EMER_MF(f.m[1], b.m[s], a1);
+    a0 = EMER_MF(f.m[0], b.h[s], a0); a1 = EMER_MF(f.m[1], b.h[s], a1);
+    a0 = EMER_MF(f.h[0], b.m[s], a0); a1 = EMER_MF(f.h[1], b.m[s], a1);
+    a0 = EMER_MF(f.h[0], b.h[s], a0); a1 = EMER_MF(f.h[1], b.h[s], a1);
 }
 // N times { NM matrix instructions, NV vector instructions }: the instruction mix of a section, for the scheduler (it may only pick
 // instructions whose operands are ready, so a pattern that asks for more of a kind than the section holds just ends early)
@@ -1467,29 +1531,6 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw_kernel(const RgbBwdWAr
 // after ONE v_permlane16_swap_b32 per register: lanes 16-31 / 48-63 take the second tile's rows 0-3 / 8-11 from lanes 0-15 / 32-47 and
 // give the first tile's rows 4-7 / 12-15 back, which leaves lane (i, kg) with rows 8 kg .. 8 kg + 7 of its feature.
 // Per tile: 148 chain + 48 transposer (16 x 16 x 32) + 72 dW (32 x 32 x 16) instructions.  Any S % 16 == 0.
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-#define EMER_MF32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
-// two 16-feature tiles (rows on the reduction index) -> the operand of their 32-feature block
-__device__ __forceinline__ SwP block32(const SwT &ta, const SwT &tb) {
-    SwP o;
-#define EMER_SWAP(T)                                                                      \
-    {                                                                                     \
-        const auto r0 = __builtin_amdgcn_permlane16_swap(ta.T[0], tb.T[0], false, false); \
-        const auto r1 = __builtin_amdgcn_permlane16_swap(ta.T[1], tb.T[1], false, false); \
-        o.T = u32x4{r0[0], r1[0], r0[1], r1[1]};                                          \
-    }
-    EMER_SWAP(h) EMER_SWAP(m) EMER_SWAP(l)
-#undef EMER_SWAP
-    return o;
-}
-// acc[q] += A^T B[q] over the tile's 16 rows for NQ 32-feature blocks of B: six partial products, NQ independent accumulators per term
-template <int NQ>
-__device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const SwP (&b)[NQ]) {
-#define EMER_DWB(X, Y) _Pragma("unroll") for (int q = 0; q < NQ; ++q) acc[q] = EMER_MF32(a.X, b[q].Y, acc[q]);
-    EMER_DWB(l, h) EMER_DWB(h, l) EMER_DWB(m, m) EMER_DWB(m, h) EMER_DWB(h, m) EMER_DWB(h, h)
-#undef EMER_DWB
-}
-
 #ifndef EMER_RGBW_NOSB
 #define EMER_RGBW_SB() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -1550,6 +1591,8 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
     // pipe left them (accumulator registers) in the meantime.
     f32x4 dgp[4];
     float *dgeo_prev = nullptr;
+    Frag6 fa, fb;
+    ld_frag6(fa, w1ap, 0, 0);
     for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
         float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int j = 0; j < tpr; ++j) {
@@ -1574,10 +1617,12 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
                 if (nr >= a.n_rays) { nr = ray; nj = j; }
                 issue(nr, nj);
             }
-            // Order of the tile body.  One wave per SIMD: whatever overlaps, overlaps inside this instruction stream, so every GEMM of the
-            // chain (matrix pipe, few vector instructions) is written next to vector work that does not depend on it -- the output layer's
-            // weight gradient next to the first GEMM, the split + transposition of the B operands (a1, geo) next to the two GEMMs of dgeo --
-            // and the scheduler is free to interleave inside a section (EMER_RGBW_SB() closes a section).
+            // Order of the tile body.  One wave per SIMD: whatever overlaps, overlaps inside this instruction stream.  The three GEMMs of the
+            // chain run as twelve stages of twelve matrix instructions (two output tiles x one k-step x six partial products); every stage
+            // first issues the NEXT stage's weight-fragment reads (the last one of a tile: the next tile's first), then its matrix
+            // instructions, then a share of the vector work that does not depend on them -- the output layer's weight gradient next to the
+            // first GEMM, the masking / splitting of d0 next to dgeo's d1 half, the split + transposition of the B operands (a1, geo) next to
+            // its d0 half.  EMER_RGBW_SB() pins the stage order; inside a stage the scheduler is free.
             Opd<2> d1o, d0o;
             {
                 f32x4 d1[4];
@@ -1588,44 +1633,63 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
                 make_opd<4>(d1, d1o);
             }
             EMER_RGBW_SB();
-            f32x4 dg[4];
-            zero<4>(dg);
-            {
-                f32x4 d0[4];
-                zero<4>(d0);
-                tgemm4_free<2>(w1ap, d1o, d0);
-                b2acc += d2;   // (independent of the GEMM: dW2 / db2 ride along)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float dc = __shfl(d2, 16 * c + m, 64);
-                    w2acc[c] += row16_reduce_scatter(m2, dc, m);
-                }
-                EMER_PIPE(24, 2, 10)
-                EMER_RGBW_SB();
-                // dgeo's first half does not depend on d0: it runs while d0 is masked and split
-                tgemm4_free<2>(w1gp, d1o, dg);
-                relu_mask<4>(d0, m1);
-                make_opd<4>(d0, d0o);
-                EMER_PIPE(24, 2, 8)
+            f32x4 dg[4], d0[4];
+            zero<4>(dg); zero<4>(d0);
+            SwP Bq[4];   // a1 features 0-31, 32-63; geo features 0-31, 32-63 (rows on the reduction index, 32-feature blocks)
+            // ---- GEMM 1: d0 = W1a^T d1 (stages 0-3) next to dW2 / db2
+            ld_frag6(fb, w1ap, 0, 1); mma_frag6<2>(fa, d1o, 0, d0[0], d0[1]);
+            b2acc += d2;
+            { const float dc = __shfl(d2, m, 64); w2acc[0] += row16_reduce_scatter(m2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1ap, 1, 0); mma_frag6<2>(fb, d1o, 0, d0[2], d0[3]);
+            { const float dc = __shfl(d2, 16 + m, 64); w2acc[1] += row16_reduce_scatter(m2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fb, w1ap, 1, 1); mma_frag6<2>(fa, d1o, 1, d0[0], d0[1]);
+            { const float dc = __shfl(d2, 32 + m, 64); w2acc[2] += row16_reduce_scatter(m2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1gp, 0, 0); mma_frag6<2>(fb, d1o, 1, d0[2], d0[3]);
+            EMER_RGBW_SB();
+            // ---- GEMM 2: dgeo += W1g^T d1 (stages 4-7) next to the mask and split of d0
+            ld_frag6(fb, w1gp, 0, 1); mma_frag6<2>(fa, d1o, 0, dg[0], dg[1]);
+            relu_mask<4>(d0, m1);
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1gp, 1, 0); mma_frag6<2>(fb, d1o, 0, dg[2], dg[3]);
+            {   // k-step 0 of the split operand = tiles 0, 1; k-step 1 = tiles 2, 3
+                f32x4 v[2] = {d0[0], d0[1]};
+                Opd<1> o1;
+                make_opd<2>(v, o1);
+                d0o.h[0] = o1.h[0]; d0o.m[0] = o1.m[0]; d0o.l[0] = o1.l[0];
             }
             EMER_RGBW_SB();
-            SwP Bq[4];   // a1 features 0-31, 32-63; geo features 0-31, 32-63 (rows on the reduction index, 32-feature blocks)
+            ld_frag6(fb, w1gp, 1, 1); mma_frag6<2>(fa, d1o, 1, dg[0], dg[1]);
             {
-                tgemm4_free<2>(w0p, d0o, dg);
-                {
-                    Opd<2> bo;
-                    make_opd<4>(m1, bo);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) Bq[q] = block32(to_rows<2>(bo, 2 * q, sel), to_rows<2>(bo, 2 * q + 1, sel));
-                    make_opd<4>(x, bo);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) Bq[2 + q] = block32(to_rows<2>(bo, 2 * q, sel), to_rows<2>(bo, 2 * q + 1, sel));
-                }
-                EMER_PIPE(36, 2, 16)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) dgp[p] = dg[p];
-                dgeo_prev = dgeo;
+                f32x4 v[2] = {d0[2], d0[3]};
+                Opd<1> o1;
+                make_opd<2>(v, o1);
+                d0o.h[1] = o1.h[0]; d0o.m[1] = o1.m[0]; d0o.l[1] = o1.l[0];
             }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w0p, 0, 0); mma_frag6<2>(fb, d1o, 1, dg[2], dg[3]);
+            Opd<2> bo;
+            make_opd<4>(m1, bo);
+            EMER_RGBW_SB();
+            // ---- GEMM 3: dgeo += W0g^T d0 (stages 8-11) next to the B operands of the dW products
+            ld_frag6(fb, w0p, 0, 1); mma_frag6<2>(fa, d0o, 0, dg[0], dg[1]);
+            Bq[0] = block32(to_rows<2>(bo, 0, sel), to_rows<2>(bo, 1, sel));
+            EMER_RGBW_SB();
+            ld_frag6(fa, w0p, 1, 0); mma_frag6<2>(fb, d0o, 0, dg[2], dg[3]);
+            Bq[1] = block32(to_rows<2>(bo, 2, sel), to_rows<2>(bo, 3, sel));
+            EMER_RGBW_SB();
+            ld_frag6(fb, w0p, 1, 1); mma_frag6<2>(fa, d0o, 1, dg[0], dg[1]);
+            make_opd<4>(x, bo);
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1ap, 0, 0); mma_frag6<2>(fb, d0o, 1, dg[2], dg[3]);   // (fa: the next tile's first stage)
+            Bq[2] = block32(to_rows<2>(bo, 0, sel), to_rows<2>(bo, 1, sel));
+            EMER_RGBW_SB();
+            Bq[3] = block32(to_rows<2>(bo, 2, sel), to_rows<2>(bo, 3, sel));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dgp[p] = dg[p];
+            dgeo_prev = dgeo;
             EMER_RGBW_SB();
             // ---- dW1 += dpre1^T [a1 | geo], dW0 += dpre0^T geo on this tile's 16 rows, as 32 x 32 blocks
 #pragma unroll
