@@ -190,7 +190,10 @@ struct SlicePlan {
     uint32_t total_items;
 };
 
-constexpr uint32_t kSchedBlock = 32;  // consecutive work items dealt to one XCD (= its CU count: one round)
+#ifndef EMER_SLICE_THREADS
+#define EMER_SLICE_THREADS 1024   // owner workgroup: 1024 lanes with a 128 KiB slice (one per CU), or -- r4 experiment, see DESIGN 4.1 -- 512 lanes
+#endif                            // with a 64 KiB slice (two per CU: 128 slices per hashed level, 256-row bitmaps)
+constexpr uint32_t kSchedBlock = EMER_SLICE_THREADS == 1024 ? 32 : 64;  // consecutive work items dealt to one XCD (= its resident owners: one round)
 static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
     // fitted to tools/kbench.py --per-level on MI355X (1M samples, ms on one XCD): coarse levels pay for
     // same-address LDS adds (many samples per cell), dense levels for the ordered scan + run reduction
@@ -219,7 +222,7 @@ static float item_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) 
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     SlicePlan p;
     const uint32_t F = g->n_features;
-    const uint32_t max_entries = (128u * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
+    const uint32_t max_entries = ((EMER_SLICE_THREADS == 1024 ? 128u : 64u) * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
     p.max_local = 0; p.ok = 1;
     for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) { p.shift[l] = 0; p.n_slices[l] = 0; p.n_ranges[l] = 1; p.gsub[l] = 0; }
     for (uint32_t l = 0; l < g->n_levels; ++l) {
@@ -555,7 +558,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // trace[0] = item counter; record i at trace[8 + 4 i] = {level | slice << 8 | range << 24 | block << 40, start, end, hits}
 __device__ unsigned long long *g_sliced_trace = nullptr;
 #endif
-constexpr int kSliceThreads = 1024;
+#ifndef EMER_PACE
+#define EMER_PACE 0        // soft pacing of the owners of a scheduling block (r4 experiment; measured): off
+#endif
+#ifndef EMER_PACE_LEAD
+#define EMER_PACE_LEAD 2   // a wave may run at most this many 65 536-sample trips ahead of the slowest wave of its block
+#endif
+constexpr int kSliceThreads = EMER_SLICE_THREADS;
 constexpr int kSliceWaves = kSliceThreads / 64;
 #ifndef EMER_STRIDED_MAX_RES
 #define EMER_STRIDED_MAX_RES 420
@@ -912,7 +921,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                                                                                    const float *__restrict__ dout, int64_t sn, int64_t sl,
                                                                                    const uint64_t *__restrict__ masks,
                                                                                    uint32_t *__restrict__ work_ctr,
-                                                                                   float *__restrict__ grad, int64_t N) {
+                                                                                   float *__restrict__ grad, int64_t N,
+                                                                                   uint32_t *__restrict__ pace, uint32_t pace_trips) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ uint32_t s_item;
     // Persistent workgroups with XCD-affine work lists.  Each XCD has a list of (level, slice, range) items -- whole
@@ -951,12 +961,19 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // local index on the XCD's list -> global item index (blocks of kSchedBlock dealt round-robin) -> (level, slice, range)
     uint32_t j = item & 0xFFFFFFu;
     j = ((j / kSchedBlock) * 8u + xcd) * kSchedBlock + (j % kSchedBlock);
+#if EMER_PACE
+    const uint32_t gj = j;   // global item index: block gj / kSchedBlock is one round of one XCD's CUs
+    uint32_t lvl_base = 0;   // global index of the level's first item
+#endif
     uint32_t level = 0, slice = 0, range = 0;
     for (uint32_t oi = 0; oi < g.n_levels; ++oi) {
         level = plan.order[oi];
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
         if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; break; }
         j -= nb;
+#if EMER_PACE
+        lvl_base += nb;
+#endif
     }
     const LevelInfo li = level_info(g, level);
 #ifdef EMER_SLICED_TRACE
@@ -984,6 +1001,20 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     unsigned long long *Hv = reinterpret_cast<unsigned long long *>(scratch + 64);  // (one type for plain and atomic accesses)
     uint32_t *El = reinterpret_cast<uint32_t *>(scratch + 128), *Hx = reinterpret_cast<uint32_t *>(scratch + 160);
 
+#if EMER_PACE
+    // Soft pacing of a round [r4 experiment, DESIGN 4.1]: the (up to) 32 items of a scheduling block are the slices of ONE level that one
+    // XCD's CUs work on together; each 128-byte x / dout line is wanted by ~10 of them, but they drift apart in the sample stream and
+    // only a third of those requests hit in the XCD's L2.  Here every wave counts the 65 536-sample trips it has finished in a per-block
+    // counter and does not start trip t before ALL waves of the block have finished trip t - EMER_PACE_LEAD: the block's owners stay
+    // within EMER_PACE_LEAD trips of each other.  Only for blocks that lie entirely on an unsplit hashed level (every member paces);
+    // members that have not started yet are picked up by CUs that never wait on this block (items are taken in order), so the wait
+    // cannot deadlock.
+    const uint32_t blk = gj / kSchedBlock;
+    const uint32_t blk_first = blk * kSchedBlock, blk_last = (blk_first + kSchedBlock < plan.total_items ? blk_first + kSchedBlock : plan.total_items) - 1u;
+    const bool paced = pace_trips != 0u && li.hashed && n_ranges == 1u && blk_first >= lvl_base && blk_last < lvl_base + plan.n_slices[level];
+    uint32_t *pc = pace + (size_t)blk * 64u;
+    const uint32_t pace_full = (blk_last - blk_first + 1u) * (uint32_t)kSliceWaves;
+#endif
     for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
     // second-pair queue (pairable levels): wave-private ring of kPairQueue words behind the compaction scratch
@@ -1019,8 +1050,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     uint32_t q_head = 0, q_len = 0;
     const int64_t my_word = dense ? (int64_t)lane * kSliceWaves + wave : (int64_t)threadIdx.x;
     const int64_t wave_word0 = dense ? wave : wave * 64;
-    const uint32_t lane_word_shift = dense ? 4u : 0u;  // log2 of the word stride between neighbouring lanes (kSliceWaves = 16)
-    static_assert(kSliceWaves == 16, "lane_word_shift assumes 16 waves");
+    const uint32_t lane_word_shift = dense ? (kSliceWaves == 16 ? 4u : 3u) : 0u;  // log2 of the word stride between neighbouring lanes (= log2 kSliceWaves)
+    static_assert(kSliceWaves == 16 || kSliceWaves == 8, "lane_word_shift assumes 16 or 8 waves");
     // ---- the hit stream of this item, as GROUPS of up to KG chunks of 64 hits --------------------------------------
     // next_trip() compacts the next non-empty 1024-word trip into the wave's scratch (hv / hexcl / total / n_chunks);
     // issue(G) materialises the next KG chunks of the current trip -- sample ids, then the x / dout gathers, left IN
@@ -1036,6 +1067,20 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     uint64_t pre = (w_begin + my_word < w_end) ? bm[w_begin + my_word] : 0ull;
     auto next_trip = [&]() __attribute__((always_inline)) -> bool {
         while (wbase < w_end) {
+#if EMER_PACE
+            if (!dense && paced) {   // (wave-uniform)
+                const uint32_t t = (uint32_t)((wbase - w_begin) / kSliceThreads);   // the trip about to start
+                if (t > 0u && lane == 0) __hip_atomic_fetch_add(pc + (t - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // trip t - 1 is done
+                if (t >= (uint32_t)EMER_PACE_LEAD) {
+                    for (;;) {
+                        uint32_t v = lane == 0 ? __hip_atomic_load(pc + (t - (uint32_t)EMER_PACE_LEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                        if (v >= pace_full) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+#endif
             const uint64_t wv = pre;
             trip_w0 = (uint32_t)wbase;
             wbase += kSliceThreads;
@@ -1583,7 +1628,11 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     ZeroRegions zr;
     zr.count = 0;
     uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * (64 * plan.mask_q) * (size_t)ceil_div(n, 64));
-    zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = 8; ++zr.count;
+    // (EMER_PACE builds: 64 blocks x 64 trip counters behind the cursors, zeroed with them; larger launches run unpaced)
+    uint32_t *pace = work_ctr + 16;
+    const uint32_t n_trips = (uint32_t)ceil_div(ceil_div(n, 64), kSliceThreads), n_blk = (total_items + kSchedBlock - 1u) / kSchedBlock;
+    const uint32_t pace_trips = (EMER_PACE && n_trips <= 64u && n_blk <= 64u && n_trips > (uint32_t)EMER_PACE_LEAD) ? n_trips : 0u;
+    zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = pace_trips ? 16u + 64u * 64u : 8u; ++zr.count;
     for (uint32_t l = 0; l < g->n_levels; ++l) {
         if (plan.n_ranges[l] > 1u) {
             zr.p[zr.count] = grad + (size_t)g->offset[l] * F; zr.n[zr.count] = g->size[l] * F; ++zr.count;
@@ -1592,7 +1641,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     hipLaunchKernelGGL(zero_regions_kernel, dim3(64, (uint32_t)zr.count), dim3(256), 0, as_stream(stream), zr);
     if (int rc = check_launch("hashgrid_bwd_params_sliced(zero)")) return rc;
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
-    uint32_t n_blocks = 256;
+    uint32_t n_blocks = EMER_SLICE_THREADS == 1024 ? 256 : 512;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
     const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * (kScanWords * sizeof(uint64_t) + kPairQueue * sizeof(uint32_t)) + kSelectLutBytes;
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
@@ -1601,7 +1650,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
         if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
         const ProfileEvents ev = take_profile_events();
         EMER_LAUNCH_PROFILED(ev, kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
-                           slice_masks, work_ctr, grad, n);
+                           slice_masks, work_ctr, grad, n, pace, pace_trips);
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }

@@ -52,7 +52,7 @@ def _dtype_tag(t: Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------ hash grid
-MASK_SCRATCH = 16  # EMER_SLICE_MASK_SCRATCH: work cursors of the backward behind the bitmaps
+MASK_SCRATCH = 2064  # EMER_SLICE_MASK_SCRATCH: work cursors (and pacing counters) of the backward behind the bitmaps
 
 
 def sliced_supported(desc: GridDesc) -> bool:

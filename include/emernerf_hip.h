@@ -85,7 +85,7 @@ int emer_grid_desc_init(emer_grid_desc *host_desc, uint32_t n_dims, uint32_t n_l
  *   lives in slice s of level l.  The buffer must hold EMER_SLICE_MASK_SCRATCH more words behind the bitmaps
  *   (work cursors of the backward).
  * Replaces native.fwd (tcnn_modules.py:122). */
-#define EMER_SLICE_MASK_SCRATCH 16
+#define EMER_SLICE_MASK_SCRATCH 2064 /* 8 work cursors + (builds with owner pacing) 64 x 64 trip counters, as 32-bit words in 64-bit units */
 int emer_hashgrid_fwd(const emer_grid_desc *host_desc, const float *x, const void *params,
                       int param_dtype, float *out, int64_t out_stride_n, int64_t out_stride_l,
                       uint64_t *slice_masks, int64_t n, void *stream);

@@ -57,5 +57,5 @@ f_us, b_us = timeit(fwd, args.iters), timeit(bwd, args.iters)
 f0_us = timeit(lambda: ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=False), args.iters)
 fb = 4 * D + (2 ** D) * L * F * 4 + L * F * 4
 bb = 4 * D + L * F * 4 + 2 * (2 ** D) * L * F * 4
-print(json.dumps({"lib": args.lib or "base", "grid": args.grid, "dist": "uniform" if args.uniform else "training", "fwd_us": round(f_us, 1), "fwd_nomask_us": round(f0_us, 1), "bwd_us": round(b_us, 1),
+print(json.dumps({"lib": args.lib or "base", "grid": args.grid, "dist": "uniform" if args.uniform else "training", "fwd_us": round(f_us, 1), "fwd_nomask_us": round(f0_us, 1), "bwd_us": round(b_us, 1), "grad_abs_sum": float(grad.double().abs().sum()),
                   "pair_frac_of_8TBps": round((fb + bb) * N / ((f_us + b_us) * 1e-6) / 8e12, 4)}))
