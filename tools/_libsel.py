@@ -15,6 +15,7 @@ if "--lib" in sys.argv:
         _L0.LIB_PATH = os.path.join(os.path.dirname(_L0.LIB_PATH), f"libemernerf_{TAG}.so")
         import emernerf_amd._build as _B
         _B.build = lambda *a, **k: _L0.LIB_PATH
-        _L0.ALLOW_MISSING_SYMBOLS = True   # an older build: entry points added since are absent ...
-        import emernerf_amd.fused as _F
-        _F.FUSED_WGRAD = False             # ... so the paths that need them are switched off
+        if os.environ.get("EMER_LIBSEL_SAME_ABI") != "1":   # (a variant of the CURRENT sources keeps every entry point)
+            _L0.ALLOW_MISSING_SYMBOLS = True   # an older build: entry points added since are absent ...
+            import emernerf_amd.fused as _F
+            _F.FUSED_WGRAD = False             # ... so the paths that need them are switched off
