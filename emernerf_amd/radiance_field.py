@@ -162,8 +162,6 @@ class RadianceField(nn.Module):
         super().__init__()
         if density_activation is not None:
             raise NotImplementedError("only the reference's default density activation trunc_exp(x - 1) is fused")
-        if enable_temporal_interpolation:
-            raise NotImplementedError("enable_temporal_interpolation is eval-only and off in every shipped config")
         if not isinstance(aabb, Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
         self.register_buffer("aabb", aabb)
@@ -361,10 +359,37 @@ class RadianceField(nn.Module):
         return (feats, enc) if return_hash_encodings else feats
 
     def forward_flow_hash(self, normed_positions: Tensor, normed_timestamps: Tensor) -> Tensor:
-        """:359-389."""
+        """:359-389.  Evaluation with ``enable_temporal_interpolation``: the flow field BETWEEN two training timesteps is the flow
+        MLP of the linearly interpolated xyzt encodings at the two nearest training timesteps (``temporal_interpolation``, :844-905,
+        called with interpolate_xyz_encoding=True).  (The dynamic branch never interpolates: the reference's ``if True:``, :336-337.)"""
         if normed_timestamps.shape[-1] != 1:
             normed_timestamps = normed_timestamps.unsqueeze(-1)
-        temporal_positions = torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1)
+        if self.enable_temporal_interpolation and not self.training:
+            return self._flow_hash_interpolated(normed_positions, normed_timestamps)
+        return self._flow_from_xyzt(torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1))
+
+    def _flow_hash_interpolated(self, normed_positions: Tensor, normed_timestamps: Tensor) -> Tensor:
+        """temporal_interpolation (:844-905) for the flow encoder.  One timestamp per ray (the slice [:, 0(, 0)] the reference reads);
+        when EVERY ray sits on a training timestep the plain evaluation is used (its ``torch.allclose`` test: one host read, eval only)."""
+        slice_t = normed_timestamps[:, 0] if normed_timestamps.dim() == 2 else normed_timestamps[:, 0, 0]
+        train_t = self.training_timesteps.to(slice_t)
+        # find_topk_nearby_timesteps (nerf_utils.py:31-57): the two training timesteps closest to each query
+        idx = torch.topk((train_t[None, :] - slice_t[:, None]).abs(), k=2, dim=1, largest=False).indices
+        closest = train_t[idx]
+        if torch.allclose(closest[:, 0], slice_t):
+            return self._flow_from_xyzt(torch.cat([normed_positions, normed_timestamps.to(normed_positions.dtype)], dim=-1))
+        assert normed_positions.dim() == 3, "temporal interpolation expects (rays, samples, 3) positions, as the reference does"
+        S = normed_positions.shape[1]
+        left, right = closest[:, 0], closest[:, 1]
+        offset = ((slice_t - left) / (right - left))[:, None, None]
+        enc = self.flow_xyz_encoder
+        xl = torch.cat([normed_positions, left[:, None, None].expand(-1, S, 1)], dim=-1)
+        xr = torch.cat([normed_positions, right[:, None, None].expand(-1, S, 1)], dim=-1)
+        el = enc(xl.reshape(-1, self.num_dims + 1)).view(*xl.shape[:-1], -1)
+        er = enc(xr.reshape(-1, self.num_dims + 1)).view(*xr.shape[:-1], -1)
+        return _run_sequential(self.flow_mlp, el * (1 - offset) + er * offset)
+
+    def _flow_from_xyzt(self, temporal_positions: Tensor) -> Tensor:
         enc_t = self.flow_xyz_encoder.tcnn_encoding
         lins = [m for m in self.flow_mlp if isinstance(m, nn.Linear)]
         if (temporal_positions.is_cuda and len(lins) == 3 and all(l.bias is not None for l in lins)
@@ -630,8 +655,10 @@ class RadianceField(nn.Module):
             normed_timestamps = data_dict["normed_timestamps"] if "normed_timestamps" in data_dict \
                 else data_dict["lidar_normed_timestamps"]
             use_flow = self.flow_xyz_encoder is not None
+            # (eval-mode temporal interpolation of the flow field takes the call-by-call path: forward_flow_hash)
+            interp = self.enable_temporal_interpolation and not self.training
             batched = self._flow_branch_batched(positions, normed_positions, normed_timestamps, hash_encodings) \
-                if (use_flow and BATCH_XYZT) else None
+                if (use_flow and BATCH_XYZT and not interp) else None
             if batched is not None:
                 dynamic_feats = batched["dynamic_feats"]
                 results_dict.update(batched)

@@ -26,8 +26,9 @@ sys.path.insert(0, ROOT)
 AABB = [-20.0, -40.0, 0.0, 80.0, 40.0, 20.0]  # configs/default_config.yaml:42
 
 
-def model_cfg(kind: str):
-    """Nested config equivalent to configs/default_config.yaml:40-105 with small grids."""
+def model_cfg(kind: str, tinterp: bool = False):
+    """Nested config equivalent to configs/default_config.yaml:40-105 with small grids.  ``tinterp``: enable_temporal_interpolation
+    (eval-only: the flow field between two training timesteps, radiance_field.py:359-389,844-905)."""
     from oracle.ref_shims import ns
     dyn = kind in ("dynamic", "flow", "feature")
     return ns(
@@ -40,7 +41,7 @@ def model_cfg(kind: str):
                   appearance_embedding_dim=16, enable_sky_head=True, enable_feature_head=kind == "feature",
                   feature_embedding_dim=16, feature_mlp_layer_width=32, enable_learnable_pe=True,
                   enable_dynamic_branch=dyn, enable_shadow_head=dyn, interpolate_xyz_encoding=True,
-                  enable_temporal_interpolation=False, enable_flow_branch=kind in ("flow", "feature")),
+                  enable_temporal_interpolation=tinterp, enable_flow_branch=kind in ("flow", "feature")),
         unbounded=True, num_cams=3 if kind == "feature" else 1, num_train_timesteps=10,
     )
 
@@ -153,8 +154,9 @@ def _flat(prefix, d, out):
             out[prefix + k] = v.detach().cpu().numpy()
 
 
-def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int, image_shape=None, lidar=False):
-    """mode: 'train' (stratified, prop nets trained, backward) or 'eval' (decomposition, chunked)."""
+def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int, image_shape=None, lidar=False, tinterp=False):
+    """mode: 'train' (stratified, prop nets trained, backward) or 'eval' (decomposition, chunked).  ``tinterp``: the model is built
+    with enable_temporal_interpolation and the rays carry timestamps BETWEEN the training timesteps."""
     from oracle import ref_shims
     ref_shims.install()
     import radiance_fields as ref_rf  # the reference's own package
@@ -162,7 +164,7 @@ def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int,
     from third_party import nerfacc_prop_net as ref_prop
 
     torch.manual_seed(seed)
-    cfg = model_cfg(kind)
+    cfg = model_cfg(kind, tinterp)
     model = ref_rf.build_radiance_field_from_cfg(cfg, verbose=False)
     model.set_aabb(AABB)
     model.register_normalized_training_timesteps(torch.linspace(0, 1, cfg.num_train_timesteps), time_diff=1 / cfg.num_train_timesteps)
@@ -174,6 +176,10 @@ def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int,
     rcfg = render_cfg(list(prop_samples), num_samples)
 
     data = make_rays(R, seed + 2, cfg.num_train_timesteps, cfg.num_cams, image_shape)
+    if tinterp:   # off-grid timestamps (a novel-time render), a few rays exactly on a training timestep
+        g = torch.Generator().manual_seed(seed + 4)
+        ts = torch.rand(data["normed_timestamps"].shape, generator=g) * 0.96 + 0.02
+        data["normed_timestamps"] = ts
     prefix = ""
     if lidar:
         prefix = "lidar_"
@@ -251,6 +257,12 @@ CASES = {
     "feature_eval_image": dict(kind="feature", mode="eval", R=60, prop_samples=(24, 16), num_samples=16, seed=500, image_shape=(6, 10)),
     "feature_train": dict(kind="feature", mode="train", R=20, prop_samples=(16, 8), num_samples=12, seed=600),
     "static_eval_chunked": dict(kind="static", mode="eval", R=240, prop_samples=(32, 16), num_samples=24, seed=700),
+}
+
+
+# eval-only temporal interpolation of the flow field (its own test: the oracle restatement does not carry this option)
+TINTERP_CASES = {
+    "flow_eval_tinterp": dict(kind="flow", mode="eval", R=48, prop_samples=(24, 16), num_samples=16, seed=1300, tinterp=True),
 }
 
 
@@ -436,7 +448,7 @@ def main():
         path = os.path.join(HERE, "pixel_source.npz")
         np.savez_compressed(path, **out)
         print(f"pixel_source: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB")
-    for name, kw in CASES.items():
+    for name, kw in {**CASES, **TINTERP_CASES}.items():
         if only and name not in only:
             continue
         out = run_case(**kw)

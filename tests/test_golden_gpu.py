@@ -27,8 +27,8 @@ def _load(name):
 def _build(case, gold, dev):
     from emernerf_amd.prop_net import PropNetEstimator
     from emernerf_amd.radiance_field import build_density_field, build_radiance_field_from_cfg
-    kw = G.CASES[case]
-    cfg = G.model_cfg(kw["kind"])
+    kw = {**G.CASES, **G.TINTERP_CASES}[case]
+    cfg = G.model_cfg(kw["kind"], kw.get("tinterp", False))
     torch.manual_seed(0)
     model = build_radiance_field_from_cfg(cfg, verbose=False)
     props = [build_density_field(aabb=G.AABB, unbounded=True, **k) for k in G.PROP_KW]
@@ -71,12 +71,14 @@ def _check_digest(name, got, gold, rtol=2e-3):
         np.testing.assert_allclose(float(flat.norm()), float(gold[name + "@norm"]), rtol=rtol, err_msg=name + "@norm")
 
 
-@pytest.mark.parametrize("case", list(G.CASES))
+@pytest.mark.parametrize("case", list(G.CASES) + list(G.TINTERP_CASES))
 def test_render_rays_matches_reference(hip_lib, case):
+    """(flow_eval_tinterp: evaluation with enable_temporal_interpolation on rays whose timestamps lie between the training timesteps --
+    the reference's temporal_interpolation of the flow field, radiance_field.py:359-389,844-905, recorded and compared like every other case)"""
     from emernerf_amd.render_utils import render_rays
     dev = torch.device("cuda:0")
     gold = _load(case)
-    kw = G.CASES[case]
+    kw = {**G.CASES, **G.TINTERP_CASES}[case]
     cfg, model, props, est = _build(case, gold, dev)
     train = kw["mode"] == "train"
     model.train(train); est.train(train)
