@@ -50,6 +50,8 @@ SIGNATURES = {
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
     "emer_contract_bwd": [_P, _P, c_int, _P, _P, c_int64, _P],
+    "emer_flow_warp_fwd": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, _P, c_int64, _P],
+    "emer_flow_warp_bwd": [_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P],
     "emer_ray_points": [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int64, c_int32, _P],
     "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P],
     "emer_stot": [_P, c_int64, c_float, c_float, c_int, _P, _P],

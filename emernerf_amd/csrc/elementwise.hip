@@ -56,44 +56,99 @@ __global__ __launch_bounds__(256) void contract_fwd_kernel(const float *__restri
     }
 }
 
+// gradient of contract_point w.r.t. the un-contracted position: g = d(loss)/d(contracted) in, d(loss)/d(p) out
+__device__ __forceinline__ void contract_point_bwd(const Aabb &bb, bool unbounded, const float (&p)[3], float (&g)[3]) {
+    float v[3];
+    const bool inside = contract_point(bb, unbounded, p, v);
+    if (!inside) { g[0] = 0.0f; g[1] = 0.0f; g[2] = 0.0f; return; }
+    if (unbounded) {
+        float u[3], mag = 0.0f;
+        int k = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            u[d] = (p[d] - bb.lo[d]) / (bb.hi[d] - bb.lo[d]) * 2.0f - 1.0f;
+            if (fabsf(u[d]) > mag) { mag = fabsf(u[d]); k = d; }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[d] = g[d] / 4.0f;  // y = c/4 + 0.5
+        if (!(mag < 1.0f)) {
+            // c_d = f(mag) u_d, f = 2/mag - 1/mag^2, mag = |u_k|
+            const float inv = 1.0f / mag;
+            const float f = 2.0f * inv - inv * inv;
+            const float df = -2.0f * inv * inv + 2.0f * inv * inv * inv;
+            const float dotug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+            const float sgn = u[k] >= 0.0f ? 1.0f : -1.0f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) g[d] = f * g[d] + (d == k ? sgn * df * dotug : 0.0f);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[d] = g[d] * 2.0f;  // u = 2v - 1
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g[d] = g[d] / (bb.hi[d] - bb.lo[d]);
+}
+
 __global__ __launch_bounds__(256) void contract_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ aabb,
                                                            int unbounded, const float *__restrict__ dout,
                                                            float *__restrict__ dpos, int64_t n) {
     const Aabb bb = load_aabb(aabb);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]}, v[3];
-        const bool inside = contract_point(bb, unbounded != 0, p, v);
-        float g[3] = {0.0f, 0.0f, 0.0f};
-        if (inside) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) g[d] = dout[i * 3 + d];
-            if (unbounded) {
-                float u[3], mag = 0.0f;
-                int k = 0;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    u[d] = (p[d] - bb.lo[d]) / (bb.hi[d] - bb.lo[d]) * 2.0f - 1.0f;
-                    if (fabsf(u[d]) > mag) { mag = fabsf(u[d]); k = d; }
-                }
-#pragma unroll
-                for (int d = 0; d < 3; ++d) g[d] = g[d] / 4.0f;  // y = c/4 + 0.5
-                if (!(mag < 1.0f)) {
-                    // c_d = f(mag) u_d, f = 2/mag - 1/mag^2, mag = |u_k|
-                    const float inv = 1.0f / mag;
-                    const float f = 2.0f * inv - inv * inv;
-                    const float df = -2.0f * inv * inv + 2.0f * inv * inv * inv;
-                    const float dotug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
-                    const float sgn = u[k] >= 0.0f ? 1.0f : -1.0f;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) g[d] = f * g[d] + (d == k ? sgn * df * dotug : 0.0f);
-                }
-#pragma unroll
-                for (int d = 0; d < 3; ++d) g[d] = g[d] * 2.0f;  // u = 2v - 1
-            }
-#pragma unroll
-            for (int d = 0; d < 3; ++d) g[d] = g[d] / (bb.hi[d] - bb.lo[d]);
-        }
+        float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]};
+        float g[3] = {dout[i * 3], dout[i * 3 + 1], dout[i * 3 + 2]};
+        contract_point_bwd(bb, unbounded != 0, p, g);
         dpos[i * 3] = g[0]; dpos[i * 3 + 1] = g[1]; dpos[i * 3 + 2] = g[2];
+    }
+}
+
+// ---- flow warp of the temporal aggregation (radiance_field.py:567-580): the xyzt query points of the batched flow branch -----------
+// x3 [3 n][4] = [ normed | t ],  [ contract(pos + fwd_flow * noise) | clamp(t + dt * noise, 0, 1) ],  [ contract(pos + bwd_flow * noise) |
+// clamp(t - dt * noise, 0, 1) ] and x2 [2 n][4] = the last two thirds again (the flow table's query is its own autograd output, so that
+// the two consumers' input gradients arrive as two tensors instead of being padded, copied and added).  Replaces rand-free part of the
+// torch chain: 2 mul + 2 add + 2 contractions + 2 scalar mul + add + sub + 2 clamp + 4 cat = 14 launches and their ~18 autograd twins.
+__global__ __launch_bounds__(256) void flow_warp_fwd_kernel(const float *__restrict__ pos, const float *__restrict__ normed, const float *__restrict__ ts,
+                                                            const float *__restrict__ flow, const float *__restrict__ noise, float dt,
+                                                            const float *__restrict__ aabb, int unbounded, float4 *__restrict__ x3,
+                                                            float4 *__restrict__ x2, int64_t n) {
+    const Aabb bb = load_aabb(aabb);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float t = ts[i], nz = noise[i];
+        x3[i] = make_float4(normed[i * 3], normed[i * 3 + 1], normed[i * 3 + 2], t);
+        const float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float q[3], v[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = p[d] + flow[i * 6 + 3 * h + d] * nz;   // positions + flow * noise (mul, then add: no FMA in this file)
+            contract_point(bb, unbounded != 0, q, v);
+            const float step = dt * nz;
+            const float tw = fminf(fmaxf(h == 0 ? t + step : t - step, 0.0f), 1.0f);   // torch.clamp(t +- time_diff * noise, 0, 1.0)
+            const float4 o = make_float4(v[0], v[1], v[2], tw);
+            x3[(int64_t)(h + 1) * n + i] = o;
+            x2[(int64_t)h * n + i] = o;
+        }
+    }
+}
+
+// dflow [n][6] from the input gradients of the two consumers: dx3 [3 n][4] (rows < n unused; may be null) and dx2 [2 n][4] (may be null);
+// positions, timestamps and the noise carry no gradient
+__global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ flow, const float *__restrict__ noise,
+                                                            const float *__restrict__ aabb, int unbounded, const float4 *__restrict__ dx3,
+                                                            const float4 *__restrict__ dx2, float *__restrict__ dflow, int64_t n) {
+    const Aabb bb = load_aabb(aabb);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float nz = noise[i];
+        const float p[3] = {pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float q[3], g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = p[d] + flow[i * 6 + 3 * h + d] * nz;
+            if (dx3) { const float4 a = dx3[(int64_t)(h + 1) * n + i]; g[0] = a.x; g[1] = a.y; g[2] = a.z; }
+            if (dx2) { const float4 a = dx2[(int64_t)h * n + i]; g[0] = g[0] + a.x; g[1] = g[1] + a.y; g[2] = g[2] + a.z; }
+            contract_point_bwd(bb, unbounded != 0, q, g);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dflow[i * 6 + 3 * h + d] = g[d] * nz;
+        }
     }
 }
 
@@ -267,6 +322,26 @@ extern "C" int emer_contract_bwd(const float *pos, const float *aabb, int unboun
     hipLaunchKernelGGL(contract_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), pos, aabb, unbounded, dout,
                        dpos, n);
     return check_launch("contract_bwd");
+}
+
+extern "C" int emer_flow_warp_fwd(const float *positions, const float *normed, const float *timestamps, const float *flow, const float *noise,
+                                  float time_diff, const float *aabb, int unbounded, float *x3, float *x2, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0, "flow_warp_fwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(positions && normed && timestamps && flow && noise && aabb && x3 && x2, "flow_warp_fwd: null pointer");
+    hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), positions, normed, timestamps, flow, noise,
+                       time_diff, aabb, unbounded, reinterpret_cast<float4 *>(x3), reinterpret_cast<float4 *>(x2), n);
+    return check_launch("flow_warp_fwd");
+}
+
+extern "C" int emer_flow_warp_bwd(const float *positions, const float *flow, const float *noise, const float *aabb, int unbounded,
+                                  const float *dx3, const float *dx2, float *dflow, int64_t n, void *stream) {
+    EMER_REQUIRE(n >= 0, "flow_warp_bwd: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(positions && flow && noise && aabb && dflow, "flow_warp_bwd: null pointer");
+    hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), positions, flow, noise, aabb, unbounded,
+                       reinterpret_cast<const float4 *>(dx3), reinterpret_cast<const float4 *>(dx2), dflow, n);
+    return check_launch("flow_warp_bwd");
 }
 
 extern "C" int emer_ray_points(const float *origins, const float *dirs, const float *ts, const float *te,

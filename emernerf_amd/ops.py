@@ -366,6 +366,47 @@ def contract_points(pos: Tensor, aabb: Tensor, unbounded: bool) -> Tensor:
     return _ContractFn.apply(pos, aabb, unbounded)
 
 
+class _FlowWarpFn(torch.autograd.Function):
+    """(x3 [3N, 4], x2 [2N, 4]) = xyzt query points of the batched flow branch (radiance_field.py:567-580), see emer_flow_warp_fwd;
+    gradient only w.r.t. ``flow`` [N, 6] (positions, timestamps and noise are inputs of the step)."""
+
+    @staticmethod
+    def forward(ctx, positions: Tensor, normed: Tensor, ts: Tensor, flow: Tensor, noise: Tensor, time_diff: float, aabb: Tensor, unbounded: bool):
+        pos, nrm, t, fl, nz, ab = _f32c(positions).view(-1, 3), _f32c(normed).view(-1, 3), _f32c(ts).view(-1), _f32c(flow).view(-1, 6), \
+            _f32c(noise).view(-1), _f32c(aabb).view(-1)
+        N = pos.shape[0]
+        assert nrm.shape[0] == N and t.numel() == N and fl.shape[0] == N and nz.numel() == N
+        with torch.cuda.device(pos.device):
+            x3 = torch.empty((3 * N, 4), device=pos.device, dtype=torch.float32)
+            x2 = torch.empty((2 * N, 4), device=pos.device, dtype=torch.float32)
+            _lib.call("emer_flow_warp_fwd", _ptr(pos), _ptr(nrm), _ptr(t), _ptr(fl), _ptr(nz), float(time_diff), _ptr(ab), int(unbounded), _ptr(x3),
+                      _ptr(x2), N, _stream(pos))
+        ctx.save_for_backward(pos, fl, nz, ab)
+        ctx.unbounded, ctx.flow_shape = bool(unbounded), flow.shape
+        return x3, x2
+
+    @staticmethod
+    def backward(ctx, dx3: Optional[Tensor], dx2: Optional[Tensor]):
+        pos, fl, nz, ab = ctx.saved_tensors
+        if not ctx.needs_input_grad[3] or (dx3 is None and dx2 is None):
+            return (None,) * 8
+        N = pos.shape[0]
+        d3 = None if dx3 is None else _f32c(dx3)
+        d2 = None if dx2 is None else _f32c(dx2)
+        with torch.cuda.device(pos.device):
+            dflow = torch.empty((N, 6), device=pos.device, dtype=torch.float32)
+            _lib.call("emer_flow_warp_bwd", _ptr(pos), _ptr(fl), _ptr(nz), _ptr(ab), int(ctx.unbounded), _ptr(d3), _ptr(d2), _ptr(dflow), N, _stream(pos))
+        return None, None, None, dflow.view(ctx.flow_shape), None, None, None, None
+
+
+def flow_warp(positions: Tensor, normed: Tensor, timestamps: Tensor, flow: Tensor, noise: Tensor, time_diff: float, aabb: Tensor,
+              unbounded: bool) -> Tuple[Tensor, Tensor]:
+    """Query points of the flow branch's three xyzt evaluations in one launch: x3 = [current | forward-warped | backward-warped] (the
+    dynamic table's batch) and x2 = its last two thirds (the flow table's batch)."""
+    _check_cuda(positions, normed, timestamps, flow, noise, aabb)
+    return _FlowWarpFn.apply(positions, normed, timestamps, flow, noise, time_diff, aabb, unbounded)
+
+
 def ray_points(origins: Tensor, dirs: Tensor, t_starts: Tensor, t_ends: Tensor, aabb: Tensor, unbounded: bool,
                times: Optional[Tensor] = None, want_positions: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     """Sample positions along rays, contracted (no grad: sample positions never carry grad,

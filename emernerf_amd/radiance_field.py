@@ -125,6 +125,7 @@ class MLP(nn.Module):
         return x
 
 
+FUSE_FLOW_WARP = True  # ... and build its warped xyzt query points (and their gradient) in one launch each way (ops.flow_warp) [r4]
 BATCH_XYZT = True  # flow configs: evaluate each xyzt table once per dependency level (RadianceField._flow_branch_batched)
 FUSE_FIELD = os.environ.get("EMER_FUSE_FIELD", "1") != "0"   # neck + rgb head of the static model as one forward launch (fused.RgbRider); 0: two launches
 
@@ -463,15 +464,24 @@ class RadianceField(nn.Module):
         forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
         # (2) warped positions and times (:567-580)
         noise = self._noise(forward_flow)
-        fwd_pos = self.contract_points(positions + forward_flow * noise)
-        bwd_pos = self.contract_points(positions + backward_flow * noise)
-        fwd_t = torch.clamp(ts + self.time_diff * noise, 0, 1.0)
-        bwd_t = torch.clamp(ts - self.time_diff * noise, 0, 1.0)
-        x_fwd = torch.cat([fwd_pos, fwd_t.to(fwd_pos.dtype)], dim=-1).reshape(-1, D4)
-        x_bwd = torch.cat([bwd_pos, bwd_t.to(bwd_pos.dtype)], dim=-1).reshape(-1, D4)
+        fused_warp = (FUSE_FLOW_WARP and self.num_dims == 3 and not isinstance(self.time_diff, Tensor) and not positions.requires_grad
+                      and not x_cur.requires_grad and not noise.requires_grad and flow.is_contiguous())
+        if fused_warp:
+            # [r4] one launch for both warps, both clamps and the batch assembly (and one for their gradient w.r.t. the flow), instead
+            # of 14 elementwise / cat launches and ~18 autograd twins; the flow table's 2N-row batch is a second output, so the two
+            # tables' input gradients arrive as two tensors (no pad / copy / add)
+            x3, x2 = ops.flow_warp(positions, normed_positions, ts, flow, noise, float(self.time_diff), self.aabb, self.unbounded)
+        else:
+            fwd_pos = self.contract_points(positions + forward_flow * noise)
+            bwd_pos = self.contract_points(positions + backward_flow * noise)
+            fwd_t = torch.clamp(ts + self.time_diff * noise, 0, 1.0)
+            bwd_t = torch.clamp(ts - self.time_diff * noise, 0, 1.0)
+            x_fwd = torch.cat([fwd_pos, fwd_t.to(fwd_pos.dtype)], dim=-1).reshape(-1, D4)
+            x_bwd = torch.cat([bwd_pos, bwd_t.to(bwd_pos.dtype)], dim=-1).reshape(-1, D4)
+            x3, x2 = torch.cat([x_cur, x_fwd, x_bwd], dim=0), torch.cat([x_fwd, x_bwd], dim=0)
         # (3) dynamic table: one evaluation of 3N samples, one neck
         # the current positions carry no gradient in a training step (inputs of the model); a caller that asks for one gets it
-        enc3 = enc_d.forward_level_major(torch.cat([x_cur, x_fwd, x_bwd], dim=0), skip_dx_rows=0 if x_cur.requires_grad else N)
+        enc3 = enc_d.forward_level_major(x3, skip_dx_rows=0 if x_cur.requires_grad else N)
         geo3, sem3, _ = fused.neck(enc3, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
         # temporal aggregation (:595-613) per feature half, straight from the 3N-row batch: one launch each way, no [., 128]
         # concatenation and no 3N-row cat in the backward
@@ -485,7 +495,7 @@ class RadianceField(nn.Module):
             cur_f, fwd_f, bwd_f = (t.view(*lead, -1) for t in feats3.split(N, dim=0))
             dyn = (cur_f + 0.5 * fwd_f + 0.5 * bwd_f) / 2.0
         # (4) flow table at both warped sets: one evaluation of 2N samples
-        flow2 = fused.seq_mlp_lm(enc_f.forward_level_major(torch.cat([x_fwd, x_bwd], dim=0)), fw, fb)
+        flow2 = fused.seq_mlp_lm(enc_f.forward_level_major(x2), fw, fb)
         fwd_pred, bwd_pred = (t.view(*lead, 6) for t in flow2.split(N, dim=0))
         out = {"forward_flow": forward_flow, "backward_flow": backward_flow,
                "dynamic_feats": dyn,

@@ -139,6 +139,17 @@ int emer_contract_fwd(const float *pos, const float *aabb, int unbounded, float 
 /* dpos = J^T dout (zero for rejected rows). */
 int emer_contract_bwd(const float *pos, const float *aabb, int unbounded, const float *dout,
                       float *dpos, int64_t n, void *stream);
+/* Flow warp of the temporal aggregation (radiance_fields/radiance_field.py:567-580): the xyzt query points of the flow branch in one
+ * launch.  x3 [3n][4] = [normed | t], [contract(positions + flow[:, 0:3] * noise) | clamp(t + time_diff * noise, 0, 1)],
+ * [contract(positions + flow[:, 3:6] * noise) | clamp(t - time_diff * noise, 0, 1)]; x2 [2n][4] = rows n .. 3n of x3 again (the flow
+ * table's query as its own tensor).  positions / normed [n][3], timestamps / noise [n], flow [n][6], aabb [6]. */
+int emer_flow_warp_fwd(const float *positions, const float *normed, const float *timestamps, const float *flow,
+                       const float *noise, float time_diff, const float *aabb, int unbounded, float *x3, float *x2,
+                       int64_t n, void *stream);
+/* dflow [n][6] from the input gradients of the two consumers, dx3 [3n][4] (rows < n ignored) and dx2 [2n][4] (either may be NULL);
+ * positions, timestamps and noise carry no gradient. */
+int emer_flow_warp_bwd(const float *positions, const float *flow, const float *noise, const float *aabb, int unbounded,
+                       const float *dx3, const float *dx2, float *dflow, int64_t n, void *stream);
 /* positions[r,s,:] = origins[r] + dirs[r] * (t_starts[r,s] + t_ends[r,s]) / 2, then contract.
  * Writes normed [R*S, out_dim] (out_dim 3, or 4 with times[r] appended as the 4th column);
  * positions_out (optional, may be NULL) receives the un-contracted world positions [R*S,3]. */
