@@ -1549,7 +1549,10 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
     float w2a[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
-    float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);   // a2 | a1 of the next tile (same LDS footprint as the paired kernel)
+    // per-wave staging, filled global -> LDS (lane-major: lane (m, g) of piece p holds columns 16 p + 4 g .. + 3 of row m): the next tile's
+    // a2 (1024 floats, single buffer: consumed at the start of a tile) and, DOUBLE buffered, its a1 | geo (2 x 2048 floats: they are
+    // consumed at the END of a tile -- as the relu mask of d0 and, read back TRANSPOSED, as the B operands of the dW products)
+    float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
     // dW1 [64][128] and dW0 [64][64] as 32 x 32 blocks: lane (j, h), register r = dW[32 P + 8 (r >> 2) + 4 h + (r & 3)][32 Q + j]
@@ -1570,21 +1573,45 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
     const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
     const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
     const unsigned lo3c = (unsigned)(3 * m + (g < 3 ? g : 2));
-    f32x4 gn[4];
     float yn = 0.0f, dn = 0.0f;
-    auto issue = [&](int64_t ray, int j) {
+    auto issue = [&](int64_t ray, int j, int buf) {
         const int64_t row0 = (ray * tpr + j) * 16;
         const float *p2 = a.a2 + row0 * 64, *p1 = a.a1 + row0 * 64, *pg = a.geo + row0 * a.ld_geo;
+        float *sb = stg + 1024 + 2048 * buf;
 #pragma unroll
         for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p2 + (lo64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p1 + (lo64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p1 + (lo64 + 16u * p)), (lptr)(sb + 256 * p), 16, 0, 0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) gn[p] = *reinterpret_cast<const f32x4 *>(pg + (log + 16u * p));
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(pg + (log + 16u * p)), (lptr)(sb + 1024 + 256 * p), 16, 0, 0);
         yn = (a.out + row0 * 3)[lo3c];
         dn = (a.dout + row0 * 3)[lo3c];
     };
-    if (wave_id < a.n_rays) issue(wave_id, 0);
+    // B operand of a dW product straight from the staged tile: lane (j, gg) of a transposer output holds rows 4 gg .. 4 gg + 3 of feature
+    // 16 p + j -- which sits at float 256 p + 4 (row + 16 (j >> 2)) + (j & 3) of the lane-major tile.  Four strided LDS reads and two
+    // exact splits per 16-feature tile replace (per tensor) one operand split of the chain layout, four transposer passes through the
+    // matrix pipe and their 48 accumulator read-backs: the matrix core only has to transpose what it produced itself (dpre1, dpre0).
+    auto b_tile = [&](const float *tile, int p) -> SwT {
+        const float *q = tile + 256 * p + 64 * (m >> 2) + (m & 3) + 16 * g;   // row 4 g (+ i below: 4 floats further per row)
+        const float v0 = q[0], v1 = q[4], v2 = q[8], v3 = q[12];
+        SwT t;
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v0, v1, h0, m0, l0);
+        split3(v2, v3, h1, m1, l1);
+        t.h = u32x2{h0, h1}; t.m = u32x2{m0, m1}; t.l = u32x2{l0, l1};
+        return t;
+    };
+    int buf = 0;
+    auto advance = [&](int64_t ray, int j, int by, int64_t &nr, int &nj) {   // tile `by` positions further in this wave's sequence (clamped at its end)
+        nr = ray; nj = j;
+        for (int i = 0; i < by; ++i) {
+            int64_t r2 = nr; int j2 = nj + 1;
+            if (j2 == tpr) { j2 = 0; r2 = nr + n_waves; }
+            if (r2 >= a.n_rays) break;
+            nr = r2; nj = j2;
+        }
+    };
+    if (wave_id < a.n_rays) issue(wave_id, 0, 0);
     // dgeo of a tile is STORED AT THE START OF THE NEXT TILE, right behind that tile's wait for its inputs: on this part stores count in
     // vmcnt like loads, so a store issued mid-tile is still in flight at the next `s_waitcnt vmcnt(0)` and the wave sits out its write
     // acknowledgement (measured: 90 of 420 us); issued behind the wait it has a whole tile to drain.  The values stay where the matrix
@@ -1602,21 +1629,18 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
 #pragma unroll
                 for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
             }
-            f32x4 m2[4], m1[4], x[4];
+            f32x4 m2[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                m2[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
-                m1[p] = *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane);
-                x[p] = gn[p];
-            }
+            for (int p = 0; p < 4; ++p) m2[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
             const float d2 = g < 3 ? dn * yn * (1.0f - yn) : 0.0f;
+            const float *sb = stg + 1024 + 2048 * buf;   // this tile's a1 | geo
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             {
-                int64_t nr = ray; int nj = j + 1;
-                if (nj == tpr) { nj = 0; nr = ray + n_waves; }
-                if (nr >= a.n_rays) { nr = ray; nj = j; }
-                issue(nr, nj);
+                int64_t nr; int nj;
+                advance(ray, j, 1, nr, nj);
+                issue(nr, nj, buf ^ 1);
             }
+            buf ^= 1;
             // Order of the tile body.  One wave per SIMD: whatever overlaps, overlaps inside this instruction stream.  The three GEMMs of the
             // chain run as twelve stages of twelve matrix instructions (two output tiles x one k-step x six partial products); every stage
             // first issues the NEXT stage's weight-fragment reads (the last one of a tile: the next tile's first), then its matrix
@@ -1651,7 +1675,12 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
             EMER_RGBW_SB();
             // ---- GEMM 2: dgeo += W1g^T d1 (stages 4-7) next to the mask and split of d0
             ld_frag6(fb, w1gp, 0, 1); mma_frag6<2>(fa, d1o, 0, dg[0], dg[1]);
-            relu_mask<4>(d0, m1);
+            {
+                f32x4 m1[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) m1[p] = *reinterpret_cast<const f32x4 *>(sb + 256 * p + 4 * lane);
+                relu_mask<4>(d0, m1);
+            }
             EMER_RGBW_SB();
             ld_frag6(fa, w1gp, 1, 0); mma_frag6<2>(fb, d1o, 0, dg[2], dg[3]);
             {   // k-step 0 of the split operand = tiles 0, 1; k-step 1 = tiles 2, 3
@@ -1670,23 +1699,20 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
             }
             EMER_RGBW_SB();
             ld_frag6(fa, w0p, 0, 0); mma_frag6<2>(fb, d1o, 1, dg[2], dg[3]);
-            Opd<2> bo;
-            make_opd<4>(m1, bo);
             EMER_RGBW_SB();
             // ---- GEMM 3: dgeo += W0g^T d0 (stages 8-11) next to the B operands of the dW products
             ld_frag6(fb, w0p, 0, 1); mma_frag6<2>(fa, d0o, 0, dg[0], dg[1]);
-            Bq[0] = block32(to_rows<2>(bo, 0, sel), to_rows<2>(bo, 1, sel));
+            Bq[0] = block32(b_tile(sb, 0), b_tile(sb, 1));
             EMER_RGBW_SB();
             ld_frag6(fa, w0p, 1, 0); mma_frag6<2>(fb, d0o, 0, dg[2], dg[3]);
-            Bq[1] = block32(to_rows<2>(bo, 2, sel), to_rows<2>(bo, 3, sel));
+            Bq[1] = block32(b_tile(sb, 2), b_tile(sb, 3));
             EMER_RGBW_SB();
             ld_frag6(fb, w0p, 1, 1); mma_frag6<2>(fa, d0o, 1, dg[0], dg[1]);
-            make_opd<4>(x, bo);
+            Bq[2] = block32(b_tile(sb + 1024, 0), b_tile(sb + 1024, 1));
             EMER_RGBW_SB();
             ld_frag6(fa, w1ap, 0, 0); mma_frag6<2>(fb, d0o, 1, dg[2], dg[3]);   // (fa: the next tile's first stage)
-            Bq[2] = block32(to_rows<2>(bo, 0, sel), to_rows<2>(bo, 1, sel));
+            Bq[3] = block32(b_tile(sb + 1024, 2), b_tile(sb + 1024, 3));
             EMER_RGBW_SB();
-            Bq[3] = block32(to_rows<2>(bo, 2, sel), to_rows<2>(bo, 3, sel));
 #pragma unroll
             for (int p = 0; p < 4; ++p) dgp[p] = dg[p];
             dgeo_prev = dgeo;
