@@ -252,8 +252,16 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
+    # EMER_DP_FORCE=1 with one rank: the trainer takes its data-parallel path and the real RCCL collectives execute (each a copy
+    # onto itself): what the exchange code costs in launches and stream hand-offs, on the only box this container reaches
+    dp = world > 1 or os.environ.get("EMER_DP_FORCE") == "1"
     rccl_log = None
-    if world > 1:
+    if dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL's own account of the communicator (ranks, rings / trees, transport) goes to a per-rank file, not to stdout
         # (the JSON line must stay alone there); rank 0 quotes the relevant lines in the result
         rccl_log = f"/tmp/emer_rccl_rank{rank}_{os.getpid()}.log"
@@ -274,7 +282,7 @@ def main():
     # Launch mode.  One step is 86 kernel launches in 3.0 ms: the host has to enqueue one every 35 us, and boxes of this pool
     # differ (the same library: 3.02 ms on most, 3.58 ms on one with a slow host).  At N = 1 the forward + backward are
     # therefore replayed as a captured hipGraph (tested equal to eager launches); the exchange and Adam stay eager.
-    args.graph = (args.graph or world == 1) and not args.eager
+    args.graph = (args.graph or not dp) and not args.eager
 
     trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
                       use_graph=args.graph, table_dtype=args.table_dtype)
@@ -320,7 +328,7 @@ def main():
     timer = _lib.KernelTimer(grid_names) if (rank == 0 and not args.graph) else None
     _lib.TIMER = timer
 
-    if world > 1:
+    if dp:
         dist.barrier()
         if rank == 0:
             trainer.comm_events = []   # HIP events around the exposed part of every step's gradient exchange
@@ -334,7 +342,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
     exposed_comm = None
-    if world > 1 and rank == 0 and trainer.comm_events:
+    if dp and rank == 0 and trainer.comm_events:
         ev = [a.elapsed_time(b) for a, b in trainer.comm_events]
         exposed_comm = {"exposed_comm_ms": sum(ev) / len(ev), "max_ms": max(ev), "steps": len(ev), "dp_mode": trainer.dp_mode,
                         "note": "device time between the end of the backward and the optimizer step: the late (table) bucket plus the waits "
@@ -570,9 +578,10 @@ def main():
         }
         # Matrix-pipe rooflines of the head kernels (static configuration only: hidden 64, geo 64).  `achieved` = algorithmic
         # (fp32-equivalent) flops of one launch / its average duration in the instrumented pass; the kernels execute SIX
-        # bf16 partial products per fp32 product (exact 3-term splits, csrc/mlp_fused.hip), so the bf16 pipe does 6x that
-        # (`executed`; the fused backward additionally transposes through the matrix core and fills only half the K of its
-        # weight-gradient instructions: x 2 on those) and `frac` = executed / 2.5 PFLOP/s dense bf16.
+        # bf16 partial products per fp32 product (exact 3-term splits, csrc/mlp_fused.hip), so the bf16 pipe does 6x that, plus -- in the
+        # fused backward kernels -- the transposer passes that put rows on the reduction index (3 instructions of 16 x 16 x 32 per
+        # 16 x 16 operand tile = 3072 flops per row and tile).  [r4] their weight gradients run on v_mfma_f32_32x32x16_bf16 (full K);
+        # `executed` = all of that, `frac` = executed / 2.5 PFLOP/s dense bf16.
         mfma = {}
         if args.kind == "static":
             k0 = L * F
@@ -585,9 +594,8 @@ def main():
                      "emer_rgb_head_fwd": (2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),
                      "emer_field_fwd": (2.0 * N * (k0 * 64 + 64 * 64) + 2.0 * N * (64 * 64 + 128 * 64 + 64 * 3), 6.0),  # neck + rgb head in one launch
                      "emer_rgb_head_bwd": (2.0 * N * (3 * 64 + 3 * 64 * 64), 6.0),
-                     # [r4] data gradients + the weight gradients of the per-sample column blocks (dW1 [64][128], dW0 [64][64]); executed: six
-                     # partial products, the transposer (3 instructions per 16 x 16 operand tile, 16 tiles) and K = 16 weight-gradient steps
-                     # (the instruction issues at the K = 32 rate: x 2), or K = 32 steps with EMER_RGBW_PAIR=1
+                     # [r4] data gradients + the weight gradients of the per-sample column blocks (dW1 [64][128], dW0 [64][64]); the transposer
+                     # handles dpre1 / dpre0 only (8 tiles per 16 rows: a1 / geo are read transposed from LDS)
                      "emer_rgb_head_bwd_fused": (2.0 * N * (3 * 64 + 3 * 64 * 64) + 2.0 * N * (64 * 128 + 64 * 64), None)}
             for kn, (fl, mult) in flops.items():
                 v = [u for u in breakdown.elapsed_us().get(kn, [])]
@@ -595,11 +603,13 @@ def main():
                     v = sorted(v)[-max(1, breakdown_steps):]
                 if v:
                     t = sum(v) / len(v)
+                    t_row = 3.0 * 2.0 * 16 * 32        # transposer flops per row and 16 x 16 operand tile
                     if kn == "emer_rgb_head_bwd_fused":
-                        pair = os.environ.get("EMER_RGBW_PAIR", "0") == "1"
-                        ex = 6.0 * 2.0 * N * (3 * 64 * 64) + (6.0 if pair else 12.0) * 2.0 * N * (64 * 128 + 64 * 64) + 3.0 * 2.0 * N * 32 * (4 * 64)
+                        ex = 6.0 * fl + t_row * 8 * N
+                    elif kn == "emer_neck_bwd_fused":    # tiles: h1 (4), d (4), dpre0 (4), the encoding ((k0 + 15) // 16)
+                        ex = 6.0 * fl + t_row * (12 + (k0 + 15) // 16) * N
                     else:
-                        ex = fl * mult if mult is not None else 6.0 * dgrad_neck + 12.0 * wgrad_neck + 3.0 * 2.0 * N * 16 * (3 * 64 + k0)
+                        ex = fl * mult
                     mfma[kn] = {"avg_us": t, "achieved": fl / (t * 1e-6) / 1e12, "executed": ex / (t * 1e-6) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": ex / (t * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                                 "vs_fp32_matrix_peak": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
@@ -648,14 +658,14 @@ def main():
             "kernels_note": f"per-kernel breakdown from a separate fully instrumented pass of {breakdown_steps} steps after the "
                             "timed region; the roofline kernels are timed with HIP events inside the timed region itself",
         }
-        if world > 1:
+        if dp:
             out["rccl"] = rccl_summary(os.environ.get("NCCL_DEBUG_FILE", rccl_log), world)
             out["rccl"].update({"env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "EMER_DP_MODE", "NCCL_MIN_NCHANNELS") if k in os.environ}})
             out["gradient_exchange"] = exposed_comm
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

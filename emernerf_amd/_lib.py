@@ -43,6 +43,7 @@ SIGNATURES = {
     "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_hashgrid_bwd_params": [_GP, _P, _P, c_int64, c_int64, _P, c_int, c_int64, _P],
     "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
+    "emer_hashgrid_bwd_params_sliced_levels": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_int32, _P],
     "emer_hashgrid_slice_masks": [_GP, _P, _P, c_int64, _P],
     "emer_hashgrid_sliced_supported": [_GP],
     "emer_hashgrid_mask_rows": [_P],
@@ -175,7 +176,7 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer to enable
 
 
-_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced")  # entries that record events around their kernel themselves
+_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
 
 
 def call(name: str, *args) -> None:

@@ -1611,17 +1611,54 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
 // Owner-computes variant: OVERWRITES grad (f32) -- every entry of every level is written exactly
 // once, so the caller does not zero the buffer.  The slice bitmaps come from emer_hashgrid_fwd (or
 // emer_hashgrid_slice_masks) for the SAME x.
+static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
+                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream);
+
 extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
                                                int64_t sl, uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
+    return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, 0u, g->n_levels, stream);
+}
+
+// The same for the levels [level_begin, level_end) only: the entries of the other levels are neither read nor written.  Two calls
+// that partition the levels give the one-call result; a data-parallel trainer launches the collective of the first call's levels
+// (a contiguous range of the table) while the second call computes (emernerf_amd/trainer.py).
+extern "C" int emer_hashgrid_bwd_params_sliced_levels(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
+                                                      uint64_t *slice_masks, float *grad, int64_t n, int32_t level_begin, int32_t level_end,
+                                                      void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(level_begin >= 0 && level_begin <= level_end && level_end <= (int32_t)g->n_levels, "hashgrid_bwd_params_sliced_levels: bad level range [%d, %d)",
+                 level_begin, level_end);
+    if (level_begin == level_end) return EMER_OK;
+    return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, (uint32_t)level_begin, (uint32_t)level_end, stream);
+}
+
+static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
+                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream) {
     EMER_REQUIRE(n >= 0 && n < (1ll << 28), "hashgrid_bwd_params_sliced: n out of range (byte offsets of the gathers are 32-bit: n < 2^28)");
     EMER_REQUIRE(sn == (int64_t)g->n_features, "hashgrid_bwd_params_sliced: dout must be level-major with packed features (stride_n == n_features)");
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
     const uint32_t F = g->n_features;
-    const SlicePlan plan = make_slice_plan(g);
+    SlicePlan plan = make_slice_plan(g);
     EMER_REQUIRE(plan.ok, "hashgrid_bwd_params_sliced: a level needs more than 256 x 64 LDS slices; use emer_hashgrid_bwd_params");
+    if (level_begin != 0u || level_end != g->n_levels) {
+        // a level outside the range contributes no work item (the bitmap layout -- mask_q, gsub, shift -- stays the whole grid's: the
+        // forward wrote the bitmaps for all levels); the item lists are dealt again over what is left
+        uint32_t left_items = 0;
+        for (uint32_t l = 0; l < g->n_levels; ++l) {
+            if (l < level_begin || l >= level_end) plan.n_slices[l] = 0;
+            left_items += plan.n_slices[l] * plan.n_ranges[l];
+        }
+        plan.total_items = left_items;
+        for (int i = 0; i < 8; ++i) plan.items_per_xcd[i] = 0;
+        for (uint32_t blk = 0; blk * kSchedBlock < left_items; ++blk) {
+            const uint32_t left = left_items - blk * kSchedBlock;
+            plan.items_per_xcd[blk & 7u] += left < kSchedBlock ? left : kSchedBlock;
+        }
+    }
     uint32_t total_items = 0;
     for (int i = 0; i < 8; ++i) total_items += plan.items_per_xcd[i];
+    if (total_items == 0u) return EMER_OK;
     // Zero, in ONE launch, the levels that are merged with atomics and the work cursors (the 16 scratch words behind
     // the bitmaps).  A kernel rather than hipMemsetAsync nodes: one launch instead of up to six, and hipGraph replays of
     // memset nodes proved unreliable on ROCm 7.2 (gradients drifted after a few replays).
@@ -1633,7 +1670,7 @@ extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const fl
     const uint32_t n_trips = (uint32_t)ceil_div(ceil_div(n, 64), kSliceThreads), n_blk = (total_items + kSchedBlock - 1u) / kSchedBlock;
     const uint32_t pace_trips = (EMER_PACE && n_trips <= 64u && n_blk <= 64u && n_trips > (uint32_t)EMER_PACE_LEAD) ? n_trips : 0u;
     zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = pace_trips ? 16u + 64u * 64u : 8u; ++zr.count;
-    for (uint32_t l = 0; l < g->n_levels; ++l) {
+    for (uint32_t l = level_begin; l < level_end; ++l) {
         if (plan.n_ranges[l] > 1u) {
             zr.p[zr.count] = grad + (size_t)g->offset[l] * F; zr.n[zr.count] = g->size[l] * F; ++zr.count;
         }

@@ -301,8 +301,19 @@ class _HashGridLMFn(torch.autograd.Function):
                     param = ctx.param
                     direct = param is not None and getattr(param, "_emer_grad_fresh", False) and param.grad is not None
                     grad = param.grad.view(-1) if direct else torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
-                    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
-                              _ptr(grad), N, st)
+                    split = getattr(ctx.param_obj, "_emer_table_split", None) if direct else None
+                    if split is not None and 0 < split[0] < L:
+                        # data-parallel trainer: the levels [k, L) first, then ITS hook (the collective of that contiguous range of the
+                        # table starts on the communication stream), then the levels [0, k) while it runs
+                        k, hook = split
+                        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
+                                  _ptr(grad), N, k, L, st)
+                        hook(param, int(desc.offset[k]) * F, pc.numel())
+                        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
+                                  _ptr(grad), N, 0, k, st)
+                    else:
+                        _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
+                                  _ptr(grad), N, st)
                     if direct:
                         param._emer_grad_fresh = False
                         grad = None

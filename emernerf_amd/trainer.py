@@ -293,9 +293,22 @@ class Trainer:
         # the exchange runs when there is more than one rank -- or when EMER_DP_FORCE=1 asks for it on a single rank (a 1-GPU box can
         # then execute the real RCCL collectives of both modes, trivially: tests/test_multi_gpu.py)
         self._dp_on = world_size > 1 or _os.environ.get("EMER_DP_FORCE") == "1"
+        self._table_work, self._table_ranges = [], []   # collectives of table level ranges launched from inside the table's backward
         if self._dp_on:
             assert dist.is_initialized(), "data-parallel exchange needs an initialised torch.distributed process group"
-            self.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = self._launch_early_bucket
+            tab = self.model.xyz_encoder.tcnn_encoding.params
+            tab._emer_before_table_grad = self._launch_early_bucket
+            # [r4] The exposed exchange of a step used to be the whole static table (48 MB at configs[1]) AFTER its backward, the
+            # longest kernel of the step, with nothing left to hide it behind.  The owner-computes backward now runs as two launches
+            # over a partition of the levels: the fine half of the table (levels k .. L - 1, a contiguous range of ~half the bytes
+            # and ~a third of the kernel time) first, whose all-reduce then overlaps the second launch.  EMER_DP_SPLIT_TABLE=0: off.
+            if self.dp_mode == "allreduce" and _os.environ.get("EMER_DP_SPLIT_TABLE", "1") != "0":
+                desc = self.model.xyz_encoder.tcnn_encoding.desc
+                Lv, Fv = desc.n_levels, desc.n_features
+                total = desc.n_entries
+                k = next((l for l in range(1, Lv) if (total - desc.offset[l]) <= 0.55 * total), 0)
+                if 0 < k < Lv:
+                    tab._emer_table_split = (k, self._launch_table_bucket)
         self.model.train(); self.estimator.train()
         for p in self.props:
             p.train()
@@ -411,6 +424,20 @@ class Trainer:
             self._early_work = [dist.all_reduce(self.flat.grads[a:b], async_op=True) for a, b in self._early_ranges]
             self._early_done = True
 
+    def _launch_table_bucket(self, param, lo: int, hi: int) -> None:
+        """Called by the static table's backward between its two launches (ops._HashGridLMFn.backward): elements [lo, hi) of the
+        table's gradient are final; their all-reduce starts now and overlaps the second launch.  Not inside a graph capture and not
+        during its warm-up (then the whole table goes with the late bucket)."""
+        if not self._dp_on or self.dp_mode == "rs_ag" or self._hold_buckets or torch.cuda.is_current_stream_capturing():
+            return
+        base = next(o for p, o in self.flat._table_offsets if p is param)
+        a, b = base + lo, base + hi
+        if self.dp_debug:   # record instead of reducing: _exchange_grads checks that nothing wrote the range afterwards
+            self._table_snapshot = ((a, b), self.flat.grads[a:b].clone())
+            return
+        self._table_work.append(dist.all_reduce(self.flat.grads[a:b], async_op=True))
+        self._table_ranges.append((a, b))
+
     def _launch_prop_bucket(self) -> None:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
         is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
@@ -430,6 +457,11 @@ class Trainer:
         self.flat.finish_grads("main")
         if prop_grad:
             self.flat.finish_grads("prop")
+        tsnap = getattr(self, "_table_snapshot", None)
+        if tsnap is not None:   # EMER_DP_DEBUG=1: the first launch's level range must be final when its collective would start
+            (lo, hi), old = tsnap
+            assert torch.equal(self.flat.grads[lo:hi], old), f"table gradient range [{lo}, {hi}) was written after its bucket would have been launched"
+            self._table_snapshot = None
         snap = getattr(self, "_early_snapshot", None)
         if snap is not None:  # EMER_DP_DEBUG=1: the early ranges must be final when the last table backward starts
             for (lo, hi), old in zip(self._early_ranges, snap):
@@ -456,11 +488,12 @@ class Trainer:
             a, b = self.flat.ranges["main"]
             if prop_grad and self._prop_work is None:
                 b = self.flat.ranges["prop"][1]  # main and the trained proposal net are adjacent in the flat buffer
-            if self._early_done:
-                late = _subtract_ranges((a, b), self._early_ranges)
+            done = (self._early_ranges if self._early_done else []) + self._table_ranges
+            if done:
+                late = _subtract_ranges((a, b), done)
                 for lo, hi in late:
                     dist.all_reduce(self.flat.grads[lo:hi])
-                for w in self._early_work:
+                for w in self._early_work + self._table_work:
                     w.wait()
             else:
                 dist.all_reduce(self.flat.grads[a:b])
@@ -470,6 +503,7 @@ class Trainer:
             ev1.record()
             self.comm_events.append((ev0, ev1))
         self._early_done, self._early_work, self._prop_work = False, [], None
+        self._table_work, self._table_ranges = [], []
         if self._dp_on:
             self.model.xyz_encoder.tcnn_encoding.params._emer_pending_evals = 0
 

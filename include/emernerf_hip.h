@@ -107,6 +107,12 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
                                     const float *dout, int64_t dout_stride_n,
                                     int64_t dout_stride_l, uint64_t *slice_masks,
                                     float *grad, int64_t n, void *stream);
+/* The same for the levels [level_begin, level_end) only (a contiguous range of the table: entries offset[level_begin] ..): the other
+ * levels' entries are neither read nor written.  Calls that partition the levels give the one-call result; a data-parallel trainer
+ * starts the collective of the first call's range while the second call computes. */
+int emer_hashgrid_bwd_params_sliced_levels(const emer_grid_desc *host_desc, const float *x, const float *dout,
+                                           int64_t dout_stride_n, int64_t dout_stride_l, uint64_t *slice_masks,
+                                           float *grad, int64_t n, int32_t level_begin, int32_t level_end, void *stream);
 int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
                               uint64_t *slice_masks, int64_t n, void *stream);
 /* 1 when the owner-computes backward covers the grid: every level cuts into LDS slices (128 KiB of double accumulators

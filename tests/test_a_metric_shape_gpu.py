@@ -150,6 +150,42 @@ def test_hashgrid_sliced_is_run_to_run_stable(hip_lib, oracle):
     assert d <= 1e-6 * outs[0].abs().max().item()
 
 
+@pytest.mark.parametrize("name", ["cfg2_static", "flow_xyzt", "prop1"])
+def test_hashgrid_sliced_level_ranges_partition_the_launch(hip_lib, oracle, name):
+    """emer_hashgrid_bwd_params_sliced_levels over [k, L) and then [0, k) writes, into a buffer poisoned with NaN, the same table
+    gradient as the single launch (every entry of a range written by its launch and by no other; the data-parallel trainer
+    starts the collective of the first range between the two), for every split point, and the empty range is a no-op."""
+    from emernerf_amd import _lib, ops
+    meta, desc = _mk(oracle, name)
+    D, L, F = meta.n_dims, meta.n_levels, meta.n_features
+    dev = _dev()
+    N = 1 << 17
+    x = _positions("training", D, 0)[:N].contiguous().to(dev)
+    g = torch.Generator().manual_seed(6)
+    p = (torch.rand(meta.n_params, generator=g) - 0.5).to(dev)
+    dlm = torch.randn(L, N, F, generator=g).to(dev)
+    _, mk = ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=True)
+    st = ops._stream(x)
+    one = torch.empty(meta.n_params, device=dev)
+    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F, ops._ptr(mk), ops._ptr(one), N, st)
+    for k in sorted({1, L // 2, L - 1}):
+        two = torch.full((meta.n_params,), float("nan"), device=dev)
+        cut = int(meta.offset[k]) * F
+        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F, ops._ptr(mk),
+                  ops._ptr(two), N, k, L, st)
+        torch.cuda.synchronize()
+        assert torch.isnan(two[:cut]).all(), f"{name}: launch over levels [{k}, {L}) wrote below the level-{k} offset"
+        assert not torch.isnan(two[cut:]).any()
+        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F, ops._ptr(mk),
+                  ops._ptr(two), N, k, k, st)   # empty range
+        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F, ops._ptr(mk),
+                  ops._ptr(two), N, 0, k, st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(two).any()
+        d = (one - two).abs().max().item()
+        assert d <= 1e-6 * one.abs().max().item(), f"{name}: split at level {k}: {d:.3e}"
+
+
 # ------------------------------------------------------------------------------------------ fused heads
 @pytest.mark.parametrize("rgbw", ["tile", "paired", "streamed"])
 def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):

@@ -67,10 +67,27 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
         calls["early"] += 1
         orig_early()
     tr._launch_prop_bucket = spy_prop
-    tr.model.xyz_encoder.tcnn_encoding.params._emer_before_table_grad = spy_early
+    tab = tr.model.xyz_encoder.tcnn_encoding.params
+    tab._emer_before_table_grad = spy_early
+    split = getattr(tab, "_emer_table_split", None)
+    calls["table"] = 0
+    if dp_mode == "allreduce":
+        assert split is not None, "all-reduce mode: the static table's backward must be split by level range"
+        k, orig_table = split
+
+        def spy_table(param, lo, hi):
+            calls["table"] += 1
+            assert param is tab and 0 < lo < hi == tab.numel()
+            orig_table(param, lo, hi)
+            if not debug:
+                assert len(tr._table_work) == 1, "the first level range's all-reduce must be in flight before the second launch"
+        tab._emer_table_split = (k, spy_table)
+    else:
+        assert split is None
     out = _step(tr, data, jit, noise, mode)
     assert out["prop_grad"], "the test step must exercise the proposal-net range of the exchange"
     assert calls["prop"] == 1 and calls["early"] == 1, f"buckets not launched exactly once: {calls}"
+    assert calls["table"] == (1 if dp_mode == "allreduce" else 0), f"table level-range bucket: {calls}"
     torch.cuda.synchronize()
     torch.save({"params": tr.flat.params.cpu(), "ranges": dict(tr.flat.ranges)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
