@@ -313,7 +313,7 @@ def main():
     # HIP events inside the timed region only around the roofline kernels (the grid encode + its backward: five
     # launches per step).  Timing every entry point costs ~1.4 ms/step in event records, so the full per-kernel
     # breakdown comes from a second, separately instrumented pass after the timed region.
-    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params"]
+    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels", "emer_hashgrid_bwd_params"]
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
@@ -517,6 +517,10 @@ def main():
 
         fwd_b, bwd_b = grid_alg_bytes(D, L, F)
         f_us, b_us = main_grid("emer_hashgrid_fwd"), main_grid("emer_hashgrid_bwd_params_sliced")
+        # data-parallel eager steps run the table's backward as two level-range launches (the first range's all-reduce starts
+        # between them): one backward = the sum of a pair
+        lv = main_grid("emer_hashgrid_bwd_params_sliced_levels")
+        b_us = b_us + [lv[i] + lv[i + 1] for i in range(0, len(lv) - 1, 2)]
         f_avg = sum(f_us) / max(len(f_us), 1)
         b_avg = sum(b_us) / max(len(b_us), 1)
         per_kernel = {n: {"launches_per_step": len(v) / breakdown_steps, "ms_per_step": sum(v) / 1e3 / breakdown_steps,
@@ -664,7 +668,9 @@ def main():
             out["gradient_exchange"] = exposed_comm
         if cpu_res is not None:
             out["cpu_baseline"] = cpu_res
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out now, so that the JSON line is the last line
+        print(json.dumps(out), flush=True)
     if dp:
         dist.destroy_process_group()
 

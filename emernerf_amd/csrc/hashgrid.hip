@@ -1633,6 +1633,28 @@ extern "C" int emer_hashgrid_bwd_params_sliced_levels(const emer_grid_desc *g, c
     return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, (uint32_t)level_begin, (uint32_t)level_end, stream);
 }
 
+// Where to cut for emer_hashgrid_bwd_params_sliced_levels: the first level k of the fine range [k, L) that a caller launches
+// first.  The persistent owners take work items in rounds (one item per CU at a time, three rounds for the cfg-2 table), so a
+// cut costs nothing only where it falls between rounds: [k, L) is the largest set of finest levels whose items fill at most ONE
+// round of the resident owners (cfg 2: levels 12..15, 4 x 64 slices = 256 items; measured 157 + 411 us against 536 us for the
+// single launch, while a cut by bytes -- k = 10 -- costs 676 us: profiles/r04_table_split.txt).  0: no useful cut (the whole
+// grid is one round, or the finest level alone is more than one).
+extern "C" int emer_hashgrid_sliced_split_level(const emer_grid_desc *g) {
+    if (check_desc(g) != EMER_OK) return 0;
+    const SlicePlan plan = make_slice_plan(g);
+    if (!plan.ok) return 0;
+    const uint32_t owners = EMER_SLICE_THREADS == 1024 ? 256 : 512;
+    if (plan.total_items <= owners) return 0;
+    uint32_t items = 0, k = g->n_levels;
+    while (k > 1u) {
+        const uint32_t add = plan.n_slices[k - 1u] * plan.n_ranges[k - 1u];
+        if (items + add > owners) break;
+        items += add;
+        --k;
+    }
+    return k < g->n_levels ? (int)k : 0;
+}
+
 static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
                                             uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream) {
     EMER_REQUIRE(n >= 0 && n < (1ll << 28), "hashgrid_bwd_params_sliced: n out of range (byte offsets of the gathers are 32-bit: n < 2^28)");

@@ -60,6 +60,12 @@ def sliced_supported(desc: GridDesc) -> bool:
     return bool(_lib.load().emer_hashgrid_sliced_supported(ctypes.byref(desc)))
 
 
+def sliced_split_level(desc) -> int:
+    """Level k at which the owner-computes table backward is cut into the launches [k, L) and [0, k) without lengthening it by a
+    round of work items (0: do not cut).  See emer_hashgrid_sliced_split_level (csrc/hashgrid.hip)."""
+    return int(_lib.load().emer_hashgrid_sliced_split_level(ctypes.byref(desc)))
+
+
 def mask_words(desc: GridDesc, n: int) -> int:
     """64-bit words of the slice bitmaps for n samples: n_levels x rows x ceil(n / 64) + the backward's work cursors
     (rows = 64, or 256 for tables with more than 64 LDS slices per level: emer_hashgrid_mask_rows)."""

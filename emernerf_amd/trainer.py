@@ -300,14 +300,14 @@ class Trainer:
             tab._emer_before_table_grad = self._launch_early_bucket
             # [r4] The exposed exchange of a step used to be the whole static table (48 MB at configs[1]) AFTER its backward, the
             # longest kernel of the step, with nothing left to hide it behind.  The owner-computes backward now runs as two launches
-            # over a partition of the levels: the fine half of the table (levels k .. L - 1, a contiguous range of ~half the bytes
-            # and ~a third of the kernel time) first, whose all-reduce then overlaps the second launch.  EMER_DP_SPLIT_TABLE=0: off.
+            # over a partition of the levels: the finest levels that fill one round of the resident owners first (cfg 2: levels
+            # 12..15, a contiguous 34 % of the table, 157 us), whose all-reduce then overlaps the second launch (411 us; the pair
+            # costs +6 % over the single launch, a cut by bytes +26 %: profiles/r04_table_split.txt).  EMER_DP_SPLIT_TABLE=0: off;
+            # EMER_DP_SPLIT_LEVEL=k: cut there instead.
             if self.dp_mode == "allreduce" and _os.environ.get("EMER_DP_SPLIT_TABLE", "1") != "0":
                 desc = self.model.xyz_encoder.tcnn_encoding.desc
-                Lv, Fv = desc.n_levels, desc.n_features
-                total = desc.n_entries
-                k = next((l for l in range(1, Lv) if (total - desc.offset[l]) <= 0.55 * total), 0)
-                if 0 < k < Lv:
+                k = int(_os.environ.get("EMER_DP_SPLIT_LEVEL", "0")) or ops.sliced_split_level(desc)
+                if 0 < k < desc.n_levels and ops.sliced_supported(desc):
                     tab._emer_table_split = (k, self._launch_table_bucket)
         self.model.train(); self.estimator.train()
         for p in self.props:

@@ -113,6 +113,9 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
 int emer_hashgrid_bwd_params_sliced_levels(const emer_grid_desc *host_desc, const float *x, const float *dout,
                                            int64_t dout_stride_n, int64_t dout_stride_l, uint64_t *slice_masks,
                                            float *grad, int64_t n, int32_t level_begin, int32_t level_end, void *stream);
+/* The level k at which to cut for two such calls, [k, n_levels) first: the finest levels whose work items fill one round of the
+ * resident owner workgroups (a cut elsewhere lengthens the pair of launches by a round); 0 = do not cut.  Host arithmetic only. */
+int emer_hashgrid_sliced_split_level(const emer_grid_desc *host_desc);
 int emer_hashgrid_slice_masks(const emer_grid_desc *host_desc, const float *x,
                               uint64_t *slice_masks, int64_t n, void *stream);
 /* 1 when the owner-computes backward covers the grid: every level cuts into LDS slices (128 KiB of double accumulators

@@ -199,6 +199,10 @@ def test_slice_plan_host_logic(hip_lib, grid, rows):
     desc = _lib.make_grid_desc(D, L, F, T, base, growth)
     assert hip_lib.emer_hashgrid_sliced_supported(ctypes.byref(desc)) == 1
     assert hip_lib.emer_hashgrid_mask_rows(ctypes.byref(desc)) == rows
+    # the level at which a data-parallel trainer cuts the table backward into two launches: the finest levels that fill one round
+    # of 256 resident owners (cfg 2: 4 hashed levels x 64 slices), never level 0 and never "everything"
+    k = hip_lib.emer_hashgrid_sliced_split_level(ctypes.byref(desc))
+    assert 0 < k < L and k == {(3, 16, 16, 2048, 19, 2): 12}.get(grid, k)
     assert hip_lib.emer_rmlp_supported(3, 40, 4, 64, 6) == 1 and hip_lib.emer_rmlp_supported(2, 64, 0, 64, 1) == 1
     assert hip_lib.emer_rmlp_supported(3, 64, 0, 64, 64) == 1 and hip_lib.emer_rmlp_supported(2, 43, 0, 32, 5) == 0
     assert hip_lib.emer_neck_supported(16, 2, 64, 64) == 1 and hip_lib.emer_neck_supported(10, 4, 64, 128) == 1

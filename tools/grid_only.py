@@ -17,6 +17,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--grid", default="3,16,16,2048,19,2")
 ap.add_argument("--table-init", type=float, default=None)
 ap.add_argument("--lib", default=None)
+ap.add_argument("--split-sweep", action="store_true", help="time the backward as two level-range launches [k, L) + [0, k) for every k")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 D, L, base, mx, T, F = (int(v) for v in args.grid.split(","))
@@ -54,6 +55,15 @@ def timeit(fn, iters):
     ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
     return ts[len(ts) // 2]
 f_us, b_us = timeit(fwd, args.iters), timeit(bwd, args.iters)
+if args.split_sweep:
+    def part(a, b):
+        _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), ops._ptr(x), ops._ptr(dlm), F, N * F, ops._ptr(mk), ops._ptr(grad), N, a, b, ops._stream(x))
+    rows = []
+    for k in range(1, L):
+        hi_us, lo_us = timeit(lambda: part(k, L), args.iters), timeit(lambda: part(0, k), args.iters)
+        rows.append({"k": k, "first_us": round(hi_us, 1), "second_us": round(lo_us, 1), "sum_us": round(hi_us + lo_us, 1),
+                     "first_bytes_frac": round(1.0 - float(desc.offset[k]) / desc.n_entries, 3)})
+    print(json.dumps({"single_us": round(b_us, 1), "split": rows}))
 f0_us = timeit(lambda: ops.hashgrid_fwd_raw(desc, x, p, level_major=True, want_masks=False), args.iters)
 fb = 4 * D + (2 ** D) * L * F * 4 + L * F * 4
 bb = 4 * D + L * F * 4 + 2 * (2 ** D) * L * F * 4
