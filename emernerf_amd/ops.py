@@ -231,21 +231,33 @@ class _HashGridFn(torch.autograd.Function):
 
 
 def _count_table_eval(param) -> None:
-    """Data-parallel trainers hang ``_emer_before_table_grad`` on the table whose backward runs LAST in a step.  If that
-    encoder is evaluated more than once per step (warped positions, chunked training), only the backward of its FIRST
-    forward evaluation is the last one to run; the evaluations are counted here so the callback fires exactly then."""
-    if getattr(param, "_emer_before_table_grad", None) is not None:
+    """Data-parallel trainers hang ``_emer_before_table_grad`` on the table whose backward runs LAST in a step and
+    ``_emer_after_table_grad`` on the other tables of the main model.  If an encoder is evaluated more than once per step (warped
+    positions, chunked training), only the backward of its FIRST forward evaluation is the last one to run; the evaluations are
+    counted here so the callbacks fire exactly then (the trainer resets the count at the start of a step)."""
+    if getattr(param, "_emer_before_table_grad", None) is not None or getattr(param, "_emer_after_table_grad", None) is not None:
         param._emer_pending_evals = getattr(param, "_emer_pending_evals", 0) + 1
 
 
-def _before_table_grad(param) -> None:
-    cb = getattr(param, "_emer_before_table_grad", None)
-    if cb is None:
-        return
+def _before_table_grad(param) -> bool:
+    """-> True when this is the last backward of ``param``'s encoder in the step (and a trainer asked to know)."""
+    cb, after = getattr(param, "_emer_before_table_grad", None), getattr(param, "_emer_after_table_grad", None)
+    if cb is None and after is None:
+        return False
     left = getattr(param, "_emer_pending_evals", 1) - 1
     param._emer_pending_evals = max(left, 0)
-    if left <= 0:  # the last backward of this table in the step: everything upstream has its gradient enqueued by now
+    if left <= 0 and cb is not None:  # the last backward of this table in the step: everything upstream has its gradient enqueued by now
         cb()
+    return left <= 0
+
+
+def _after_table_grad(param, last: bool, in_place: bool) -> None:
+    """The table's gradient of this step is complete IN the trainer's buffer (``in_place``: written or added there by this
+    backward, not handed to autograd's AccumulateGrad): a data-parallel trainer starts the table's collective now, behind the
+    backward kernels that follow."""
+    cb = getattr(param, "_emer_after_table_grad", None)
+    if cb is not None and last and in_place:
+        cb(param)
 
 
 class _HashGridLMFn(torch.autograd.Function):
@@ -295,7 +307,7 @@ class _HashGridLMFn(torch.autograd.Function):
         desc = ctx.desc
         N, L, F = xc.shape[0], desc.n_levels, desc.n_features
         dx = dp = None
-        _before_table_grad(ctx.param_obj)  # data-parallel trainer: early gradient bucket (fires on the table's last backward)
+        last = _before_table_grad(ctx.param_obj)  # data-parallel trainer: early gradient bucket (fires on the table's last backward)
         with torch.cuda.device(xc.device):
             dlm = _f32c(dlm)
             if CHECK_FINITE:
@@ -331,6 +343,7 @@ class _HashGridLMFn(torch.autograd.Function):
                     _lib.call("emer_hashgrid_bwd_params", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(grad),
                               _dtype_tag(grad), N, st)
                 dp = None if grad is None else _table_grad_via_autograd(ctx.param_obj, grad.to(ctx.master_dtype) if grad.dtype != ctx.master_dtype else grad)
+                _after_table_grad(ctx.param_obj, last, dp is None)
             if ctx.needs_input_grad[0]:
                 k, D = min(ctx.skip_dx_rows, N), desc.n_dims
                 dx = torch.empty_like(xc)

@@ -163,6 +163,7 @@ class FlatParams:
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)
         for p in self._tables:
             p._emer_grad_fresh = True
+            p._emer_pending_evals = 0   # (a forward without a backward -- an eval render between steps -- must not shift the count)
 
     def finish_grads(self, group: str) -> None:
         """Tables of ``group`` that no backward wrote this step get their zero gradient now."""
@@ -294,6 +295,7 @@ class Trainer:
         # then execute the real RCCL collectives of both modes, trivially: tests/test_multi_gpu.py)
         self._dp_on = world_size > 1 or _os.environ.get("EMER_DP_FORCE") == "1"
         self._table_work, self._table_ranges = [], []   # collectives of table level ranges launched from inside the table's backward
+        self._table_snapshots = []
         if self._dp_on:
             assert dist.is_initialized(), "data-parallel exchange needs an initialised torch.distributed process group"
             tab = self.model.xyz_encoder.tcnn_encoding.params
@@ -309,6 +311,14 @@ class Trainer:
                 k = int(_os.environ.get("EMER_DP_SPLIT_LEVEL", "0")) or ops.sliced_split_level(desc)
                 if 0 < k < desc.n_levels and ops.sliced_supported(desc):
                     tab._emer_table_split = (k, self._launch_table_bucket)
+            # the other tables of the main model (dynamic and flow xyzt grids): their backwards run BEFORE the static table's (their
+            # encoders come later in the forward), so each one's all-reduce starts when its last backward of the step has written
+            # it and runs behind the backward kernels that follow -- three serial collectives after the backward before [r4]
+            if self.dp_mode == "allreduce" and _os.environ.get("EMER_DP_SPLIT_TABLE", "1") != "0":
+                a, b = self.flat.ranges["main"]
+                for p, o in self.flat._table_offsets:
+                    if a <= o < b and p is not tab:
+                        p._emer_after_table_grad = self._launch_whole_table_bucket
         self.model.train(); self.estimator.train()
         for p in self.props:
             p.train()
@@ -433,10 +443,14 @@ class Trainer:
         base = next(o for p, o in self.flat._table_offsets if p is param)
         a, b = base + lo, base + hi
         if self.dp_debug:   # record instead of reducing: _exchange_grads checks that nothing wrote the range afterwards
-            self._table_snapshot = ((a, b), self.flat.grads[a:b].clone())
+            self._table_snapshots.append(((a, b), self.flat.grads[a:b].clone()))
             return
         self._table_work.append(dist.all_reduce(self.flat.grads[a:b], async_op=True))
         self._table_ranges.append((a, b))
+
+    def _launch_whole_table_bucket(self, param) -> None:
+        """Called by the last backward of a dynamic / flow table in a step, after it wrote the table's gradient (ops._after_table_grad)."""
+        self._launch_table_bucket(param, 0, param.numel())
 
     def _launch_prop_bucket(self) -> None:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
@@ -457,11 +471,9 @@ class Trainer:
         self.flat.finish_grads("main")
         if prop_grad:
             self.flat.finish_grads("prop")
-        tsnap = getattr(self, "_table_snapshot", None)
-        if tsnap is not None:   # EMER_DP_DEBUG=1: the first launch's level range must be final when its collective would start
-            (lo, hi), old = tsnap
+        for (lo, hi), old in self._table_snapshots:   # EMER_DP_DEBUG=1: a table range must be final when its collective would start
             assert torch.equal(self.flat.grads[lo:hi], old), f"table gradient range [{lo}, {hi}) was written after its bucket would have been launched"
-            self._table_snapshot = None
+        self._table_snapshots = []
         snap = getattr(self, "_early_snapshot", None)
         if snap is not None:  # EMER_DP_DEBUG=1: the early ranges must be final when the last table backward starts
             for (lo, hi), old in zip(self._early_ranges, snap):

@@ -78,13 +78,25 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
         def spy_table(param, lo, hi):
             calls["table"] += 1
             assert param is tab and 0 < lo < hi == tab.numel()
+            n_before = len(tr._table_work)
             orig_table(param, lo, hi)
             if not debug:
-                assert len(tr._table_work) == 1, "the first level range's all-reduce must be in flight before the second launch"
+                assert len(tr._table_work) == n_before + 1, "the first level range's all-reduce must be in flight before the second launch"
         tab._emer_table_split = (k, spy_table)
     else:
         assert split is None
+    calls["xyzt"] = 0
+    for p, _ in tr.flat._table_offsets:   # the dynamic / flow tables: their collectives start from their own last backward
+        orig_after = getattr(p, "_emer_after_table_grad", None)
+        if orig_after is not None:
+            def spy_after(param, _orig=orig_after):
+                calls["xyzt"] += 1
+                n_before = len(tr._table_work) + len(tr._table_snapshots)
+                _orig(param)
+                assert len(tr._table_work) + len(tr._table_snapshots) == n_before + 1
+            p._emer_after_table_grad = spy_after
     out = _step(tr, data, jit, noise, mode)
+    assert calls["xyzt"] == (2 if kind == "flow" and dp_mode == "allreduce" else 0), f"xyzt table buckets: {calls}"
     assert out["prop_grad"], "the test step must exercise the proposal-net range of the exchange"
     assert calls["prop"] == 1 and calls["early"] == 1, f"buckets not launched exactly once: {calls}"
     assert calls["table"] == (1 if dp_mode == "allreduce" else 0), f"table level-range bucket: {calls}"
@@ -94,7 +106,8 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
 
 
 @pytest.mark.parametrize("kind,mode,dp_mode,debug", [("static", "pixel", "allreduce", False), ("static", "pixel", "allreduce", True),
-                                                     ("flow", "pixel", "allreduce", True), ("static", "lidar", "allreduce", True),
+                                                     ("flow", "pixel", "allreduce", True), ("flow", "pixel", "allreduce", False),
+                                                     ("static", "lidar", "allreduce", True),
                                                      ("static", "pixel", "rs_ag", False), ("flow", "lidar", "rs_ag", False)])
 def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, mode, dp_mode, debug):
     """static and flow models, the pixel step and the lidar step, the bucketed all-reduce and the reduce-scatter -> sharded
