@@ -49,6 +49,8 @@ SIGNATURES = {
     "emer_hashgrid_sliced_supported": [_GP],
     "emer_hashgrid_mask_rows": [_P],
     "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
+    "emer_hashgrid_fwd_jac": [_GP, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, c_int64, _P],
+    "emer_hashgrid_bwd_input_jac": [_GP, _P, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
     "emer_contract_bwd": [_P, _P, c_int, _P, _P, c_int64, _P],
@@ -177,7 +179,7 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer to enable
 
 
-_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
+_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
 
 
 def call(name: str, *args) -> None:

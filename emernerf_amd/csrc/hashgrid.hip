@@ -382,11 +382,16 @@ __device__ __forceinline__ void set_row(uint64_t (&mask)[Q], uint32_t row) {
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int D, int F, typename PT, int Q>
+// JAC [r4]: rows n >= jac_row0 also store J[f][d] = d out[n][level][f] / d x[n][d] (jac[level][n - jac_row0][F][D]) -- the corner
+// values are in registers here anyway, and the input gradient of the flow configs becomes a streaming contraction of J with dOut
+// (hashgrid_bwd_input_jac_kernel) instead of a second pass of 2^D * L gathers per sample (hashgrid_bwd_input_kernel).  The encoding
+// itself is computed exactly as without JAC (same loop, same order).
+template <int D, int F, typename PT, int Q, bool JAC = false>
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc g, const float *__restrict__ x,
                                                            const PT *__restrict__ params, float *__restrict__ out,
                                                            int64_t sn, int64_t sl, int64_t N, uint32_t n_chunks, const LevelMap lmap,
-                                                           const SlicePlan plan, uint64_t *__restrict__ masks) {
+                                                           const SlicePlan plan, uint64_t *__restrict__ masks,
+                                                           float *__restrict__ jac = nullptr, int64_t jac_row0 = 0) {
     uint32_t level, chunk;
     if (!map_block(blockIdx.x, lmap, n_chunks, level, chunk)) return;
     const int64_t n = (int64_t)chunk * 256 + threadIdx.x;
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         for (int f = 0; f < F; ++f) acc[f] = 0.0f;
         const bool pow2 = (li.size & (li.size - 1u)) == 0u;
         bool paired = false;
-        if constexpr (sizeof(PT) * F <= 8) {
+        if constexpr (sizeof(PT) * F <= 8 && !JAC) {
         if (li.hashed && pow2) {  // level-uniform
             paired = true;
             // Hashed power-of-two level: the x-neighbours of a (y, z[, t]) combination are idx0 = (x ^ h) & mask and
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         }
         }
         if (!paired) {
+        float vv[JAC ? (1 << D) : 1][F];   // JAC: every corner's features stay live for the differences along each axis
 #pragma unroll
         for (uint32_t m = 0; m < (1u << D); ++m) {
             float wt = 1.0f;
@@ -472,7 +478,47 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             load_feats<F, PT>(table + (size_t)idx * F, v);
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] += wt * v[f];  // same order as the oracle (corner-major)
+            if constexpr (JAC) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) vv[m][f] = v[f];
+            }
             if (masks) set_row<Q>(mask, slice_of(plan, level, idx));  // by-product for the owner-computes backward
+        }
+        if constexpr (JAC) {
+            if (n >= jac_row0) {
+                // J[f][gd] = scale * sum over the corners m with bit gd clear of prod_{d != gd} t_d(m) * (v[m | gd] - v[m])[f]:
+                // the same differences, weights and corner order as hashgrid_bwd_input_kernel forms after projecting on dOut
+                float J[F][D];
+#pragma unroll
+                for (int gd = 0; gd < D; ++gd) {
+                    float a[F];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) a[f] = 0.0f;
+#pragma unroll
+                    for (uint32_t m = 0; m < (1u << D); ++m) {
+                        if (m & (1u << gd)) continue;
+                        float wt = li.scale;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            if (d == gd) continue;
+                            wt *= (m & (1u << d)) ? w[d] : 1.0f - w[d];
+                        }
+#pragma unroll
+                        for (int f = 0; f < F; ++f) a[f] += wt * (vv[m | (1u << gd)][f] - vv[m][f]);
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; ++f) J[f][gd] = a[f];
+                }
+                float *jp = jac + (((int64_t)level * (N - jac_row0)) + (n - jac_row0)) * (F * D);
+                if constexpr ((F * D) % 4 == 0) {
+#pragma unroll
+                    for (int i = 0; i < F * D; i += 4)
+                        *reinterpret_cast<float4 *>(jp + i) = make_float4(J[i / D][i % D], J[(i + 1) / D][(i + 1) % D], J[(i + 2) / D][(i + 2) % D], J[(i + 3) / D][(i + 3) % D]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < F * D; ++i) jp[i] = J[i / D][i % D];
+                }
+            }
         }
         }
         float *o = out + n * sn + (int64_t)level * sl;
@@ -1487,6 +1533,44 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_input_kernel(const emer_grid
     for (int d = 0; d < D; ++d) dx[n * D + d] = gx[d];
 }
 
+// The same gradient from the Jacobians the JAC forward stored: dx[row0 + j][d] = sum_l sum_f dOut[l][row0 + j][f] * J[l][j][f][d].
+// Streaming (F D + F floats per sample and level, coalesced), no table gathers; levels summed in the gather kernel's order.
+template <int D, int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_input_jac_kernel(const float *__restrict__ jac, const float *__restrict__ dout, int64_t sn,
+                                                                     int64_t sl, float *__restrict__ dx, int64_t n_rows, uint32_t n_levels) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_rows) return;
+    float gx[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) gx[d] = 0.0f;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        const float *jp = jac + ((int64_t)l * n_rows + j) * (F * D);
+        const float *gp = dout + j * sn + (int64_t)l * sl;
+        float J[F * D], go[F];
+        if constexpr ((F * D) % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < F * D; i += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(jp + i);
+                J[i] = t.x; J[i + 1] = t.y; J[i + 2] = t.z; J[i + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < F * D; ++i) J[i] = jp[i];
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) go[f] = gp[f];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float a = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) a += go[f] * J[f * D + d];
+            gx[d] += a;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dx[j * D + d] = gx[d];
+}
+
 // ------------------------------------------------------------------------------- dispatch
 template <typename Fn>
 static int dispatch_df(uint32_t D, uint32_t F, Fn &&fn) {
@@ -1529,19 +1613,63 @@ extern "C" int emer_hashgrid_fwd(const emer_grid_desc *g, const float *x, const 
         if (param_dtype == EMER_F32) {
             if (wide)
                 EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks, (float *)nullptr, (int64_t)0);
             else
                 EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                                     (const float *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks, (float *)nullptr, (int64_t)0);
         } else {
             if (wide)
                 EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, __half, 4>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks, (float *)nullptr, (int64_t)0);
             else
                 EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, __half, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x,
-                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks);
+                                     (const __half *)params, out, sn, sl, n, n_chunks, lmap, plan, slice_masks, (float *)nullptr, (int64_t)0);
         }
         return check_launch("hashgrid_fwd");
+    });
+}
+
+// emer_hashgrid_fwd (fp32 tables) that also stores, for the rows jac_row0 .. n - 1, the Jacobian of the encoding with respect to the
+// position: jac [n_levels][n - jac_row0][n_features][n_dims].  emer_hashgrid_bwd_input_jac contracts it with dOut.
+extern "C" int emer_hashgrid_fwd_jac(const emer_grid_desc *g, const float *x, const float *params, float *out, int64_t sn, int64_t sl,
+                                     uint64_t *slice_masks, float *jac, int64_t jac_row0, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n >= 0 && jac_row0 >= 0 && jac_row0 <= n, "hashgrid_fwd_jac: bad row range (n=%lld, jac_row0=%lld)", (long long)n, (long long)jac_row0);
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(x && params && out && (jac || jac_row0 == n), "hashgrid_fwd_jac: null pointer");
+    EMER_REQUIRE(((uintptr_t)jac % 16) == 0, "hashgrid_fwd_jac: jac must be 16-byte aligned");
+    const uint32_t n_chunks = (uint32_t)ceil_div(n, 256);
+    uint32_t blocks = 0;
+    const LevelMap lmap = make_level_map(g, n_chunks, &blocks);
+    const SlicePlan plan = make_slice_plan(g);
+    EMER_REQUIRE(!slice_masks || plan.ok, "hashgrid_fwd_jac: slice bitmaps requested but a level needs more than 256 x 64 LDS slices");
+    const ProfileEvents ev = take_profile_events();
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, F = decltype(f)::value;
+        if (slice_masks && plan.mask_q == 4)
+            EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 4, true>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x, params, out,
+                                 sn, sl, n, n_chunks, lmap, plan, slice_masks, jac, jac_row0);
+        else
+            EMER_LAUNCH_PROFILED(ev, (hashgrid_fwd_kernel<D, F, float, 1, true>), dim3(blocks), dim3(256), 0, as_stream(stream), *g, x, params, out,
+                                 sn, sl, n, n_chunks, lmap, plan, slice_masks, jac, jac_row0);
+        return check_launch("hashgrid_fwd_jac");
+    });
+}
+
+// dx [n_rows][n_dims] from jac [n_levels][n_rows][n_features][n_dims] and dout (row j of dout at dout + j * sn + level * sl: pass the
+// pointer of the first of the n_rows rows)
+extern "C" int emer_hashgrid_bwd_input_jac(const emer_grid_desc *g, const float *jac, const float *dout, int64_t sn, int64_t sl, float *dx,
+                                           int64_t n_rows, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n_rows >= 0, "hashgrid_bwd_input_jac: negative n_rows");
+    if (n_rows == 0) return EMER_OK;
+    EMER_REQUIRE(jac && dout && dx && ((uintptr_t)jac % 16) == 0, "hashgrid_bwd_input_jac: null or misaligned pointer");
+    const uint32_t blocks = (uint32_t)ceil_div(n_rows, 256);
+    return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
+        constexpr int D = decltype(d)::value, F = decltype(f)::value;
+        hipLaunchKernelGGL((hashgrid_bwd_input_jac_kernel<D, F>), dim3(blocks), dim3(256), 0, as_stream(stream), jac, dout, sn, sl, dx, n_rows,
+                           g->n_levels);
+        return check_launch("hashgrid_bwd_input_jac");
     });
 }
 

@@ -75,8 +75,10 @@ def mask_words(desc: GridDesc, n: int) -> int:
     return desc.n_levels * rows * ((n + 63) // 64) + MASK_SCRATCH
 
 
-def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True, want_masks: bool = False):
-    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32 (and the int64 slice bitmaps, ``mask_words(desc, N)`` long, if asked)."""
+def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: bool = True, want_masks: bool = False, jac_row0=None):
+    """Encode; returns [L, N, F] (level_major) or [N, L*F] fp32 (and the int64 slice bitmaps, ``mask_words(desc, N)`` long, if asked).
+    ``jac_row0`` (fp32 tables): also returns d out / d x of the rows jac_row0 .. N - 1 as [L, N - jac_row0, F, D] (last element of
+    the returned tuple) -- see emer_hashgrid_fwd_jac."""
     _check_cuda(x, params)
     N, L, F = x.shape[0], desc.n_levels, desc.n_features
     assert x.shape[1] == desc.n_dims and params.numel() == desc.n_entries * F
@@ -88,9 +90,20 @@ def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: boo
             out = torch.empty((N, L * F), device=x.device, dtype=torch.float32)
             sn, sl = L * F, F
         masks = torch.empty((mask_words(desc, N),), device=x.device, dtype=torch.int64) if want_masks else None
-        _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl,
-                  _ptr(masks), N, _stream(x))
-    return (out, masks) if want_masks else out
+        if jac_row0 is None:
+            _lib.call("emer_hashgrid_fwd", ctypes.byref(desc), _ptr(x), _ptr(params), _dtype_tag(params), _ptr(out), sn, sl,
+                      _ptr(masks), N, _stream(x))
+            return (out, masks) if want_masks else out
+        assert params.dtype == torch.float32 and 0 <= jac_row0 <= N
+        jac = torch.empty((L, N - jac_row0, F, desc.n_dims), device=x.device, dtype=torch.float32)
+        _lib.call("emer_hashgrid_fwd_jac", ctypes.byref(desc), _ptr(x), _ptr(params), _ptr(out), sn, sl, _ptr(masks), _ptr(jac),
+                  int(jac_row0), N, _stream(x))
+    return (out, masks, jac) if want_masks else (out, jac)
+
+
+# [r4] input gradient of a grid encoding (the flow configs: warped positions) from the Jacobians the forward stores instead of a second
+# gather pass over the table (emer_hashgrid_bwd_input): -0.4 ms per flow step at 2048 rays.  EMER_GRID_JAC=0: the gather pass.
+GRID_JAC = os.environ.get("EMER_GRID_JAC", "1") != "0"
 
 
 def slice_masks(desc: GridDesc, x: Tensor) -> Tensor:
@@ -286,10 +299,16 @@ class _HashGridLMFn(torch.autograd.Function):
             pc = ph  # what the kernels read; `params` stays the fp32 master (gradient sink)
         gdt = grad_dtype or torch.float32
         ctx.sliced = bool(ctx.needs_input_grad[1] and gdt == torch.float32 and sliced_supported(desc))
-        if ctx.sliced:
+        k = min(int(skip_dx_rows), xc.shape[0])
+        jac = None
+        if GRID_JAC and ctx.needs_input_grad[0] and pc.dtype == torch.float32 and k < xc.shape[0]:
+            res = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=ctx.sliced, jac_row0=k)
+            lm, masks, jac = res if ctx.sliced else (res[0], None, res[1])
+        elif ctx.sliced:
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=True)
         else:
             lm, masks = hashgrid_fwd_raw(desc, xc, pc, level_major=True), None
+        ctx.jac = jac   # (not through save_for_backward: never an input or output of the function, freed with the node)
         ctx.desc, ctx.grad_dtype = desc, grad_dtype
         ctx.skip_dx_rows = int(skip_dx_rows)
         ctx.master_dtype = params.dtype
@@ -349,7 +368,11 @@ class _HashGridLMFn(torch.autograd.Function):
                 dx = torch.empty_like(xc)
                 if k > 0:
                     dx[:k].zero_()  # rows without a consumer (torch.cat's backward slices them away)
-                if N > k:  # level-major dlm [L][N][F]: row k of every level is k*F floats in, the level stride stays N*F
+                if N > k and ctx.jac is not None:
+                    _lib.call("emer_hashgrid_bwd_input_jac", ctypes.byref(desc), _ptr(ctx.jac), dlm.data_ptr() + 4 * k * F, F, N * F,
+                              dx.data_ptr() + 4 * k * D, N - k, st)
+                    ctx.jac = None
+                elif N > k:  # level-major dlm [L][N][F]: row k of every level is k*F floats in, the level stride stays N*F
                     _lib.call("emer_hashgrid_bwd_input", ctypes.byref(desc), xc.data_ptr() + 4 * k * D, _ptr(pc), _dtype_tag(pc),
                               dlm.data_ptr() + 4 * k * F, F, N * F, dx.data_ptr() + 4 * k * D, N - k, st)
         return dx, dp, None, None, None, None

@@ -131,6 +131,15 @@ int emer_hashgrid_mask_rows(const emer_grid_desc *host_desc);
 int emer_hashgrid_bwd_input(const emer_grid_desc *host_desc, const float *x, const void *params,
                             int param_dtype, const float *dout, int64_t dout_stride_n,
                             int64_t dout_stride_l, float *dx, int64_t n, void *stream);
+/* The same gradient without a second gather pass [r4]: emer_hashgrid_fwd_jac is emer_hashgrid_fwd on fp32 tables that also stores,
+ * for the rows jac_row0 .. n - 1 (the rows whose position needs a gradient), jac [n_levels][n - jac_row0][n_features][n_dims] =
+ * d out / d x; emer_hashgrid_bwd_input_jac contracts it with dOut (dout: pointer of the first of the n_rows rows, same strides).
+ * The encoding is bitwise emer_hashgrid_fwd's.  Same reference path as above (native.bwd's input gradient). */
+int emer_hashgrid_fwd_jac(const emer_grid_desc *host_desc, const float *x, const float *params, float *out,
+                          int64_t out_stride_n, int64_t out_stride_l, uint64_t *slice_masks, float *jac,
+                          int64_t jac_row0, int64_t n, void *stream);
+int emer_hashgrid_bwd_input_jac(const emer_grid_desc *host_desc, const float *jac, const float *dout,
+                                int64_t dout_stride_n, int64_t dout_stride_l, float *dx, int64_t n_rows, void *stream);
 
 /* Layout glue: level-major [L][N][F] <-> row-major [N, L*F] (the layout tcnn_modules.py:263 returns).
  * to_row_major != 0: src is level-major, dst row-major; 0: the reverse.  src != dst. */

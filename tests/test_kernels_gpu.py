@@ -112,6 +112,42 @@ def test_hashgrid_backward(hip_lib, oracle, name):
     np.testing.assert_allclose(xd.grad.cpu().numpy(), ref_dx, rtol=0, atol=2e-5 * sx)
 
 
+@pytest.mark.parametrize("name", list(GRIDS))
+@pytest.mark.parametrize("skip", [0, 1500])
+def test_hashgrid_input_gradient_from_stored_jacobians(hip_lib, oracle, monkeypatch, name, skip):
+    """[r4] ops.hashgrid_encode_lm with positions that need a gradient: the forward stores d out / d x for the rows past
+    ``skip_dx_rows`` (emer_hashgrid_fwd_jac) and the backward contracts them with dOut (emer_hashgrid_bwd_input_jac).  The encoding is
+    bitwise the plain forward's (the four-feature grids the flow configs differentiate), the input gradient matches the oracle AND the
+    gather kernel it replaces, skipped rows get zero."""
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    n = 4099
+    x, p = _inputs(meta, n, 13)
+    L, F = meta.n_levels, meta.n_features
+    dout = torch.randn(n, meta.n_output_dims, generator=torch.Generator().manual_seed(14))
+    dev = _dev()
+    dlm = dout.view(n, L, F).permute(1, 0, 2).contiguous().to(dev)
+    got = {}
+    for jac in (True, False):
+        monkeypatch.setattr(ops, "GRID_JAC", jac)
+        xd = x.to(dev).requires_grad_(True)
+        pd = p.to(dev).requires_grad_(True)
+        lm = ops.hashgrid_encode_lm(xd, pd, desc, skip_dx_rows=skip)
+        lm.backward(dlm)
+        got[jac] = (lm.detach().clone(), xd.grad.clone(), pd.grad.clone())
+    if F * 4 > 8:   # (entries of <= 8 bytes: the plain forward takes its paired-gather path on hashed levels, the Jacobian forward the
+        assert torch.equal(got[True][0], got[False][0]), "the Jacobian forward must not change the encoding"   # generic loop)
+    else:
+        np.testing.assert_allclose(got[True][0].cpu().numpy(), got[False][0].cpu().numpy(), rtol=0, atol=1e-6)
+    gp = got[False][2].abs().max().item()   # (two launches of the owner-computes backward agree to an ulp or two, not bitwise)
+    assert (got[True][2] - got[False][2]).abs().max().item() <= 1e-6 * gp
+    ref_dx = oracle.hashgrid_bwd_input(meta, x, p, dout)
+    ref_dx[:skip] = 0.0
+    sx = np.abs(ref_dx).max()
+    np.testing.assert_allclose(got[True][1].cpu().numpy(), ref_dx, rtol=0, atol=2e-5 * sx)
+    np.testing.assert_allclose(got[True][1].cpu().numpy(), got[False][1].cpu().numpy(), rtol=0, atol=2e-6 * sx)
+
+
 def test_hashgrid_fp16_grads(hip_lib, oracle):
     from emernerf_amd import ops
     meta, desc = _mk(oracle, "cfg2_static")
