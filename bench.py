@@ -160,7 +160,7 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     batches = [synthetic_rays(rays, dev, seed=3000 + i, **kw) for i in range(4)]
     for i in range(init_steps + warmup):
         tr.train_step(batches[i % 4])
-    names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input"]
+    names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input", "emer_hashgrid_bwd_input_jac"]
     timer = _lib.KernelTimer(names)
     graphed = tr.use_graph   # (False if the capture failed: Trainer falls back to eager launches with a warning)
     if not graphed:
@@ -190,9 +190,11 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     N = rays * samples
     dyn = tr.cfg.dynamic_xyz_encoder
     D4, L4, F4 = dyn.n_input_dims, dyn.n_levels, dyn.n_features_per_level
-    f4 = [u for u, tg in zip(us["emer_hashgrid_fwd"], tags["emer_hashgrid_fwd"]) if tg == (D4, L4, F4)]
-    b4 = [u for u, tg in zip(us["emer_hashgrid_bwd_params_sliced"], tags["emer_hashgrid_bwd_params_sliced"]) if tg == (D4, L4, F4)]
-    i4 = [u for u, tg in zip(us["emer_hashgrid_bwd_input"], tags["emer_hashgrid_bwd_input"]) if tg == (D4, L4, F4)]
+    def xyzt(*ks):   # launches on the xyzt grids; the evaluations whose positions need a gradient run the Jacobian-storing forward and
+        return [u for k in ks for u, tg in zip(us[k], tags[k]) if tg == (D4, L4, F4)]   # the streaming input gradient [r4]
+    f4 = xyzt("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac")
+    b4 = xyzt("emer_hashgrid_bwd_params_sliced")
+    i4 = xyzt("emer_hashgrid_bwd_input", "emer_hashgrid_bwd_input_jac")
     if f4 and b4:
         fb4, bb4 = grid_alg_bytes(D4, L4, F4)
         # samples per launch differ once evaluations are batched: bytes are counted per SAMPLE EVALUATION of the step
@@ -313,7 +315,8 @@ def main():
     # HIP events inside the timed region only around the roofline kernels (the grid encode + its backward: five
     # launches per step).  Timing every entry point costs ~1.4 ms/step in event records, so the full per-kernel
     # breakdown comes from a second, separately instrumented pass after the timed region.
-    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels", "emer_hashgrid_bwd_params"]
+    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels",
+                  "emer_hashgrid_bwd_params", "emer_hashgrid_bwd_input_jac"]
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",

@@ -50,6 +50,50 @@ template <> __device__ __forceinline__ void load_feats<8, __half>(const __half *
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
 }
 
+#ifndef EMER_DENSE_PAIR
+#define EMER_DENSE_PAIR 0   // [r4 experiment, off] double-width gathers of x-adjacent entries on DENSE levels.  Same-session A/B on MI355X
+#endif                      // (tools/ab_grid.sh): main grid fwd 229 vs 231 us, proposal grids 80 vs 77 and 108 vs 106 us, step 2.398 vs 2.397 ms --
+                            // the coarse levels are L1 hits whose lane-request count is not what bounds the kernel; nothing to gain
+// 2 F consecutive features (two x-adjacent entries of a dense level) from an address that is only ENTRY-aligned: one double-width
+// gather (buffer loads need dword alignment only)
+// (16 bytes at 8-byte alignment: hipcc splits the plain load into two dwordx2; the buffer form of the instruction carries no alignment
+// assumption -- `table` / `table_bytes` are level-uniform, the entry offset rides in the 32-bit voffset)
+template <int NW, typename PT>
+__device__ __forceinline__ void words_to_feats(const uint32_t (&w)[NW], float (&v)[NW * 4 / (int)sizeof(PT)]) {
+    if constexpr (sizeof(PT) == 4) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) v[i] = __builtin_bit_cast(float, w[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            uint32_t wv = w[i];
+            const float2 t = __half22float2(*reinterpret_cast<__half2 *>(&wv));
+            v[2 * i] = t.x; v[2 * i + 1] = t.y;
+        }
+    }
+}
+template <int F, typename PT>
+__device__ __forceinline__ void load_feats_pair(const PT *__restrict__ table, uint32_t table_bytes, uint32_t idx0, float (&v)[2 * F]) {
+    constexpr int NW = (int)(sizeof(PT) * 2 * F / 4), AL = (int)(sizeof(PT) * F) < 4 ? 4 : (int)(sizeof(PT) * F);
+    // (the buffer form for both widths: a plain 8-byte load next to the two-load fallback of the wrap case was if-converted by hipcc
+    // into two dword loads with a selected address -- the double-width gather gone)
+    static_assert(NW == 2 || NW == 4, "entry pairs of 8 or 16 bytes");
+    (void)AL;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT *>(table), (short)0, (int)table_bytes, 0x00020000);
+    const int off = (int)(idx0 * (uint32_t)(sizeof(PT) * F));
+    if constexpr (NW == 4) {
+        using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4_t q = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        const uint32_t w[4] = {q[0], q[1], q[2], q[3]};
+        words_to_feats<4, PT>(w, v);
+    } else {
+        using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+        const u32x2_t q = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        const uint32_t w[2] = {q[0], q[1]};
+        words_to_feats<2, PT>(w, v);
+    }
+}
+
 // Relaxed device-scope float atomics.  The file is built with -munsafe-fp-atomics so these lower
 // to global_atomic_add_f32 / global_atomic_pk_add_f16 (no CAS loop, no return value).
 template <int F>
@@ -458,6 +502,52 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
                 if (masks) {
                     set_row<Q>(mask, slice_of(plan, level, idx0));
                     if (!x_pair_one_slice) set_row<Q>(mask, slice_of(plan, level, idx1));  // (level-uniform)
+                }
+            }
+        }
+        }
+        if constexpr (sizeof(PT) * F <= 8 && sizeof(PT) * F >= 4 && !JAC && EMER_DENSE_PAIR) {
+        if (!li.hashed) {  // level-uniform
+            // [r4] Dense level: index = x + res * (y + res * (...)), so the x-neighbours of a (y, z[, t]) combination are ADJACENT entries
+            // -- one double-width gather from an entry-aligned address instead of two (half the L1/TA lane requests on the coarse
+            // levels: a third of the proposal grids' gathers).  The exception is the one entry at which the index wraps (idx0 = size - 1,
+            // only reachable from coordinates outside [0, 1]): two loads there.  Accumulation order unchanged (corner-major, x fastest).
+            paired = true;
+#pragma unroll
+            for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+                uint32_t c[D];
+                float t[D];
+                c[0] = gi[0];
+#pragma unroll
+                for (int d = 1; d < D; ++d) {
+                    const uint32_t bit = (m >> (d - 1)) & 1u;
+                    c[d] = gi[d] + bit;
+                    t[d] = bit ? w[d] : 1.0f - w[d];
+                }
+                const uint32_t idx0 = grid_index<D>(li, c);
+                uint32_t idx1 = idx0 + 1u;
+                float v0[F], v1[F];
+                if (idx1 < li.size) {
+                    float e[2 * F];
+                    load_feats_pair<F, PT>(table, li.size * (uint32_t)(sizeof(PT) * F), idx0, e);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) { v0[f] = e[f]; v1[f] = e[F + f]; }
+                } else {
+                    c[0] = gi[0] + 1u;
+                    idx1 = grid_index<D>(li, c);
+                    load_feats<F, PT>(table + (size_t)idx0 * F, v0);
+                    load_feats<F, PT>(table + (size_t)idx1 * F, v1);
+                }
+                float wa = 1.0f - w[0], wb = w[0];  // ((t0*t1)*t2)*t3, as the generic loop
+#pragma unroll
+                for (int d = 1; d < D; ++d) { wa *= t[d]; wb *= t[d]; }
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] += wa * v0[f];
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
+                if (masks) {
+                    set_row<Q>(mask, slice_of(plan, level, idx0));
+                    set_row<Q>(mask, slice_of(plan, level, idx1));
                 }
             }
         }
