@@ -526,6 +526,10 @@ def main():
         b_us = b_us + [lv[i] + lv[i + 1] for i in range(0, len(lv) - 1, 2)]
         f_avg = sum(f_us) / max(len(f_us), 1)
         b_avg = sum(b_us) / max(len(b_us), 1)
+
+        def spread(v):   # median and the 10th / 90th percentile of the per-launch durations next to the average the roofline uses
+            s_ = sorted(v)
+            return {"median": s_[len(s_) // 2], "p10": s_[len(s_) // 10], "p90": s_[(9 * len(s_)) // 10], "launches": len(s_)} if s_ else None
         per_kernel = {n: {"launches_per_step": len(v) / breakdown_steps, "ms_per_step": sum(v) / 1e3 / breakdown_steps,
                           "avg_us": (sum(v) / len(v)) if v else 0.0}
                       for n, v in breakdown.elapsed_us().items() if v}
@@ -651,7 +655,7 @@ def main():
                          "timed_in": (f"HIP events on the dispatch packets of the eager loop of {args.steps} steps that follows the hipGraph-timed "
                                       "region (config.other_launch_mode; a graph replay launches nothing from the host to bracket)")
                          if (args.graph and world == 1) else "HIP events on the dispatch packets inside the timed region",
-                         "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg,
+                         "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg, "fwd_us_spread": spread(f_us), "bwd_us_spread": spread(b_us),
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
             "roofline_trained_like": roof2,
             "roofline_fp16_tables": roof16,
