@@ -65,6 +65,8 @@ SIGNATURES = {
     "emer_cast_f32_f16": [_P, _P, c_int64, _P],
     "emer_render_weights_fwd": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_render_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
+    "emer_composite_rgb_fwd": [_P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "emer_composite_rgb_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P],
     "emer_blend_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P],
     "emer_blend_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_ray_epilogue_fwd": [_P, _P, _P, c_int64, _P, _P, _P, _P, _P],

@@ -50,6 +50,17 @@ int launch_dw_reduce(const float *partials, int32_t n_blocks, int64_t stride, in
 int launch_dw_reduce_cols(const float *partials, int32_t n_blocks, int64_t stride, int32_t n, int32_t k, float *dw, int64_t ld_dw,
                           int32_t n_segs, const int32_t *col, const int32_t *width, const int32_t *dst, hipStream_t st);
 
+// ... and several gradients of one partial buffer in ONE launch [r4]
+#define EMER_DW_MAX_JOBS 3
+struct DwReduceJob {
+    int64_t off;                 // float offset of this gradient inside a partial
+    int32_t n, k;                // dW [n][k], followed by dbias [n] when db != nullptr
+    float *dw; int64_t ld_dw; float *db;
+    int32_t n_segs;              // 0: plain; else column blocks col[s] .. col[s] + width[s] - 1 land at dw[row * ld_dw + dst[s] ..]
+    int32_t col[4], width[4], dst[4];
+};
+int launch_dw_reduce_multi(const float *partials, int32_t n_blocks, int64_t stride, int n_jobs, const DwReduceJob *jobs, hipStream_t st);
+
 // Measurement hook (emer_profile_next): a pair of caller-owned HIP events that the NEXT instrumented launch of this thread
 // records immediately before / after its kernel (hipExtLaunchKernelGGL), so bench.py times the kernel itself and not
 // the host's enqueue latency around it.  One-shot; both null when not armed.

@@ -296,9 +296,190 @@ __global__ __launch_bounds__(256) void blend_accumulate_bwd_kernel(const float *
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------ [r4]
+// The static model's `rendering` (render_utils.py:73-122,158-159,217-220) as ONE launch each way: weights / transmittance scan,
+// accumulation of the 3-channel colour, and the per-ray epilogue (opacity clamp, expected depth, median depth, sky composite) --
+// three launches forward and three backward before, on tensors of a few MB.  Same arithmetic, same order as the three kernels
+// (render_weights_fwd / accumulate_fwd_small<3> / ray_epilogue_fwd): results are bitwise theirs.  rgb == nullptr: geometry only
+// (the density-only render of the lidar step).
+__global__ __launch_bounds__(256) void composite_rgb_fwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                                const float *__restrict__ sigma, const float *__restrict__ rgb,
+                                                                const float *__restrict__ rgb_sky, int64_t R, int32_t S,
+                                                                float *__restrict__ weights, float *__restrict__ trans,
+                                                                float *__restrict__ t_mid, float *__restrict__ t_dist,
+                                                                float *__restrict__ ray_stats, float *__restrict__ opacity,
+                                                                float *__restrict__ depth, float *__restrict__ median_out,
+                                                                float *__restrict__ rgb_out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    float carry = 0.0f, wsum = 0.0f, wmid = 0.0f, wcarry = 0.0f, median = 0.0f, last_mid = 0.0f;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    bool found = false;
+    for (int32_t base = 0; base < S; base += kWave) {
+        const int32_t s = base + lane;
+        const bool ok = s < S;
+        const int64_t i = r * S + s;
+        const float a = ok ? ts[i] : 0.0f, b = ok ? te[i] : 0.0f, sg = ok ? sigma[i] : 0.0f;
+        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        if (ok && rgb) { c0 = rgb[i * 3 + 0]; c1 = rgb[i * 3 + 1]; c2 = rgb[i * 3 + 2]; }
+        const float sdt = sg * (b - a);
+        const float incl = wave_inclusive_sum(sdt, lane);
+        const float excl = carry + (incl - sdt);
+        const float T = expf(-excl);
+        const float al = 1.0f - expf(-sdt);
+        const float w = ok ? T * al : 0.0f;
+        const float mid = (a + b) / 2.0f;
+        if (ok) {
+            weights[i] = w;
+            if (trans) trans[i] = T;
+            if (t_mid) t_mid[i] = mid;
+            if (t_dist) t_dist[i] = b - a;
+            acc[0] += w * c0; acc[1] += w * c1; acc[2] += w * c2;
+        }
+        carry += __shfl(incl, kWave - 1, kWave);
+        const float cw = wcarry + wave_inclusive_sum(w, lane);
+        const unsigned long long hit = __ballot(ok && cw >= 0.5f);
+        if (!found && hit) {
+            const int first = __ffsll((long long)hit) - 1;
+            median = __shfl(mid, first, kWave);
+            found = true;
+        }
+        const int last_lane = (S - 1 - base) < (kWave - 1) ? (S - 1 - base) : (kWave - 1);
+        last_mid = __shfl(mid, last_lane, kWave);
+        wcarry = __shfl(cw, kWave - 1, kWave);
+        wsum += w;
+        wmid += w * mid;
+    }
+    wsum = wave_sum(wsum);
+    wmid = wave_sum(wmid);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = wave_sum(acc[c]);
+    if (lane == 0) {
+        const float med = found ? median : last_mid;
+        *reinterpret_cast<float4 *>(ray_stats + r * 4) = make_float4(wsum, wmid, med, 0.0f);
+        const float o = fminf(fmaxf(wsum, 1e-6f), 1.0f);  // torch.clamp(1e-6, 1.0)
+        opacity[r] = o;
+        depth[r] = wmid / o;
+        if (median_out) median_out[r] = med;
+        if (rgb_out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = acc[c];
+                if (rgb_sky) v = v + rgb_sky[r * 3 + c] * (1.0f - o);
+                rgb_out[r * 3 + c] = v;
+            }
+        }
+    }
+}
+
+// Reverse of the above: ray_epilogue_bwd (per ray, by every lane), accumulate_bwd_small<3> and render_weights_bwd in one pass.
+// d_weights / d_trans: gradients that reach the extras from other consumers (may be null).
+__global__ __launch_bounds__(256) void composite_rgb_bwd_kernel(const float *__restrict__ ts, const float *__restrict__ te,
+                                                                const float *__restrict__ sigma, const float *__restrict__ rgb,
+                                                                const float *__restrict__ rgb_sky, const float *__restrict__ weights,
+                                                                const float *__restrict__ ray_stats, const float *__restrict__ d_rgb_out,
+                                                                const float *__restrict__ d_opacity, const float *__restrict__ d_depth,
+                                                                const float *__restrict__ d_weights, const float *__restrict__ d_trans,
+                                                                int64_t R, int32_t S, float *__restrict__ d_sigma,
+                                                                float *__restrict__ d_rgb, float *__restrict__ d_rgb_sky) {
+    __shared__ float chunk_base[kRaysPerBlockC][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    const bool active = r < R;
+    const int32_t n_chunks = (S + kWave - 1) / kWave;
+    if (active) {
+        float carry = 0.0f;
+        for (int32_t c = 0; c < n_chunks; ++c) {
+            const int32_t s = c * kWave + lane;
+            const int64_t i = r * S + s;
+            const float sdt = s < S ? sigma[i] * (te[i] - ts[i]) : 0.0f;
+            if (lane == 0) chunk_base[wave][c] = carry;
+            carry += wave_sum(sdt);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    // per-ray part (ray_epilogue_bwd): gradient of (sum w, sum w mid) and of the accumulated colour
+    const float4 st = *reinterpret_cast<const float4 *>(ray_stats + r * 4);
+    const float o = fminf(fmaxf(st.x, 1e-6f), 1.0f);
+    float go = d_opacity ? d_opacity[r] : 0.0f;
+    const float gd = d_depth ? d_depth[r] : 0.0f;
+    go -= gd * st.y / (o * o);
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    if (d_rgb_out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g[c] = d_rgb_out[r * 3 + c];
+            if (rgb_sky) {
+                go -= g[c] * rgb_sky[r * 3 + c];
+                if (d_rgb_sky && lane == 0) d_rgb_sky[r * 3 + c] = g[c] * (1.0f - o);
+            }
+        }
+    }
+    const float g0 = (st.x >= 1e-6f && st.x <= 1.0f) ? go : 0.0f;  // clamp passes the gradient where min <= x <= max (torch semantics)
+    const float g1 = gd / o;
+    float suffix = 0.0f;
+    for (int32_t c = n_chunks - 1; c >= 0; --c) {
+        const int32_t s = c * kWave + lane;
+        const bool ok = s < S;
+        const int64_t i = r * S + s;
+        const float a = ok ? ts[i] : 0.0f, b = ok ? te[i] : 0.0f, sg = ok ? sigma[i] : 0.0f;
+        const float dt = b - a;
+        const float sdt = sg * dt;
+        const float incl = wave_inclusive_sum(sdt, lane);
+        const float excl = chunk_base[wave][c] + (incl - sdt);
+        const float T = expf(-excl);
+        const float e = expf(-sdt);
+        const float w = T * (1.0f - e);
+        float gw = (ok && d_weights) ? d_weights[i] : 0.0f;
+        if (ok && rgb && d_rgb_out) {   // accumulate_bwd: d_w += sum_c g_c rgb_c,  d_rgb = w g
+            float acc = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) acc += g[ch] * rgb[i * 3 + ch];
+            gw += acc;
+            if (d_rgb) {
+                const float ws = weights[i];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) d_rgb[i * 3 + ch] = ws * g[ch];
+            }
+        }
+        gw += g0 + g1 * ((a + b) / 2.0f);
+        const float gT = (ok && d_trans) ? d_trans[i] : 0.0f;
+        const float term = ok ? gw * w + gT * T : 0.0f;
+        const float sfx_incl = wave_inclusive_suffix_sum(term, lane);
+        const float later = suffix + (sfx_incl - term);
+        if (ok) d_sigma[i] = dt * (gw * T * e - later);
+        suffix += __shfl(sfx_incl, 0, kWave);
+    }
+}
+
 }  // namespace emer
 
 using namespace emer;
+
+extern "C" int emer_composite_rgb_fwd(const float *ts, const float *te, const float *sigma, const float *rgb, const float *rgb_sky, int64_t R,
+                                      int32_t S, float *weights, float *trans, float *t_mid, float *t_dist, float *ray_stats, float *opacity,
+                                      float *depth, float *median_depth, float *rgb_out, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1, "composite_rgb_fwd: bad sizes R=%lld S=%d", (long long)R, S);
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(ts && te && sigma && weights && ray_stats && opacity && depth && (!rgb_out || rgb), "composite_rgb_fwd: null pointer");
+    hipLaunchKernelGGL(composite_rgb_fwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), ts, te, sigma,
+                       rgb_out ? rgb : nullptr, rgb_sky, R, S, weights, trans, t_mid, t_dist, ray_stats, opacity, depth, median_depth, rgb_out);
+    return check_launch("composite_rgb_fwd");
+}
+
+extern "C" int emer_composite_rgb_bwd(const float *ts, const float *te, const float *sigma, const float *rgb, const float *rgb_sky,
+                                      const float *weights, const float *ray_stats, const float *d_rgb_out, const float *d_opacity,
+                                      const float *d_depth, const float *d_weights, const float *d_trans, int64_t R, int32_t S,
+                                      float *d_sigma, float *d_rgb, float *d_rgb_sky, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && S <= 4096, "composite_rgb_bwd: bad sizes R=%lld S=%d (S <= 4096)", (long long)R, S);
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(ts && te && sigma && ray_stats && d_sigma && (!d_rgb || (rgb && weights && d_rgb_out)), "composite_rgb_bwd: null pointer");
+    hipLaunchKernelGGL(composite_rgb_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), ts, te, sigma, rgb,
+                       rgb_sky, weights, ray_stats, d_rgb_out, d_opacity, d_depth, d_weights, d_trans, R, S, d_sigma, d_rgb, d_rgb_sky);
+    return check_launch("composite_rgb_bwd");
+}
 
 extern "C" int emer_render_weights_fwd(const float *ts, const float *te, const float *sigma, int64_t R, int32_t S,
                                        float *weights, float *trans, float *alphas, float *cdfs, float *ray_stats,

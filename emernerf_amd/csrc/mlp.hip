@@ -287,6 +287,44 @@ __global__ __launch_bounds__(256) void linear_dw_reduce_kernel(const float *__re
     } else if (dbias) __hip_atomic_fetch_add(dbias + (i - nk), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// [r4] Several (dW | dbias) pairs of ONE partial buffer in one launch (blockIdx.z = job): the fused backward kernels leave two or three
+// gradients in each workgroup's partial, and three 5-us launches in a row cost more than the sums themselves.
+struct DwJobs {
+    int32_t n_jobs;
+    int64_t off[EMER_DW_MAX_JOBS], nk[EMER_DW_MAX_JOBS], extent[EMER_DW_MAX_JOBS];   // start inside a partial, floats of dW, floats of dW + dbias
+    float *dw[EMER_DW_MAX_JOBS], *dbias[EMER_DW_MAX_JOBS];
+    DwDst dst[EMER_DW_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void linear_dw_reduce_multi_kernel(const float *__restrict__ partials, int32_t n_blocks, int64_t stride, const DwJobs jobs) {
+    const int j = (int)blockIdx.z;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= jobs.extent[j]) return;
+    const int32_t per = (n_blocks + (int32_t)gridDim.y - 1) / (int32_t)gridDim.y;
+    const int32_t b0 = (int32_t)blockIdx.y * per;
+    const int32_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    if (b0 >= b1) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const float *__restrict__ p = partials + jobs.off[j] + i;
+    int32_t b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        a0 += p[(int64_t)b * stride];
+        a1 += p[(int64_t)(b + 1) * stride];
+        a2 += p[(int64_t)(b + 2) * stride];
+        a3 += p[(int64_t)(b + 3) * stride];
+    }
+    for (; b < b1; ++b) a0 += p[(int64_t)b * stride];
+    const float a = (a0 + a1) + (a2 + a3);
+    const DwDst &dst = jobs.dst[j];
+    if (i < jobs.nk[j]) {
+        const int32_t n = (int32_t)(i / dst.K), k = (int32_t)(i - (int64_t)n * dst.K);
+        int64_t o = -1;
+#pragma unroll
+        for (int sg = 0; sg < EMER_CHAIN_MAX_SEGS; ++sg)
+            if (sg < dst.n && k >= dst.col[sg] && k < dst.col[sg] + dst.width[sg]) o = (int64_t)n * dst.ld + dst.dst[sg] + (k - dst.col[sg]);
+        if (o >= 0) __hip_atomic_fetch_add(jobs.dw[j] + o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (jobs.dbias[j]) __hip_atomic_fetch_add(jobs.dbias[j] + (i - jobs.nk[j]), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static inline uint32_t dw_reduce_splits(int32_t n_blocks, int64_t stride) {
     // ~2048 workgroups in total, at least 8 partial blocks per range
     int64_t s = 2048 / ((stride + 255) / 256);
@@ -332,6 +370,31 @@ int launch_dw_reduce_cols(const float *partials, int32_t n_blocks, int64_t strid
     hipLaunchKernelGGL(linear_dw_reduce_kernel, dim3((uint32_t)ceil_div(extent, 256), dw_reduce_splits(n_blocks, extent)), dim3(256), 0, st, partials,
                        n_blocks, stride, (int64_t)n * k, dw, (float *)nullptr, d, extent);
     return check_launch("dw_reduce_cols");
+}
+
+// Up to EMER_DW_MAX_JOBS gradients of one partial buffer in one launch.  Job j: dW [n][k] (+ dbias [n] when db != null) at float `off`
+// of every partial; `n_segs` == 0: dW goes to dw[row * ld + column]; else its column blocks are scattered as in launch_dw_reduce_cols.
+int launch_dw_reduce_multi(const float *partials, int32_t n_blocks, int64_t stride, int n_jobs, const DwReduceJob *jb, hipStream_t st) {
+    DwJobs jobs;
+    jobs.n_jobs = n_jobs;
+    int64_t max_extent = 0;
+    for (int j = 0; j < EMER_DW_MAX_JOBS; ++j) {
+        const bool on = j < n_jobs;
+        const DwReduceJob &q = jb[on ? j : 0];
+        DwDst d = dw_dst_identity(q.k);
+        d.ld = q.ld_dw;
+        if (q.n_segs > 0) {
+            d.n = q.n_segs;
+            for (int i = 0; i < q.n_segs && i < EMER_CHAIN_MAX_SEGS; ++i) { d.col[i] = q.col[i]; d.width[i] = q.width[i]; d.dst[i] = q.dst[i]; }
+        }
+        jobs.dst[j] = d;
+        jobs.off[j] = q.off; jobs.nk[j] = (int64_t)q.n * q.k; jobs.extent[j] = on ? (int64_t)q.n * q.k + (q.db ? q.n : 0) : 0;
+        jobs.dw[j] = q.dw; jobs.dbias[j] = q.db;
+        if (jobs.extent[j] > max_extent) max_extent = jobs.extent[j];
+    }
+    hipLaunchKernelGGL(linear_dw_reduce_multi_kernel, dim3((uint32_t)ceil_div(max_extent, 256), dw_reduce_splits(n_blocks, max_extent), (uint32_t)n_jobs),
+                       dim3(256), 0, st, partials, n_blocks, stride, jobs);
+    return check_launch("dw_reduce_multi");
 }
 
 static int launch_linear(const float *x, int64_t ldx, const float *w, int64_t sbj, int64_t sbk, const float *bias, float *y,

@@ -2244,8 +2244,8 @@ extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const fl
     if (n_feat == 1) rc = EMER_NBW(1); else if (n_feat == 2) rc = EMER_NBW(2); else if (n_feat == 4) rc = EMER_NBW(4); else rc = EMER_NBW(8);
 #undef EMER_NBW
     if (rc) return rc;
-    if (int r = launch_dw_reduce(workspace, (int32_t)grid, a.stride, 64, 64, dw1, ld_dw1, db1, st)) return r;
-    return launch_dw_reduce(workspace + 64 * 64 + 64, (int32_t)grid, a.stride, 64, k0, dw0, ld_dw0, db0, st);
+    const DwReduceJob jb[2] = {{0, 64, 64, dw1, ld_dw1, db1, 0, {0}, {0}, {0}}, {64 * 64 + 64, 64, k0, dw0, ld_dw0, db0, 0, {0}, {0}, {0}}};
+    return launch_dw_reduce_multi(workspace, (int32_t)grid, a.stride, 2, jb, st);
 }
 
 // Backward of the density MLP (emer_neck_fwd with n_out = 1) INCLUDING the weight gradients, for narrow inputs (L F <= 16: the
@@ -2276,8 +2276,8 @@ extern "C" int emer_density_bwd_fused(const float *ddens, const float *dens, con
     if (ks4 == 1) EMER_DBW(1); else if (ks4 == 2) EMER_DBW(2); else if (ks4 == 3) EMER_DBW(3); else EMER_DBW(4);
 #undef EMER_DBW
     if (int rc = check_launch("density_bwd_fused")) return rc;
-    if (int r = launch_dw_reduce(workspace, (int32_t)grid, a.stride, 64, k0, dw0, ld_dw0, db0, st)) return r;
-    return launch_dw_reduce(workspace + 64 * k0 + 64, (int32_t)grid, a.stride, 1, 64, dw1, 64, db1, st);
+    const DwReduceJob jb[2] = {{0, 64, k0, dw0, ld_dw0, db0, 0, {0}, {0}, {0}}, {64 * k0 + 64, 1, 64, dw1, 64, db1, 0, {0}, {0}, {0}}};
+    return launch_dw_reduce_multi(workspace, (int32_t)grid, a.stride, 2, jb, st);
 }
 
 // rgb head forward: a1 = relu(geo W0g^T + rb0[ray]); a2 = relu(a1 W1a^T + geo W1g^T + rb1[ray]); out = sigmoid(a2 W2^T + b2).
@@ -2436,11 +2436,11 @@ extern "C" int emer_rgb_head_bwd_fused(const float *dout, const float *out, cons
     }
     if (int rc = check_launch("rgb_head_bwd_fused")) return rc;
     // the workgroups' partials -> the parameters' gradients (+=): dW1's two column blocks land 0.. and 64 + kh.., dW0's at kh..
-    const int32_t c1[2] = {0, 64}, w1c[2] = {64, 64}, d1c[2] = {0, 64 + kh};
-    if (int rc = launch_dw_reduce_cols(workspace, (int32_t)grid, kRgbBwdWStride, 64, 128, dw1, ld_dw1, 2, c1, w1c, d1c, st)) return rc;
-    const int32_t c0[1] = {0}, w0c[1] = {64}, d0c[1] = {kh};
-    if (int rc = launch_dw_reduce_cols(workspace + 64 * 128, (int32_t)grid, kRgbBwdWStride, 64, 64, dw0, ld_dw0, 1, c0, w0c, d0c, st)) return rc;
-    return launch_dw_reduce(workspace + 64 * 128 + 64 * 64, (int32_t)grid, kRgbBwdWStride, 3, 64, dw2, ld_dw2, db2, st);
+    // (one launch for the three)
+    const DwReduceJob jb[3] = {{0, 64, 128, dw1, ld_dw1, nullptr, 2, {0, 64}, {64, 64}, {0, 64 + kh}},
+                               {64 * 128, 64, 64, dw0, ld_dw0, nullptr, 1, {0}, {64}, {kh}},
+                               {64 * 128 + 64 * 64, 3, 64, dw2, ld_dw2, db2, 0, {0}, {0}, {0}}};
+    return launch_dw_reduce_multi(workspace, (int32_t)grid, kRgbBwdWStride, 3, jb, st);
 }
 
 // floats of workspace emer_rgb_head_bwd needs when it also produces dw2 / db2

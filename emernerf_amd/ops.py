@@ -605,6 +605,59 @@ def render_weights(t_starts: Tensor, t_ends: Tensor, sigma: Tensor, want_t: bool
     return _RenderWeightsFn.apply(t_starts, t_ends, sigma, want_t)
 
 
+class _CompositeRgbFn(torch.autograd.Function):
+    """[r4] ``rendering`` of a model with one density and one colour per sample (render_utils.py:73-122,158-159,217-220) as one launch
+    each way: (weights, trans, t_vals, t_dist, opacity [R,1], depth [R,1], median_depth [R,1], rgb [R,3] | None).  Same values as
+    render_weights -> accumulate_along_rays -> ray_epilogue (bitwise: tests/test_kernels_gpu.py); ``rgb`` None: geometry only."""
+
+    @staticmethod
+    def forward(ctx, t_starts: Tensor, t_ends: Tensor, sigma: Tensor, rgb: Optional[Tensor], rgb_sky: Optional[Tensor]):
+        ctx.set_materialize_grads(False)
+        ts, te, sg = _f32c(t_starts), _f32c(t_ends), _f32c(sigma)
+        R, S = sg.shape
+        c = None if rgb is None else _f32c(rgb).reshape(R, S, 3)
+        sk = None if (rgb_sky is None or rgb is None) else _f32c(rgb_sky).reshape(R, 3)
+        with torch.cuda.device(sg.device):
+            w, T, tm, td = (torch.empty_like(sg) for _ in range(4))
+            stats = torch.empty((R, 4), device=sg.device, dtype=torch.float32)
+            opa, dep, med = (torch.empty((R, 1), device=sg.device, dtype=torch.float32) for _ in range(3))
+            out = torch.empty((R, 3), device=sg.device, dtype=torch.float32) if c is not None else None
+            _lib.call("emer_composite_rgb_fwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(c), _ptr(sk), R, S, _ptr(w), _ptr(T), _ptr(tm), _ptr(td),
+                      _ptr(stats), _ptr(opa), _ptr(dep), _ptr(med), _ptr(out), _stream(sg))
+        ctx.save_for_backward(ts, te, sg, c, sk, w, stats)
+        ctx.mark_non_differentiable(tm, td, med)
+        return w, T, tm, td, opa, dep, med, out
+
+    @staticmethod
+    def backward(ctx, dw, dT, _dtm, _dtd, dopa, ddep, _dmed, dout):
+        ts, te, sg, c, sk, w, stats = ctx.saved_tensors
+        R, S = sg.shape
+        if all(g is None for g in (dw, dT, dopa, ddep, dout)):
+            return None, None, None, None, None
+        f = lambda g: None if g is None else _f32c(g)
+        gw, gT, go, gd, gr = f(dw), f(dT), f(dopa), f(ddep), f(dout)
+        need_rgb = c is not None and ctx.needs_input_grad[3] and gr is not None
+        need_sky = sk is not None and ctx.needs_input_grad[4] and gr is not None
+        with torch.cuda.device(sg.device):
+            dsig = torch.empty_like(sg)
+            drgb = torch.empty_like(c) if need_rgb else None
+            dsky = torch.empty_like(sk) if need_sky else None
+            _lib.call("emer_composite_rgb_bwd", _ptr(ts), _ptr(te), _ptr(sg), _ptr(c), _ptr(sk), _ptr(w), _ptr(stats), _ptr(gr), _ptr(go),
+                      _ptr(gd), _ptr(gw), _ptr(gT), R, S, _ptr(dsig), _ptr(drgb), _ptr(dsky), _stream(sg))
+        if c is not None and ctx.needs_input_grad[3] and drgb is None:
+            drgb = torch.zeros_like(c)
+        return None, None, (dsig if ctx.needs_input_grad[2] else None), drgb, dsky
+
+
+# one launch each way for the static model's rendering (EMER_FUSE_COMPOSITE=0: the three kernels of rounds 1-3)
+FUSE_COMPOSITE = os.environ.get("EMER_FUSE_COMPOSITE", "1") != "0"
+
+
+def composite_rgb(t_starts: Tensor, t_ends: Tensor, sigma: Tensor, rgb: Optional[Tensor], rgb_sky: Optional[Tensor]):
+    _check_cuda(t_starts, t_ends, sigma)
+    return _CompositeRgbFn.apply(t_starts, t_ends, sigma, rgb, rgb_sky)
+
+
 class _AccumulateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights: Tensor, values: Optional[Tensor]):

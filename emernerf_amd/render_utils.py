@@ -37,6 +37,23 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
     """render_utils.py:48-287."""
     results = query_fn(t_starts, t_ends)
     density = results["density"].squeeze(-1)
+    if (ops.FUSE_COMPOSITE and density.is_cuda and density.dim() == 2 and "static_density" not in results and "static_rgb" not in results
+            and "dino_feat" not in results and "static_dino_feat" not in results
+            and ("rgb" not in results or results["rgb"].shape[-1] == 3)):
+        # [r4] one density, one colour (or none: the lidar step's density-only render): scan, accumulation and per-ray epilogue in one
+        # launch each way (:73-122,158-159,217-220) -- same values as the general path below
+        rgb = results.get("rgb")
+        weights, trans, t_vals, t_dist, opacities, depths, median_depth, rgb_out = ops.composite_rgb(
+            t_starts, t_ends, density, rgb, results.get("rgb_sky") if rgb is not None else None)
+        extras = {"weights": weights, "trans": trans, "t_vals": t_vals, "t_dist": t_dist}
+        for k in ["forward_flow", "backward_flow", "forward_pred_backward_flow", "backward_pred_forward_flow"]:
+            if k in results:
+                extras[k] = results[k]
+        results_dict = {"density": density, "depth": depths, "opacity": opacities, "median_depth": median_depth}
+        if rgb_out is not None:
+            results_dict["rgb"] = rgb_out
+        results_dict["extras"] = extras
+        return results_dict
     # one scan kernel: weights, transmittance, the per-ray sums behind opacity / depth / median depth (:102-122) and the
     # t_vals / t_dist extras (:84-85)
     weights, trans, _, _, stats, t_vals, t_dist = ops.render_weights(t_starts, t_ends, density, want_t=True)

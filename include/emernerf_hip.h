@@ -241,6 +241,21 @@ int emer_render_weights_bwd(const float *t_starts, const float *t_ends, const fl
                             const float *d_weights, const float *d_trans, const float *d_alphas,
                             const float *d_ray_stats, int64_t n_rays, int32_t n_samples, float *d_sigma,
                             void *stream);
+
+/* [r4] The static model's `rendering` as ONE launch each way (render_utils.py:73-122,158-159,217-220): the scan of
+ * emer_render_weights_fwd, the 3-channel emer_accumulate_fwd and emer_ray_epilogue_fwd (opacity = clamp(sum w, 1e-6, 1),
+ * depth = sum(w mid) / opacity, median depth, rgb_out = sum(w rgb) + rgb_sky (1 - opacity)); results bitwise those of the three
+ * calls.  rgb / rgb_out NULL: geometry only.  trans, t_mid, t_dist, median_depth, rgb_sky may be NULL.  ray_stats [R,4] is saved
+ * for the backward.  The backward takes the gradients of rgb_out [R,3], opacity [R], depth [R] and -- from other consumers of the
+ * extras -- weights / trans [R,S] (each may be NULL) and writes d_sigma [R,S], d_rgb [R,S,3] and d_rgb_sky [R,3] (may be NULL). */
+int emer_composite_rgb_fwd(const float *t_starts, const float *t_ends, const float *sigma, const float *rgb,
+                           const float *rgb_sky, int64_t n_rays, int32_t n_samples, float *weights, float *trans,
+                           float *t_mid, float *t_dist, float *ray_stats, float *opacity, float *depth,
+                           float *median_depth, float *rgb_out, void *stream);
+int emer_composite_rgb_bwd(const float *t_starts, const float *t_ends, const float *sigma, const float *rgb,
+                           const float *rgb_sky, const float *weights, const float *ray_stats, const float *d_rgb_out,
+                           const float *d_opacity, const float *d_depth, const float *d_weights, const float *d_trans,
+                           int64_t n_rays, int32_t n_samples, float *d_sigma, float *d_rgb, float *d_rgb_sky, void *stream);
 /* Static / dynamic / shadow colour blend + accumulation of `rendering` (radiance_fields/render_utils.py:125-175):
  *   a = static_density / (density + 1e-6), b = dynamic_density / (density + 1e-6),
  *   acc_rgb[r] = sum_s w (a rgb_s (1 - shadow) + b rgb_d),   acc_shadow_sq[r] = sum_s w shadow^2

@@ -975,3 +975,44 @@ def test_aggregate3_matches_the_reference_expression(hip_lib, N, C):
     up = torch.randn(N, C, generator=g).to(dev)
     (dx,) = torch.autograd.grad(out, x3, up)
     assert torch.equal(dx, torch.cat([up / 2.0, 0.5 * (up / 2.0), 0.5 * (up / 2.0)], 0))
+
+
+@pytest.mark.parametrize("R,S,with_rgb,with_sky", [(513, 128, True, True), (64, 48, True, False), (300, 200, False, False), (8192, 128, True, True)])
+def test_composite_rgb_equals_the_three_kernel_rendering(hip_lib, R, S, with_rgb, with_sky):
+    """[r4] emer_composite_rgb_fwd/bwd (the static model's `rendering` as one launch each way) against render_weights ->
+    accumulate_along_rays -> ray_epilogue: outputs bitwise equal, gradients of density / colour / sky colour equal to fp32 rounding,
+    including gradients that reach the extras (weights, trans) from other consumers and rays whose opacity sits on the clamp."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    ts = torch.sort(torch.rand(R, S + 1, generator=g) * 6, dim=-1).values
+    t0, t1 = ts[:, :-1].contiguous().to(dev), ts[:, 1:].contiguous().to(dev)
+    sig = (torch.rand(R, S, generator=g) * 3).pow(3)
+    sig[0] = 0.0          # opacity below the clamp's lower bound
+    sig[1] = 50.0         # saturated
+    rgb = torch.rand(R, S, 3, generator=g)
+    sky = torch.rand(R, 3, generator=g)
+    ups = {k: torch.randn(*shape, generator=g).to(dev) for k, shape in
+           {"rgb": (R, 3), "opa": (R, 1), "dep": (R, 1), "w": (R, S), "T": (R, S)}.items()}
+    res = {}
+    for fused in (False, True):
+        sg = sig.to(dev).requires_grad_(True)
+        c = rgb.to(dev).requires_grad_(True) if with_rgb else None
+        sk = sky.to(dev).requires_grad_(True) if (with_rgb and with_sky) else None
+        if fused:
+            w, T, tm, td, opa, dep, med, out = ops.composite_rgb(t0, t1, sg, c, sk)
+        else:
+            w, T, _, _, stats, tm, td = ops.render_weights(t0, t1, sg, want_t=True)
+            acc = ops.accumulate_along_rays(w, c) if c is not None else None
+            opa, dep, med, out = ops.ray_epilogue(stats, acc, sk if acc is not None else None)
+        loss = (opa * ups["opa"]).sum() + (dep * ups["dep"]).sum() + (w * ups["w"]).sum() + (T * ups["T"]).sum()
+        if out is not None:
+            loss = loss + (out * ups["rgb"]).sum()
+        loss.backward()
+        res[fused] = ([w, T, tm, td, opa, dep, med] + ([out] if out is not None else []),
+                      [sg.grad] + ([c.grad] if c is not None else []) + ([sk.grad] if sk is not None else []))
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a.detach(), b.detach())
+    for a, b in zip(res[False][1], res[True][1]):
+        scale = a.abs().max().item() + 1e-30
+        assert (a - b).abs().max().item() <= 2e-6 * scale, f"gradient differs: {(a - b).abs().max().item():.3e} of {scale:.3e}"
