@@ -69,6 +69,8 @@ SIGNATURES = {
     "emer_composite_rgb_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P],
     "emer_blend_accumulate_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P],
     "emer_blend_accumulate_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "emer_blend_accumulate_wide_fwd": [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P],
+    "emer_blend_accumulate_wide_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P],
     "emer_ray_epilogue_fwd": [_P, _P, _P, c_int64, _P, _P, _P, _P, _P],
     "emer_ray_epilogue_bwd": [_P, _P, _P, _P, _P, c_int64, _P, _P, _P],
     "emer_pixel_loss_fwd": [_P, _P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],

@@ -296,6 +296,77 @@ __global__ __launch_bounds__(256) void blend_accumulate_bwd_kernel(const float *
     }
 }
 
+// [r4] The same blend for the WIDE feature channels of the decomposed feature head (render_utils.py:247-252):
+//   acc[r][c] = sum_s w * (a * feat_s[c] + b * feat_d[c]),  a, b as above.
+// The reference materialises both ratios with a trailing axis, two [R,S,C] products, their sum and the accumulation -- with autograd,
+// ~15 elementwise launches on 67 MB tensors at the 2048-ray shard.  One wave owns a ray, lanes walk the channels (coalesced rows), the
+// per-sample scalars are wave-uniform loads; the backward needs two wave reductions per sample (<g, feat_s>, <g, feat_d>).
+__global__ __launch_bounds__(256) void blend_accumulate_wide_fwd_kernel(const float *__restrict__ w, const float *__restrict__ sig,
+                                                                        const float *__restrict__ sig_s, const float *__restrict__ sig_d,
+                                                                        const float *__restrict__ f_s, const float *__restrict__ f_d, int64_t R,
+                                                                        int32_t S, int32_t C, float *__restrict__ acc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    for (int32_t c0 = 0; c0 < C; c0 += kWave) {
+        const int32_t c = c0 + lane;
+        const bool on = c < C;
+        float a0 = 0.0f, a1 = 0.0f;   // two independent chains over the samples (loads of s and s + 1 in flight together)
+        int32_t s = 0;
+        for (; s + 2 <= S; s += 2) {
+            const int64_t i = r * S + s;
+            const float inv0 = 1.0f / (sig[i] + 1e-6f), inv1 = 1.0f / (sig[i + 1] + 1e-6f);
+            const float wa0 = sig_s[i] * inv0, wb0 = sig_d[i] * inv0, wa1 = sig_s[i + 1] * inv1, wb1 = sig_d[i + 1] * inv1;
+            const float fs0 = on ? f_s[i * C + c] : 0.0f, fd0 = on ? f_d[i * C + c] : 0.0f;
+            const float fs1 = on ? f_s[(i + 1) * C + c] : 0.0f, fd1 = on ? f_d[(i + 1) * C + c] : 0.0f;
+            a0 += w[i] * (wa0 * fs0 + wb0 * fd0);
+            a1 += w[i + 1] * (wa1 * fs1 + wb1 * fd1);
+        }
+        if (s < S) {
+            const int64_t i = r * S + s;
+            const float inv = 1.0f / (sig[i] + 1e-6f);
+            const float fs0 = on ? f_s[i * C + c] : 0.0f, fd0 = on ? f_d[i * C + c] : 0.0f;
+            a0 += w[i] * (sig_s[i] * inv * fs0 + sig_d[i] * inv * fd0);
+        }
+        if (on) acc[r * (int64_t)C + c] = a0 + a1;
+    }
+}
+
+__global__ __launch_bounds__(256) void blend_accumulate_wide_bwd_kernel(const float *__restrict__ w, const float *__restrict__ sig,
+                                                                        const float *__restrict__ sig_s, const float *__restrict__ sig_d,
+                                                                        const float *__restrict__ f_s, const float *__restrict__ f_d,
+                                                                        const float *__restrict__ g_acc, int64_t R, int32_t S, int32_t C,
+                                                                        float *__restrict__ d_w, float *__restrict__ d_sig,
+                                                                        float *__restrict__ d_sig_s, float *__restrict__ d_sig_d,
+                                                                        float *__restrict__ d_f_s, float *__restrict__ d_f_d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
+    if (r >= R) return;
+    for (int32_t s = 0; s < S; ++s) {
+        const int64_t i = r * S + s;
+        const float wi = w[i], ss = sig_s[i], sd = sig_d[i], inv = 1.0f / (sig[i] + 1e-6f);
+        const float a = ss * inv, b = sd * inv, wa = wi * a, wb = wi * b;
+        float gS = 0.0f, gD = 0.0f;
+        for (int32_t c = lane; c < C; c += kWave) {
+            const float g = g_acc[r * (int64_t)C + c];
+            const int64_t j = i * C + c;
+            gS += g * f_s[j];
+            gD += g * f_d[j];
+            if (d_f_s) d_f_s[j] = g * wa;
+            if (d_f_d) d_f_d[j] = g * wb;
+        }
+        gS = wave_sum(gS);
+        gD = wave_sum(gD);
+        if (lane == 0) {
+            if (d_w) d_w[i] = a * gS + b * gD;
+            const float da = wi * gS, db = wi * gD;
+            if (d_sig_s) d_sig_s[i] = da * inv;
+            if (d_sig_d) d_sig_d[i] = db * inv;
+            if (d_sig) d_sig[i] = -(da * ss + db * sd) * inv * inv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ [r4]
 // The static model's `rendering` (render_utils.py:73-122,158-159,217-220) as ONE launch each way: weights / transmittance scan,
 // accumulation of the 3-channel colour, and the per-ray epilogue (opacity clamp, expected depth, median depth, sky composite) --
@@ -479,6 +550,30 @@ extern "C" int emer_composite_rgb_bwd(const float *ts, const float *te, const fl
     hipLaunchKernelGGL(composite_rgb_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), ts, te, sigma, rgb,
                        rgb_sky, weights, ray_stats, d_rgb_out, d_opacity, d_depth, d_weights, d_trans, R, S, d_sigma, d_rgb, d_rgb_sky);
     return check_launch("composite_rgb_bwd");
+}
+
+extern "C" int emer_blend_accumulate_wide_fwd(const float *weights, const float *density, const float *static_density, const float *dynamic_density,
+                                             const float *static_feat, const float *dynamic_feat, int64_t R, int32_t S, int32_t C, float *acc,
+                                             void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "blend_accumulate_wide_fwd: bad sizes");
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(weights && density && static_density && dynamic_density && static_feat && dynamic_feat && acc, "blend_accumulate_wide_fwd: null pointer");
+    hipLaunchKernelGGL(blend_accumulate_wide_fwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), weights, density,
+                       static_density, dynamic_density, static_feat, dynamic_feat, R, S, C, acc);
+    return check_launch("blend_accumulate_wide_fwd");
+}
+
+extern "C" int emer_blend_accumulate_wide_bwd(const float *weights, const float *density, const float *static_density, const float *dynamic_density,
+                                             const float *static_feat, const float *dynamic_feat, const float *d_acc, int64_t R, int32_t S, int32_t C,
+                                             float *d_weights, float *d_density, float *d_static_density, float *d_dynamic_density,
+                                             float *d_static_feat, float *d_dynamic_feat, void *stream) {
+    EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "blend_accumulate_wide_bwd: bad sizes");
+    if (R == 0) return EMER_OK;
+    EMER_REQUIRE(weights && density && static_density && dynamic_density && static_feat && dynamic_feat && d_acc, "blend_accumulate_wide_bwd: null pointer");
+    hipLaunchKernelGGL(blend_accumulate_wide_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), weights, density,
+                       static_density, dynamic_density, static_feat, dynamic_feat, d_acc, R, S, C, d_weights, d_density, d_static_density,
+                       d_dynamic_density, d_static_feat, d_dynamic_feat);
+    return check_launch("blend_accumulate_wide_bwd");
 }
 
 extern "C" int emer_render_weights_fwd(const float *ts, const float *te, const float *sigma, int64_t R, int32_t S,

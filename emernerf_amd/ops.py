@@ -1073,6 +1073,50 @@ class _BlendAccumulateFn(torch.autograd.Function):
         return dw, dsg, dss, dsd, drs, drd, (None if dsh is None else dsh.view(ctx.sh_shape))
 
 
+class _BlendAccumulateWideFn(torch.autograd.Function):
+    """acc [R,C] of rendering's decomposed FEATURE path (render_utils.py:247-252), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, weights, density, static_density, dynamic_density, static_feat, dynamic_feat):
+        ctx.set_materialize_grads(False)
+        w, sg, ss, sd = _f32c(weights), _f32c(density).reshape(weights.shape), _f32c(static_density).reshape(weights.shape), \
+            _f32c(dynamic_density).reshape(weights.shape)
+        fs, fd = _f32c(static_feat), _f32c(dynamic_feat)
+        R, S = w.shape
+        C = fs.shape[-1]
+        with torch.cuda.device(w.device):
+            acc = torch.empty((R, C), device=w.device, dtype=torch.float32)
+            _lib.call("emer_blend_accumulate_wide_fwd", _ptr(w), _ptr(sg), _ptr(ss), _ptr(sd), _ptr(fs), _ptr(fd), R, S, C, _ptr(acc), _stream(w))
+        ctx.save_for_backward(w, sg, ss, sd, fs, fd)
+        ctx.shapes = (density.shape, static_density.shape, dynamic_density.shape)
+        return acc
+
+    @staticmethod
+    def backward(ctx, g_acc):
+        if g_acc is None:
+            return (None,) * 6
+        w, sg, ss, sd, fs, fd = ctx.saved_tensors
+        R, S = w.shape
+        C = fs.shape[-1]
+        g = _f32c(g_acc)
+        need = ctx.needs_input_grad
+        with torch.cuda.device(w.device):
+            mk = lambda t, on: torch.empty_like(t) if on else None  # noqa: E731
+            dw, dsg, dss, dsd, dfs, dfd = mk(w, need[0]), mk(sg, need[1]), mk(ss, need[2]), mk(sd, need[3]), mk(fs, need[4]), mk(fd, need[5])
+            _lib.call("emer_blend_accumulate_wide_bwd", _ptr(w), _ptr(sg), _ptr(ss), _ptr(sd), _ptr(fs), _ptr(fd), _ptr(g), R, S, C, _ptr(dw),
+                      _ptr(dsg), _ptr(dss), _ptr(dsd), _ptr(dfs), _ptr(dfd), _stream(w))
+        sh = ctx.shapes
+        rs = lambda t, shape: None if t is None else t.view(shape)  # noqa: E731
+        return dw, rs(dsg, sh[0]), rs(dss, sh[1]), rs(dsd, sh[2]), dfs, dfd
+
+
+def blend_accumulate_wide(weights: Tensor, density: Tensor, static_density: Tensor, dynamic_density: Tensor, static_feat: Tensor,
+                          dynamic_feat: Tensor) -> Tensor:
+    """sum_s w (sigma_s / (sigma + 1e-6) feat_s + sigma_d / (sigma + 1e-6) feat_d) for [R,S,C] features -> [R,C]."""
+    _check_cuda(weights, density, static_density, dynamic_density, static_feat, dynamic_feat)
+    return _BlendAccumulateWideFn.apply(weights, density, static_density, dynamic_density, static_feat, dynamic_feat)
+
+
 def blend_accumulate(weights: Tensor, density: Tensor, static_density: Tensor, dynamic_density: Tensor, static_rgb: Tensor,
                      dynamic_rgb: Tensor, shadow_ratio: Optional[Tensor] = None):
     """sum_s w (sigma_s / (sigma + 1e-6) rgb_s (1 - shadow) + sigma_d / (sigma + 1e-6) rgb_d) and sum_s w shadow^2."""

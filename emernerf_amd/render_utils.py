@@ -121,10 +121,16 @@ def rendering(t_starts: Tensor, t_ends: Tensor, query_fn: Optional[Callable] = N
         results_dict["dino_feat"] = accumulate_along_rays(weights, values=results["dino_feat"])
         _finish_dino()
     elif "static_dino_feat" in results and "dynamic_dino_feat" in results:  # :247-282
-        static_ratio = results["static_density"] / (results["density"] + 1e-6)  # (:131-136; the colour path has them fused)
-        dynamic_ratio = results["dynamic_density"] / (results["density"] + 1e-6)
-        dino_feat = static_ratio[..., None] * results["static_dino_feat"] + dynamic_ratio[..., None] * results["dynamic_dino_feat"]
-        results_dict["dino_feat"] = accumulate_along_rays(weights, values=dino_feat)
+        if weights.is_cuda and results["static_dino_feat"].dim() == 3:
+            # [r4] ratios, blend and accumulation of the C-channel features in one launch each way (:131-136,247-252)
+            results_dict["dino_feat"] = ops.blend_accumulate_wide(weights, results["density"], results["static_density"],
+                                                                  results["dynamic_density"], results["static_dino_feat"],
+                                                                  results["dynamic_dino_feat"])
+        else:
+            static_ratio = results["static_density"] / (results["density"] + 1e-6)
+            dynamic_ratio = results["dynamic_density"] / (results["density"] + 1e-6)
+            dino_feat = static_ratio[..., None] * results["static_dino_feat"] + dynamic_ratio[..., None] * results["dynamic_dino_feat"]
+            results_dict["dino_feat"] = accumulate_along_rays(weights, values=dino_feat)
         _finish_dino()
         if return_decomposition:
             results_dict["static_dino"] = accumulate_along_rays(static_weights, values=results["static_dino_feat"])

@@ -272,6 +272,18 @@ int emer_blend_accumulate_bwd(const float *weights, const float *density, const 
                               int64_t n_rays, int32_t n_samples, float *d_weights, float *d_density,
                               float *d_static_density, float *d_dynamic_density, float *d_static_rgb,
                               float *d_dynamic_rgb, float *d_shadow_ratio, void *stream);
+
+/* [r4] The same blend for the C-channel features of the decomposed feature head (render_utils.py:247-252, `dino_feat`):
+ * acc [R,C] = sum_s w (sigma_s / (sigma + 1e-6) feat_s + sigma_d / (sigma + 1e-6) feat_d); feat_* [R,S,C].  Backward: any output
+ * pointer may be NULL. */
+int emer_blend_accumulate_wide_fwd(const float *weights, const float *density, const float *static_density,
+                                   const float *dynamic_density, const float *static_feat, const float *dynamic_feat,
+                                   int64_t n_rays, int32_t n_samples, int32_t n_channels, float *acc, void *stream);
+int emer_blend_accumulate_wide_bwd(const float *weights, const float *density, const float *static_density,
+                                   const float *dynamic_density, const float *static_feat, const float *dynamic_feat,
+                                   const float *d_acc, int64_t n_rays, int32_t n_samples, int32_t n_channels,
+                                   float *d_weights, float *d_density, float *d_static_density, float *d_dynamic_density,
+                                   float *d_static_feat, float *d_dynamic_feat, void *stream);
 /* Per-ray epilogue of `rendering` (radiance_fields/render_utils.py:102-105,217-226):
  *   opacity = clamp(sum w, 1e-6, 1); depth = (sum w*mid) / opacity; median_depth = ray_stats[:,2];
  *   rgb = acc_rgb + rgb_sky * (1 - opacity)   (rgb_sky NULL: rgb = acc_rgb; rgb NULL: geometry only, lidar rays).

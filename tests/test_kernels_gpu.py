@@ -1016,3 +1016,33 @@ def test_composite_rgb_equals_the_three_kernel_rendering(hip_lib, R, S, with_rgb
     for a, b in zip(res[False][1], res[True][1]):
         scale = a.abs().max().item() + 1e-30
         assert (a - b).abs().max().item() <= 2e-6 * scale, f"gradient differs: {(a - b).abs().max().item():.3e} of {scale:.3e}"
+
+
+@pytest.mark.parametrize("R,S,C", [(257, 128, 64), (33, 50, 100), (2048, 128, 64)])
+def test_blend_accumulate_wide_matches_the_reference_expression(hip_lib, R, S, C):
+    """[r4] emer_blend_accumulate_wide_fwd/bwd against the reference's own expression (render_utils.py:131-136,247-252) in fp64."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    w = torch.rand(R, S, generator=g) / S
+    ss, sd = torch.rand(R, S, 1, generator=g).pow(3) * 5, torch.rand(R, S, 1, generator=g).pow(3) * 5
+    ss[0] = 0.0
+    sd[0] = 0.0   # density 0: ratios 0 / 1e-6
+    fs, fd = torch.randn(R, S, C, generator=g), torch.randn(R, S, C, generator=g)
+    up = torch.randn(R, C, generator=g)
+    leaves = [t.to(dev).requires_grad_(True) for t in (w, ss, sd, fs, fd)]
+    sg = leaves[1] + leaves[2]
+    sg.retain_grad()
+    acc = ops.blend_accumulate_wide(leaves[0], sg, leaves[1], leaves[2], leaves[3], leaves[4])
+    (acc * up.to(dev)).sum().backward()
+    ref = [t.double().requires_grad_(True) for t in (w, ss, sd, fs, fd)]
+    rsg = ref[1] + ref[2]
+    rsg.retain_grad()
+    feat = (ref[1] / (rsg + 1e-6)) * ref[3] + (ref[2] / (rsg + 1e-6)) * ref[4]
+    racc = (ref[0][..., None] * feat).sum(1)
+    (racc * up.double()).sum().backward()
+    np.testing.assert_allclose(acc.detach().cpu().numpy(), racc.detach().numpy(), rtol=0, atol=2e-6 * float(racc.abs().max()))
+    for a, b, name in zip(leaves + [sg], ref + [rsg], ["w", "sigma_s", "sigma_d", "feat_s", "feat_d", "sigma"]):
+        scale = float(b.grad.abs().max()) + 1e-30
+        err = float((a.grad.cpu().double() - b.grad).abs().max())
+        assert err <= 5e-6 * scale, f"d {name}: {err:.3e} of {scale:.3e}"
