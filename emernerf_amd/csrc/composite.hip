@@ -305,22 +305,23 @@ __global__ __launch_bounds__(256) void blend_accumulate_wide_fwd_kernel(const fl
                                                                         const float *__restrict__ sig_s, const float *__restrict__ sig_d,
                                                                         const float *__restrict__ f_s, const float *__restrict__ f_d, int64_t R,
                                                                         int32_t S, int32_t C, float *__restrict__ acc) {
+    // one workgroup per ray: wave k takes the samples k, k + 4, ... (two at a time: two independent chains), the four partial sums meet in LDS
+    __shared__ float part[4][kWave];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
-    if (r >= R) return;
+    const int64_t r = blockIdx.x;
     for (int32_t c0 = 0; c0 < C; c0 += kWave) {
         const int32_t c = c0 + lane;
         const bool on = c < C;
-        float a0 = 0.0f, a1 = 0.0f;   // two independent chains over the samples (loads of s and s + 1 in flight together)
-        int32_t s = 0;
-        for (; s + 2 <= S; s += 2) {
-            const int64_t i = r * S + s;
-            const float inv0 = 1.0f / (sig[i] + 1e-6f), inv1 = 1.0f / (sig[i + 1] + 1e-6f);
-            const float wa0 = sig_s[i] * inv0, wb0 = sig_d[i] * inv0, wa1 = sig_s[i + 1] * inv1, wb1 = sig_d[i + 1] * inv1;
+        float a0 = 0.0f, a1 = 0.0f;
+        int32_t s = wave;
+        for (; s + 4 < S; s += 8) {
+            const int64_t i = r * S + s, i2 = i + 4;
+            const float inv0 = 1.0f / (sig[i] + 1e-6f), inv1 = 1.0f / (sig[i2] + 1e-6f);
+            const float wa0 = sig_s[i] * inv0, wb0 = sig_d[i] * inv0, wa1 = sig_s[i2] * inv1, wb1 = sig_d[i2] * inv1;
             const float fs0 = on ? f_s[i * C + c] : 0.0f, fd0 = on ? f_d[i * C + c] : 0.0f;
-            const float fs1 = on ? f_s[(i + 1) * C + c] : 0.0f, fd1 = on ? f_d[(i + 1) * C + c] : 0.0f;
+            const float fs1 = on ? f_s[i2 * C + c] : 0.0f, fd1 = on ? f_d[i2 * C + c] : 0.0f;
             a0 += w[i] * (wa0 * fs0 + wb0 * fd0);
-            a1 += w[i + 1] * (wa1 * fs1 + wb1 * fd1);
+            a1 += w[i2] * (wa1 * fs1 + wb1 * fd1);
         }
         if (s < S) {
             const int64_t i = r * S + s;
@@ -328,7 +329,10 @@ __global__ __launch_bounds__(256) void blend_accumulate_wide_fwd_kernel(const fl
             const float fs0 = on ? f_s[i * C + c] : 0.0f, fd0 = on ? f_d[i * C + c] : 0.0f;
             a0 += w[i] * (sig_s[i] * inv * fs0 + sig_d[i] * inv * fd0);
         }
-        if (on) acc[r * (int64_t)C + c] = a0 + a1;
+        part[wave][lane] = a0 + a1;
+        __syncthreads();
+        if (wave == 0 && on) acc[r * (int64_t)C + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        __syncthreads();
     }
 }
 
@@ -339,27 +343,52 @@ __global__ __launch_bounds__(256) void blend_accumulate_wide_bwd_kernel(const fl
                                                                         float *__restrict__ d_w, float *__restrict__ d_sig,
                                                                         float *__restrict__ d_sig_s, float *__restrict__ d_sig_d,
                                                                         float *__restrict__ d_f_s, float *__restrict__ d_f_d) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * kRaysPerBlockC + wave;
-    if (r >= R) return;
-    for (int32_t s = 0; s < S; ++s) {
-        const int64_t i = r * S + s;
-        const float wi = w[i], ss = sig_s[i], sd = sig_d[i], inv = 1.0f / (sig[i] + 1e-6f);
-        const float a = ss * inv, b = sd * inv, wa = wi * a, wb = wi * b;
-        float gS = 0.0f, gD = 0.0f;
-        for (int32_t c = lane; c < C; c += kWave) {
-            const float g = g_acc[r * (int64_t)C + c];
-            const int64_t j = i * C + c;
-            gS += g * f_s[j];
-            gD += g * f_d[j];
-            if (d_f_s) d_f_s[j] = g * wa;
-            if (d_f_d) d_f_d[j] = g * wb;
+    // samples are independent in the backward: a wave takes FOUR consecutive samples at a time (flat over (ray, sample); their eight
+    // feature rows are in flight together, the eight dot products reduce interleaved, lanes 0..3 write the per-sample scalars)
+    const int lane = threadIdx.x & 63;
+    const int64_t n = R * (int64_t)S, n_quads = (n + 3) >> 2, n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_quads; q += n_waves) {
+        float gS[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gD[4] = {0.0f, 0.0f, 0.0f, 0.0f}, wa[4], wb[4];
+        int64_t rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = q * 4 + u < n ? q * 4 + u : n - 1;
+            rr[u] = i / S;
+            const float inv = 1.0f / (sig[i] + 1e-6f);
+            wa[u] = w[i] * sig_s[i] * inv;
+            wb[u] = w[i] * sig_d[i] * inv;
         }
-        gS = wave_sum(gS);
-        gD = wave_sum(gD);
-        if (lane == 0) {
-            if (d_w) d_w[i] = a * gS + b * gD;
-            const float da = wi * gS, db = wi * gD;
+        for (int32_t c = lane; c < C; c += kWave) {
+            float fs[4], fd[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = q * 4 + u < n ? q * 4 + u : n - 1;
+                g[u] = g_acc[rr[u] * (int64_t)C + c];
+                fs[u] = f_s[i * C + c];
+                fd[u] = f_d[i * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = q * 4 + u;
+                gS[u] += g[u] * fs[u];
+                gD[u] += g[u] * fd[u];
+                if (i < n) {
+                    if (d_f_s) d_f_s[i * C + c] = g[u] * wa[u];
+                    if (d_f_d) d_f_d[i * C + c] = g[u] * wb[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { gS[u] = wave_sum(gS[u]); gD[u] = wave_sum(gD[u]); }
+        const int u = lane & 3;
+        const int64_t i = q * 4 + u;
+        if (lane < 4 && i < n) {
+            const float mS = u == 0 ? gS[0] : u == 1 ? gS[1] : u == 2 ? gS[2] : gS[3];
+            const float mD = u == 0 ? gD[0] : u == 1 ? gD[1] : u == 2 ? gD[2] : gD[3];
+            const float wi = w[i], ss = sig_s[i], sd = sig_d[i], inv = 1.0f / (sig[i] + 1e-6f);
+            const float a_ = ss * inv, b_ = sd * inv;
+            if (d_w) d_w[i] = a_ * mS + b_ * mD;
+            const float da = wi * mS, db = wi * mD;
             if (d_sig_s) d_sig_s[i] = da * inv;
             if (d_sig_d) d_sig_d[i] = db * inv;
             if (d_sig) d_sig[i] = -(da * ss + db * sd) * inv * inv;
@@ -558,7 +587,7 @@ extern "C" int emer_blend_accumulate_wide_fwd(const float *weights, const float 
     EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "blend_accumulate_wide_fwd: bad sizes");
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(weights && density && static_density && dynamic_density && static_feat && dynamic_feat && acc, "blend_accumulate_wide_fwd: null pointer");
-    hipLaunchKernelGGL(blend_accumulate_wide_fwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), weights, density,
+    hipLaunchKernelGGL(blend_accumulate_wide_fwd_kernel, dim3((uint32_t)R), dim3(256), 0, as_stream(stream), weights, density,
                        static_density, dynamic_density, static_feat, dynamic_feat, R, S, C, acc);
     return check_launch("blend_accumulate_wide_fwd");
 }
@@ -570,7 +599,8 @@ extern "C" int emer_blend_accumulate_wide_bwd(const float *weights, const float 
     EMER_REQUIRE(R >= 0 && S >= 1 && C >= 1, "blend_accumulate_wide_bwd: bad sizes");
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(weights && density && static_density && dynamic_density && static_feat && dynamic_feat && d_acc, "blend_accumulate_wide_bwd: null pointer");
-    hipLaunchKernelGGL(blend_accumulate_wide_bwd_kernel, dim3((uint32_t)ceil_div(R, kRaysPerBlockC)), dim3(256), 0, as_stream(stream), weights, density,
+    const int64_t wg = ceil_div(R * (int64_t)S, 4 * 8);   // ~two quads of samples per wave
+    hipLaunchKernelGGL(blend_accumulate_wide_bwd_kernel, dim3((uint32_t)(wg > 16384 ? 16384 : wg)), dim3(256), 0, as_stream(stream), weights, density,
                        static_density, dynamic_density, static_feat, dynamic_feat, d_acc, R, S, C, d_weights, d_density, d_static_density,
                        d_dynamic_density, d_static_feat, d_dynamic_feat);
     return check_launch("blend_accumulate_wide_bwd");
