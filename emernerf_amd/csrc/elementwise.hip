@@ -207,19 +207,67 @@ __global__ __launch_bounds__(256) void dir_encode_kernel(const float *__restrict
 }
 
 // torch.optim.Adam (weight_decay as L2, no amsgrad) on a flat buffer; builders.py:50-60.
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float gscale, float bc1, float bc2_sqrt) {
+__global__ __launch_bounds__(256) void adam_scalar_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                          float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                          float wd, float gscale, float bc1, float bc2_sqrt) {
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i] * gscale;
         const float pi = p[i];
         if (wd != 0.0f) gi = gi + wd * pi;
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);   // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;  // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         m[i] = mi; v[i] = vi;
         p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+__device__ __forceinline__ void adam_one(float &pi, float gi, float &mi, float &vi, float lr_step, float b1, float b2, float eps, float wd,
+                                         float gscale, float bc2_sqrt) {
+    gi = gi * gscale;
+    if (wd != 0.0f) gi = gi + wd * pi;
+    mi = mi + (gi - mi) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * b2 + (1.0f - b2) * gi * gi;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - lr_step * (mi / denom);
+}
+// [r4] 16 bytes per lane and array (the four arrays are views at the SAME offset of equally aligned buffers: one scalar head of
+// `head` < 4 elements aligns them all), two vectors per thread and trip: three tables of a flow model (970 MB) 252 -> see DESIGN 5.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, int32_t head, float lr, float b1, float b2, float eps,
+                                                   float wd, float gscale, float bc1, float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+    const int64_t n4 = (n - head) >> 2;   // whole vectors behind the head
+    float4 *p4 = reinterpret_cast<float4 *>(p + head), *m4 = reinterpret_cast<float4 *>(m + head), *v4 = reinterpret_cast<float4 *>(v + head);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g + head);
+    for (int64_t i = tid; i < n4; i += 2 * nthreads) {
+        const int64_t j = i + nthreads;
+        const bool two = j < n4;
+        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        float4 pb = pa, gb = ga, mb = ma, vb = va;
+        if (two) { pb = p4[j]; gb = g4[j]; mb = m4[j]; vb = v4[j]; }
+        adam_one(pa.x, ga.x, ma.x, va.x, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+        adam_one(pa.y, ga.y, ma.y, va.y, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+        adam_one(pa.z, ga.z, ma.z, va.z, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+        adam_one(pa.w, ga.w, ma.w, va.w, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+        m4[i] = ma; v4[i] = va; p4[i] = pa;
+        if (two) {
+            adam_one(pb.x, gb.x, mb.x, vb.x, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+            adam_one(pb.y, gb.y, mb.y, vb.y, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+            adam_one(pb.z, gb.z, mb.z, vb.z, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+            adam_one(pb.w, gb.w, mb.w, vb.w, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+            m4[j] = mb; v4[j] = vb; p4[j] = pb;
+        }
+    }
+    // the (< 4)-element head and the (< 4)-element tail
+    const int64_t tail0 = head + 4 * n4;
+    if (tid < head + (n - tail0)) {
+        const int64_t i = tid < head ? tid : tail0 + (tid - head);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_one(pi, g[i], mi, vi, step_size, b1, b2, eps, wd, gscale, bc2_sqrt);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 
@@ -371,8 +419,18 @@ extern "C" int emer_adam_step(float *params, const float *grads, float *exp_avg,
     if (n == 0) return EMER_OK;
     EMER_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: null pointer");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
-                       lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
+    // the vector body needs all four arrays 16-byte aligned behind a common scalar head; otherwise everything is "head / tail" (scalar)
+    const uintptr_t mis = (uintptr_t)params & 15u;
+    const bool same = (((uintptr_t)grads & 15u) == mis) && (((uintptr_t)exp_avg & 15u) == mis) && (((uintptr_t)exp_avg_sq & 15u) == mis) && (mis & 3u) == 0;
+    if (!same) {   // (never the case for the trainer's flat buffers) one element per thread
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(stream_blocks(n)), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
+                           lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
+        return check_launch("adam_step");
+    }
+    int64_t head = mis ? (int64_t)((16u - mis) >> 2) : 0;
+    if (head > n) head = n;
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks((n + 7) / 8 + 8)), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
+                       (int32_t)head, lr, beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)sqrt(bc2));
     return check_launch("adam_step");
 }
 

