@@ -623,6 +623,185 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         store_slice_bitmaps<Q>(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
 }
 
+// ------------------------------------------------------------------------ proposal round, no gradient [r4]
+// One launch for sigma_fn of a proposal network outside autograd recording (5 steps in 6, and evaluation): sample position
+// (render_utils.py:316-318,341: o + d (t0 + t1) / 2, scene contraction) -> L-level encoding -> 8..16 -> 64 -> 1 MLP -> exp(. - 1)
+// (radiance_field.py:808-812,836-840).  thread = sample, ALL levels: measured (tools/prop_probe.py) the per-sample gather of all
+// levels costs what the level-major forward costs on these small tables (52 vs 58 us, 94 vs 90 us at 1 M samples), so nothing is lost
+// by giving up the level-major blocks, and the positions ([N,3]), the encoding ([L][N][F]) and a 20-us MLP launch never exist.
+// The encoding is computed exactly as hashgrid_fwd_kernel does (same branches, same order); the MLP is a plain fmaf chain on the
+// vector pipe with the weights as scalar operands (641 floats: uniform loads), hidden under the gathers of the other waves.
+__device__ __forceinline__ void ray_point_contracted(const float *__restrict__ aabb, bool unbounded, const float *__restrict__ o,
+                                                     const float *__restrict__ d, float tsum, float (&v)[3]) {
+#pragma clang fp contract(off)   // bit-exact with emer_ray_points (csrc/elementwise.hip is compiled with contraction off)
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = o[k] + d[k] * tsum / 2.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = (p[k] - aabb[k]) / (aabb[3 + k] - aabb[k]);
+    if (unbounded) {
+        float mag = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[k] = v[k] * 2.0f - 1.0f; mag = fmaxf(mag, fabsf(v[k])); }
+        if (!(mag < 1.0f)) {
+            const float sc = 2.0f - 1.0f / mag;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = sc * (v[k] / mag);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] / 4.0f + 0.5f;
+    }
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) inside = inside && (v[k] > 0.0f) && (v[k] < 1.0f);
+    if (!inside) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] * 0.0f;
+    }
+}
+
+// one level of the D = 3 encoding of one sample: the arithmetic of hashgrid_fwd_kernel<3, F, float, ., false> (paired gathers on hashed
+// power-of-two levels, generic corner loop elsewhere)
+template <int F>
+__device__ __forceinline__ void encode_level_d3(const LevelInfo &li, const float *__restrict__ table, const float (&xv)[3], float (&acc)[F]) {
+    constexpr int D = 3;
+    float w[D];
+    uint32_t gi[D];
+    cell_of<D>(li, xv, gi, w);
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+    const bool pow2 = (li.size & (li.size - 1u)) == 0u;
+    if (F <= 2 && li.hashed && pow2) {
+        const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
+        const uint32_t maskv = li.size - 1u;
+        const bool x_even = (gi[0] & 1u) == 0u;
+#pragma unroll
+        for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+            uint32_t h = 0;
+            float t[D];
+#pragma unroll
+            for (int d = 1; d < D; ++d) {
+                const uint32_t bit = (m >> (d - 1)) & 1u;
+                h ^= (gi[d] + bit) * primes[d];
+                t[d] = bit ? w[d] : 1.0f - w[d];
+            }
+            const uint32_t idx0 = (gi[0] ^ h) & maskv, idx1 = ((gi[0] + 1u) ^ h) & maskv;
+            float v0[F], v1[F];
+            if (x_even) {
+                float e[2 * F];
+                load_feats<2 * F, float>(table + (size_t)(idx0 & ~1u) * F, e);
+#pragma unroll
+                for (int f = 0; f < F; ++f) { v0[f] = (idx0 & 1u) ? e[F + f] : e[f]; v1[f] = (idx0 & 1u) ? e[f] : e[F + f]; }
+            } else {
+                load_feats<F, float>(table + (size_t)idx0 * F, v0);
+                load_feats<F, float>(table + (size_t)idx1 * F, v1);
+            }
+            float wa = 1.0f - w[0], wb = w[0];
+#pragma unroll
+            for (int d = 1; d < D; ++d) { wa *= t[d]; wb *= t[d]; }
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += wa * v0[f];
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t m = 0; m < (1u << D); ++m) {
+            float wt = 1.0f;
+            uint32_t c[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
+                else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
+            }
+            float v[F];
+            load_feats<F, float>(table + (size_t)grid_index<D>(li, c) * F, v);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += wt * v[f];
+        }
+    }
+}
+
+// MLP part: the arithmetic of density_fwd_kernel (csrc/mlp_fused.hip) -- v_mfma_f32_16x16x4_f32 with W0 as the A operand held in
+// registers, the bias as the initial accumulator, relu, the 64-term dot product with w1 as an fmaf chain per lane and two xor shuffles --
+// so the density is BITWISE what emer_neck_fwd(n_out = 1) returns for the same encoding.  The encodings of a wave's 64 samples change
+// layout (lane = sample -> lane (m, g) = feature 4 s + g of row 16 j + m) through a wave-private LDS tile: no barrier.
+template <int F>
+__global__ __launch_bounds__(256) void prop_density_fwd_kernel(const emer_grid_desc g, const float *__restrict__ params,
+                                                               const float *__restrict__ origins, const float *__restrict__ dirs,
+                                                               const float *__restrict__ ts, const float *__restrict__ te,
+                                                               const float *__restrict__ aabb, int unbounded, const float *__restrict__ w0,
+                                                               const float *__restrict__ b0, const float *__restrict__ w1,
+                                                               const float *__restrict__ b1, int64_t R, int32_t S, float *__restrict__ dens) {
+    constexpr int LMAX = 8, K0P = LMAX * F, KS4 = K0P / 4, PITCH = 80;   // (levels past n_levels contribute zero features with zero weights)
+    using f32x4m = __attribute__((ext_vector_type(4))) float;
+    __shared__ float tile[4][K0P][PITCH];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, gq = lane >> 4;
+    const int32_t K0 = (int32_t)g.n_levels * F;
+    float aw[4][KS4];
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+        const int32_t k = 4 * s + gq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) aw[p][s] = k < K0 ? w0[(int64_t)(16 * p + m) * K0 + k] : 0.0f;
+    }
+    f32x4m b0r[4], w1r[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b0r[p][i] = b0 ? b0[16 * p + 4 * gq + i] : 0.0f;
+            w1r[p][i] = w1[16 * p + 4 * gq + i];
+        }
+    const float b1v = b1 ? b1[0] : 0.0f;
+    const int64_t N = R * (int64_t)S, n_chunks = (N + 63) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < n_chunks; c += n_waves) {
+        const int64_t n = c * 64 + lane;
+        const int64_t nc = n < N ? n : N - 1;   // (clamped: every lane computes, rows past the end are not stored)
+        const int64_t r = nc / S;
+        float xv[3];
+        ray_point_contracted(aabb, unbounded != 0, origins + r * 3, dirs + r * 3, ts[nc] + te[nc], xv);
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            float acc[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+            if (l < (int)g.n_levels) {
+                const LevelInfo li = level_info(g, (uint32_t)l);
+                encode_level_d3<F>(li, params + (size_t)li.offset * F, xv, acc);
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) tile[wave][l * F + f][lane] = acc[f];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private tile: no barrier)
+        float x[4][KS4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < KS4; ++s) x[j][s] = tile[wave][4 * s + gq][16 * j + m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4m h[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) h[p] = b0r[p];
+#pragma unroll
+            for (int s = 0; s < KS4; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) h[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[p][s], x[j][s], h[p], 0, 0, 0);
+            float dot = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dot = fmaf(w1r[p][i], fmaxf(h[p][i], 0.0f), dot);
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            const int64_t row = c * 64 + 16 * j + m;
+            if (gq == 0 && row < N) dens[row] = expf(dot + b1v - 1.0f);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile has been read before the next chunk overwrites it
+    }
+}
+
 // ------------------------------------------------------------------------ backward (params)
 template <int D, int F, typename GT>
 __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_grid_desc g, const float *__restrict__ x,
@@ -1761,6 +1940,33 @@ extern "C" int emer_hashgrid_bwd_input_jac(const emer_grid_desc *g, const float 
                            g->n_levels);
         return check_launch("hashgrid_bwd_input_jac");
     });
+}
+
+extern "C" int emer_prop_density_supported(const emer_grid_desc *g, int32_t hidden, int32_t n_out) {
+    if (check_desc(g) != EMER_OK) return 0;
+    // (F = 1: up to 8 levels -- two 16-byte pieces of a weight row; F = 2: up to 8 levels = 16 inputs)
+    return (g->n_dims == 3 && (g->n_features == 1 || g->n_features == 2) && g->n_levels <= 8 && hidden == 64 && n_out == 1) ? 1 : 0;
+}
+
+// density [R * S] of a proposal network for the samples (t_starts, t_ends) [R, S] of the rays (origins, dirs) [R, 3], outside autograd:
+// emer_ray_points -> emer_hashgrid_fwd -> emer_neck_fwd(n_out = 1) in one launch.  w0 [64][L * F] row-major, b0 [64], w1 [64], b1 [1].
+extern "C" int emer_prop_density_fwd(const emer_grid_desc *g, const float *params, const float *origins, const float *dirs, const float *t_starts,
+                                     const float *t_ends, const float *aabb, int unbounded, const float *w0, const float *b0, const float *w1,
+                                     const float *b1, int64_t n_rays, int32_t n_samples, float *density, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    EMER_REQUIRE(n_rays >= 0 && n_samples >= 1, "prop_density_fwd: bad sizes");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(emer_prop_density_supported(g, 64, 1), "prop_density_fwd: needs a D3 grid with F in {1, 2} and at most 8 levels");
+    EMER_REQUIRE(params && origins && dirs && t_starts && t_ends && aabb && w0 && w1 && density, "prop_density_fwd: null pointer");
+    int64_t blocks64 = ceil_div(n_rays * (int64_t)n_samples, 256 * 4);   // ~four 64-sample chunks per wave (the MLP weights are loaded once per wave)
+    const uint32_t blocks = (uint32_t)(blocks64 < 1 ? 1 : blocks64);
+    if (g->n_features == 1)
+        hipLaunchKernelGGL(prop_density_fwd_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), *g, params, origins, dirs, t_starts, t_ends, aabb,
+                           unbounded, w0, b0, w1, b1, n_rays, n_samples, density);
+    else
+        hipLaunchKernelGGL(prop_density_fwd_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream), *g, params, origins, dirs, t_starts, t_ends, aabb,
+                           unbounded, w0, b0, w1, b1, n_rays, n_samples, density);
+    return check_launch("prop_density_fwd");
 }
 
 extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,

@@ -162,6 +162,9 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         return {k: chunk[k][..., None].expand(*chunk[k].shape, n_samples) for k in keys if k in chunk}
 
     def prop_sigma_fn(t_starts, t_ends, proposal_network: DensityField):
+        fused_density = proposal_network.density_from_rays(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends)
+        if fused_density is not None:   # outside autograd recording: positions, encoding and MLP in one launch
+            return {"density": fused_density}
         normed, _ = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
                                    proposal_network.aabb, proposal_network.unbounded)
         return {"density": proposal_network.density_from_normed(normed)}

@@ -141,6 +141,18 @@ int emer_hashgrid_fwd_jac(const emer_grid_desc *host_desc, const float *x, const
 int emer_hashgrid_bwd_input_jac(const emer_grid_desc *host_desc, const float *jac, const float *dout,
                                 int64_t dout_stride_n, int64_t dout_stride_l, float *dx, int64_t n_rows, void *stream);
 
+/* [r4] sigma_fn of a proposal network OUTSIDE autograd recording (the proposal sampling of the steps that do not train the proposal nets,
+ * evaluation) as one launch: emer_ray_points (positions o + d (t0 + t1) / 2, contraction: render_utils.py:316-318,341) ->
+ * emer_hashgrid_fwd -> the DensityField MLP L*F -> 64 -> 1 and exp(. - 1) (radiance_field.py:808-812,836-840).  Positions and encoding
+ * are bitwise those of the separate calls; the MLP is an fmaf chain (differs from emer_neck_fwd's matrix-core order by fp32 rounding).
+ * w0 [64][L * F] row-major, b0 [64] (may be NULL), w1 [64], b1 [1] (may be NULL); density [n_rays * n_samples].
+ * emer_prop_density_supported: 1 for D = 3, F in {1, 2}, at most 8 levels, hidden 64, one output. */
+int emer_prop_density_supported(const emer_grid_desc *host_desc, int32_t hidden, int32_t n_out);
+int emer_prop_density_fwd(const emer_grid_desc *host_desc, const float *params, const float *origins, const float *dirs,
+                          const float *t_starts, const float *t_ends, const float *aabb, int unbounded, const float *w0,
+                          const float *b0, const float *w1, const float *b1, int64_t n_rays, int32_t n_samples,
+                          float *density, void *stream);
+
 /* Layout glue: level-major [L][N][F] <-> row-major [N, L*F] (the layout tcnn_modules.py:263 returns).
  * to_row_major != 0: src is level-major, dst row-major; 0: the reverse.  src != dst. */
 int emer_layout_transpose(const float *src, float *dst, int32_t n_levels, int64_t n,
