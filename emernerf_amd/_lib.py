@@ -109,6 +109,8 @@ SIGNATURES = {
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],
     "emer_aggregate3_fwd": [_P, c_int64, _P, _P],
     "emer_aggregate3_bwd": [_P, c_int64, _P, _P],
+    "emer_aggregate3_density_fwd": [_P, c_int64, c_int32, _P, _P, _P],
+    "emer_aggregate3_density_bwd": [_P, _P, _P, c_int64, c_int32, _P, _P],
     "emer_ray_inputs_fwd": [_P, c_int64, _P, c_int64, _P, c_int32, c_int32, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
     "emer_embed_grad": [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P],
     "emer_ray_pre_fwd": [_P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P],

@@ -334,6 +334,36 @@ __global__ __launch_bounds__(256) void aggregate3_fwd_kernel(const float4 *__res
         out[i] = r;
     }
 }
+// [r4] ... with the density read off column 0 of the aggregated features in the same launch (radiance_field.py:461: trunc_exp(f[..., 0] - 1)
+// = exp(f - 1); its backward g * exp(min(f - 1, 15)) joins column 0 of the incoming gradient instead of travelling as a second, mostly zero
+// [N, C] tensor that autograd has to add: the separate path cost a zero fill, a strided store and a 67 MB add per flow step).
+// c4 = float4 groups per row; dens / d_dens [rows].
+__global__ __launch_bounds__(256) void aggregate3_density_fwd_kernel(const float4 *__restrict__ x, int64_t n4, int32_t c4, float4 *__restrict__ out,
+                                                                     float *__restrict__ dens) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = x[i], b = x[n4 + i], c = x[2 * n4 + i];
+        float4 r;
+        r.x = ((a.x + 0.5f * b.x) + 0.5f * c.x) / 2.0f;
+        r.y = ((a.y + 0.5f * b.y) + 0.5f * c.y) / 2.0f;
+        r.z = ((a.z + 0.5f * b.z) + 0.5f * c.z) / 2.0f;
+        r.w = ((a.w + 0.5f * b.w) + 0.5f * c.w) / 2.0f;
+        out[i] = r;
+        if (i % c4 == 0) dens[i / c4] = expf(r.x - 1.0f);
+    }
+}
+__global__ __launch_bounds__(256) void aggregate3_density_bwd_kernel(const float4 *__restrict__ g, const float *__restrict__ d_dens,
+                                                                     const float *__restrict__ dens, int64_t n4, int32_t c4,
+                                                                     float4 *__restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = g ? g[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (d_dens && i % c4 == 0) v.x = v.x + d_dens[i / c4] * fminf(dens[i / c4], 3269017.3724721107f);  // g * exp(min(x - 1, 15))
+        const float4 h = {v.x / 2.0f, v.y / 2.0f, v.z / 2.0f, v.w / 2.0f};
+        const float4 q = {0.5f * h.x, 0.5f * h.y, 0.5f * h.z, 0.5f * h.w};
+        dx[i] = h;
+        dx[n4 + i] = q;
+        dx[2 * n4 + i] = q;
+    }
+}
 __global__ __launch_bounds__(256) void aggregate3_bwd_kernel(const float4 *__restrict__ g, int64_t n4, float4 *__restrict__ dx) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = g[i];
@@ -502,6 +532,27 @@ extern "C" int emer_aggregate3_fwd(const float *x3, int64_t n, float *out, void 
     hipLaunchKernelGGL(aggregate3_fwd_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(x3), n / 4,
                        reinterpret_cast<float4 *>(out));
     return check_launch("aggregate3_fwd");
+}
+
+extern "C" int emer_aggregate3_density_fwd(const float *x3, int64_t n_rows, int32_t n_cols, float *out, float *density, void *stream) {
+    EMER_REQUIRE(n_rows >= 0 && n_cols >= 4 && n_cols % 4 == 0, "aggregate3_density_fwd: the row width must be a multiple of 4");
+    if (n_rows == 0) return EMER_OK;
+    EMER_REQUIRE(x3 && out && density && (uintptr_t)x3 % 16 == 0 && (uintptr_t)out % 16 == 0, "aggregate3_density_fwd: null or unaligned pointer");
+    const int64_t n4 = n_rows * (n_cols / 4);
+    hipLaunchKernelGGL(aggregate3_density_fwd_kernel, dim3(stream_blocks(n4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(x3), n4,
+                       n_cols / 4, reinterpret_cast<float4 *>(out), density);
+    return check_launch("aggregate3_density_fwd");
+}
+
+extern "C" int emer_aggregate3_density_bwd(const float *g, const float *d_density, const float *density, int64_t n_rows, int32_t n_cols, float *dx3,
+                                           void *stream) {
+    EMER_REQUIRE(n_rows >= 0 && n_cols >= 4 && n_cols % 4 == 0, "aggregate3_density_bwd: the row width must be a multiple of 4");
+    if (n_rows == 0) return EMER_OK;
+    EMER_REQUIRE(dx3 && (!d_density || density) && (!g || (uintptr_t)g % 16 == 0) && (uintptr_t)dx3 % 16 == 0, "aggregate3_density_bwd: null or unaligned pointer");
+    const int64_t n4 = n_rows * (n_cols / 4);
+    hipLaunchKernelGGL(aggregate3_density_bwd_kernel, dim3(stream_blocks(n4)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4 *>(g),
+                       d_density, density, n4, n_cols / 4, reinterpret_cast<float4 *>(dx3));
+    return check_launch("aggregate3_density_bwd");
 }
 
 extern "C" int emer_aggregate3_bwd(const float *g, int64_t n, float *dx3, void *stream) {

@@ -1036,6 +1036,43 @@ def aggregate3(x3: Tensor) -> Tensor:
     return _Aggregate3Fn.apply(x3)
 
 
+class _Aggregate3DensityFn(torch.autograd.Function):
+    """[r4] (aggregated features [N, C], density [N] = trunc_exp(features[:, 0] - 1)) of a [3 N, C] batch, one launch each way: the
+    density's gradient joins column 0 inside the backward kernel (bitwise the sum autograd would form from the separate trunc_exp)."""
+
+    @staticmethod
+    def forward(ctx, x3: Tensor):
+        ctx.set_materialize_grads(False)
+        x = _f32c(x3)
+        n3, C = x.shape
+        assert n3 % 3 == 0 and C % 4 == 0
+        with torch.cuda.device(x.device):
+            out = torch.empty((n3 // 3, C), device=x.device, dtype=torch.float32)
+            dens = torch.empty((n3 // 3,), device=x.device, dtype=torch.float32)
+            _lib.call("emer_aggregate3_density_fwd", _ptr(x), n3 // 3, C, _ptr(out), _ptr(dens), _stream(x))
+        ctx.save_for_backward(dens)
+        ctx.C = C
+        return out, dens
+
+    @staticmethod
+    def backward(ctx, g, gd):
+        (dens,) = ctx.saved_tensors
+        if g is None and gd is None:
+            return None
+        gc = None if g is None else _f32c(g)
+        gdc = None if gd is None else _f32c(gd).reshape(-1)
+        n = dens.shape[0]
+        with torch.cuda.device(dens.device):
+            dx = torch.empty((3 * n, ctx.C), device=dens.device, dtype=torch.float32)
+            _lib.call("emer_aggregate3_density_bwd", _ptr(gc), _ptr(gdc), _ptr(dens), n, ctx.C, _ptr(dx), _stream(dens))
+        return dx
+
+
+def aggregate3_density(x3: Tensor):
+    _check_cuda(x3)
+    return _Aggregate3DensityFn.apply(x3)
+
+
 def dir_encode(dirs: Tensor, max_deg: int = 4, remap: bool = True) -> Tensor:
     """SinusoidalEncoder(3, 0, max_deg); remap=True applies (dirs+1)/2 first (radiance_field.py:629; no grad)."""
     _check_cuda(dirs)

@@ -491,8 +491,11 @@ class RadianceField(nn.Module):
         # temporal aggregation (:595-613) per feature half, straight from the 3N-row batch: one launch each way, no [., 128]
         # concatenation and no 3N-row cat in the backward
         agg_ok = (N * 64) % 4 == 0
+        dyn_density = None
         if agg_ok:
-            dyn = ops.aggregate3(geo3).view(*lead, -1)
+            # [r4] the density (trunc_exp of the aggregated geometry features' column 0, :461) comes out of the same launch
+            dyn, dyn_density = ops.aggregate3_density(geo3)
+            dyn, dyn_density = dyn.view(*lead, -1), dyn_density.view(*lead)
             if sem3 is not None:
                 dyn = (dyn, ops.aggregate3(sem3).view(*lead, -1))  # forward() takes the pair as (geometry, semantic) features
         else:
@@ -503,7 +506,7 @@ class RadianceField(nn.Module):
         flow2 = fused.seq_mlp_lm(enc_f.forward_level_major(x2), fw, fb)
         fwd_pred, bwd_pred = (t.view(*lead, 6) for t in flow2.split(N, dim=0))
         out = {"forward_flow": forward_flow, "backward_flow": backward_flow,
-               "dynamic_feats": dyn,
+               "dynamic_feats": dyn, "_dynamic_density": dyn_density,
                "forward_pred_backward_flow": fwd_pred[..., 3:], "backward_pred_forward_flow": bwd_pred[..., :3]}
         if want_hash:  # row-major copies of the encodings: part of forward()'s contract (:453-459, 615-617), consumed by nobody
             cur_h, fwd_h, bwd_h = (t.view(*lead, -1) for t in ops.lm_to_rm(enc3).split(N, dim=0))
@@ -676,13 +679,15 @@ class RadianceField(nn.Module):
                 if (use_flow and BATCH_XYZT and not interp) else None
             if batched is not None:
                 dynamic_feats = batched["dynamic_feats"]
+                fused_density = batched.pop("_dynamic_density")
                 results_dict.update(batched)
                 if isinstance(dynamic_feats, tuple):  # (geometry, semantic) halves kept apart: the reference's tensor on request only
                     if hash_encodings:
                         results_dict["dynamic_feats"] = torch.cat(dynamic_feats, dim=-1)
                     else:
                         del results_dict["dynamic_feats"]
-                dynamic_density = ops.trunc_exp_column(dynamic_feats[0] if isinstance(dynamic_feats, tuple) else dynamic_feats, 0)
+                dynamic_density = fused_density if fused_density is not None else \
+                    ops.trunc_exp_column(dynamic_feats[0] if isinstance(dynamic_feats, tuple) else dynamic_feats, 0)
             else:
                 dynamic_feats, dynamic_hash_encodings, dynamic_density = self._dynamic(
                     normed_positions, normed_timestamps, want_density=not use_flow, want_hash=use_flow)
@@ -698,6 +703,9 @@ class RadianceField(nn.Module):
                 dynamic_density = ops.trunc_exp_column(dynamic_feats, 0)
             if isinstance(dynamic_feats, tuple):
                 dynamic_geo_feats, dynamic_semantic_feats = dynamic_feats
+            elif self.semantic_feature_dim == 0:
+                # (torch.split(x, [64, 0]) is a view forward and a full-size cat backward -- 31 us per flow step for an empty half)
+                dynamic_geo_feats, dynamic_semantic_feats = dynamic_feats, dynamic_feats[..., self.geometry_feature_dim:]
             else:
                 dynamic_geo_feats, dynamic_semantic_feats = torch.split(
                     dynamic_feats, [self.geometry_feature_dim, self.semantic_feature_dim], dim=-1)

@@ -575,6 +575,12 @@ int emer_trunc_exp_bwd(const float *dy, const float *y, float *dx, int64_t dx_st
  *   fwd: out[i] = (x3[i] + 0.5 x3[n + i] + 0.5 x3[2 n + i]) / 2          bwd: dx3 = [g / 2 | g / 4 | g / 4]. */
 int emer_aggregate3_fwd(const float *x3, int64_t n, float *out, void *stream);
 int emer_aggregate3_bwd(const float *g, int64_t n, float *dx3, void *stream);
+/* [r4] The same with the density activation of the aggregated features' column 0 in the launch (radiance_field.py:461,595-613):
+ * x3 [3 n_rows, n_cols] (n_cols % 4 == 0), out [n_rows, n_cols], density [n_rows] = exp(out[:, 0] - 1); the backward adds
+ * d_density * exp(min(out[:, 0] - 1, 15)) to column 0 of g (either gradient may be NULL) before the split into thirds. */
+int emer_aggregate3_density_fwd(const float *x3, int64_t n_rows, int32_t n_cols, float *out, float *density, void *stream);
+int emer_aggregate3_density_bwd(const float *g, const float *d_density, const float *density, int64_t n_rows,
+                                int32_t n_cols, float *dx3, void *stream);
 
 /* Direction encoding used by the rgb / sky heads: d -> (d+1)/2 -> [x, sin(2^i x), sin(2^i x + pi/2)]
  * i = 0..max_deg (radiance_fields/encodings.py:60-104, radiance_field.py:629-632).
