@@ -185,6 +185,86 @@ def test_data_parallel_flat_allreduce_gloo():
         assert len(ret) == world and all(v < 1e-6 for v in ret.values()), dict(ret)
 
 
+class _FakeEncoding(torch.nn.Module):
+    """A parameter named like a hash table (``...tcnn_encoding.params``): FlatParams files it under the tables."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.tcnn_encoding = torch.nn.Module()
+        self.tcnn_encoding.params = torch.nn.Parameter(torch.zeros(n))
+
+
+def _exchange_worker(rank, world, port, ret, dp_mode, early, table_cut, prop_grad):
+    """The trainer's OWN exchange code (Trainer._exchange_grads / _launch_table_bucket / _launch_early_bucket / _launch_prop_bucket) on a
+    CPU flat buffer over gloo: whatever subset of the buckets was started early, every gradient of the step ends up summed exactly once."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import types
+    from emernerf_amd import trainer as T
+    enc = _FakeEncoding(4096)
+    mlp = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    xyzt = _FakeEncoding(1024)
+    head = torch.nn.Linear(3, 2)
+    prop = torch.nn.Sequential(_FakeEncoding(512), torch.nn.Linear(4, 1))
+    flat = T.FlatParams({"main": [enc, mlp, xyzt, head], "prop": [prop]}, "cpu", align=4 * world)
+    g = torch.Generator().manual_seed(7 + rank)
+    flat.grads.copy_(torch.randn(flat.numel, generator=g))
+    for p in flat._tables:
+        p._emer_grad_fresh = False   # every table "was written" this step
+    mine = flat.grads.clone()
+    tr = types.SimpleNamespace(flat=flat, world_size=world, dp_mode=dp_mode, dp_debug=False, comm_events=None, _dp_on=True, _hold_buckets=False,
+                               _rs_emulate=True, _early_done=False, _early_work=[], _prop_work=None, _table_work=[], _table_ranges=[],
+                               _table_snapshots=[], model=types.SimpleNamespace(xyz_encoder=enc))
+    a, b = flat.ranges["main"]
+    tr._early_ranges = [(lo, hi) for lo, hi in flat._dense_ranges if a <= lo and hi <= b]
+    for name in ("_exchange_grads", "_launch_table_bucket", "_launch_whole_table_bucket", "_launch_early_bucket", "_launch_prop_bucket"):
+        setattr(tr, name, types.MethodType(getattr(T.Trainer, name), tr))
+    orig_cap = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: False   # (CPU build of the test: no stream to ask)
+    T.fused.join_side_stream = lambda: None
+    try:
+        if prop_grad:
+            tr._launch_prop_bucket()
+        if early and dp_mode == "allreduce":
+            tr._launch_whole_table_bucket(xyzt.tcnn_encoding.params)         # an xyzt table, from its own last backward
+            tr._launch_early_bucket()                                        # the MLP ranges, when the static table's backward starts
+            if table_cut:
+                tr._launch_table_bucket(enc.tcnn_encoding.params, table_cut, 4096)   # the fine levels, between the two launches
+        tr._exchange_grads(prop_grad)
+    finally:
+        torch.cuda.is_current_stream_capturing = orig_cap
+    # reference: the plain sum over ranks
+    total = mine.clone()
+    dist.all_reduce(total)
+    pa, pb = flat.ranges["prop"]
+    if dp_mode == "rs_ag":   # every rank holds the sum of ITS shard of each exchanged group
+        err = 0.0
+        for grp, (lo, hi) in tr._rs_shards.items():
+            err = max(err, float((flat.grads[lo:hi] - total[lo:hi]).abs().max()))
+        assert set(tr._rs_shards) == ({"main", "prop"} if prop_grad else {"main"})
+    else:
+        err = float((flat.grads[a:b] - total[a:b]).abs().max())
+        if prop_grad:
+            err = max(err, float((flat.grads[pa:pb] - total[pa:pb]).abs().max()))
+        else:   # the idle proposal net's range is not exchanged
+            assert torch.equal(flat.grads[pa:pb], mine[pa:pb])
+    assert tr._early_work == [] and tr._table_work == [] and tr._table_ranges == [] and tr._prop_work is None
+    ret[rank] = err
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dp_mode,early,table_cut,prop_grad", [("allreduce", False, 0, False), ("allreduce", True, 0, False),
+                                                                ("allreduce", True, 3000, False), ("allreduce", True, 3000, True),
+                                                                ("rs_ag", False, 0, True), ("rs_ag", False, 0, False)])
+def test_trainer_exchange_code_over_gloo(dp_mode, early, table_cut, prop_grad):
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_exchange_worker, args=(world, port, ret, dp_mode, early, table_cut, prop_grad), nprocs=world, join=True)
+        assert len(ret) == world and all(v < 1e-6 for v in ret.values()), dict(ret)
+
+
 @pytest.mark.parametrize("grid,rows", [((3, 16, 16, 2048, 19, 2), 64),     # BASELINE configs[1] main grid: 64 slices per hashed level
                                        ((3, 10, 16, 8192, 20, 4), 256),    # default static grid: 256 LDS slices -> 256 bitmap rows
                                        ((4, 10, 32, 8192, 18, 4), 64),     # dynamic / flow xyzt grids
