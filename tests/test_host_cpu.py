@@ -185,6 +185,28 @@ def test_data_parallel_flat_allreduce_gloo():
         assert len(ret) == world and all(v < 1e-6 for v in ret.values()), dict(ret)
 
 
+def test_subtract_ranges_partitions_the_span():
+    """trainer._subtract_ranges: what is left of the exchange span after the ranges whose collectives started early -- together with those
+    ranges it must cover every element of the span exactly once (random spans / holes, including holes that stick out or touch)."""
+    sys.path.insert(0, ROOT)
+    from emernerf_amd.trainer import _subtract_ranges
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a = int(rng.integers(0, 50)); b = a + int(rng.integers(1, 200))
+        cuts = sorted(set(int(v) for v in rng.integers(a - 20, b + 20, size=int(rng.integers(0, 9)))))
+        holes = [(cuts[i], cuts[i + 1]) for i in range(0, len(cuts) - 1, 2)]   # disjoint, sorted, possibly outside [a, b)
+        rng.shuffle(holes)
+        late = _subtract_ranges((a, b), holes)
+        count = np.zeros(b - a + 60, dtype=np.int64)
+        for lo, hi in late:
+            assert a <= lo < hi <= b
+            count[lo - a + 30:hi - a + 30] += 1
+        for lo, hi in holes:
+            count[max(lo, a) - a + 30:max(min(hi, b), a) - a + 30] += 1
+        assert (count[30:30 + b - a] == 1).all() and count[:30].sum() == 0 and count[30 + b - a:].sum() == 0
+    assert _subtract_ranges((0, 10), []) == [(0, 10)] and _subtract_ranges((0, 10), [(0, 10)]) == []
+
+
 class _FakeEncoding(torch.nn.Module):
     """A parameter named like a hash table (``...tcnn_encoding.params``): FlatParams files it under the tables."""
 
