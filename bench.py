@@ -154,8 +154,6 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     from emernerf_amd.trainer import Trainer, synthetic_rays
     tr = Trainer(kind=kind, device=dev, num_samples=samples, world_size=1, use_graph=use_graph)
     tr.set_step(start_step)
-    for s_ in range(start_step):
-        tr.requires_grad_fn(s_)
     kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
     batches = [synthetic_rays(rays, dev, seed=3000 + i, **kw) for i in range(4)]
     for i in range(init_steps + warmup):
@@ -288,11 +286,7 @@ def main():
 
     trainer = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=world, table_init=args.table_init,
                       use_graph=args.graph, table_dtype=args.table_dtype)
-    trainer.set_step(args.start_step)
-    # advance the proposal schedule to its state at start_step
-    fn = trainer.requires_grad_fn
-    for s in range(args.start_step):
-        fn(s)
+    trainer.set_step(args.start_step)   # (also replays the proposal schedule to its state at start_step)
     # each rank its own rays (weak scaling), and a NEW batch every step: N_BATCHES seeded batches resident in HBM, rotated
     feat_kw = dict(num_cams=3, feature_dim=64) if args.kind == "feature" else {}
     batches = [synthetic_rays(args.rays, dev, seed=1000 + 64 * rank + i, **feat_kw) for i in range(N_BATCHES)]
@@ -447,8 +441,6 @@ def main():
     if rank == 0 and args.table_init is None and not args.no_second_state:
         t2 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_init=0.3)
         t2.set_step(args.start_step)
-        for s_ in range(args.start_step):
-            t2.requires_grad_fn(s_)
         for _ in range(18):
             t2.train_step(next_batch())
         clustered = _lib.KernelTimer(grid_names)
@@ -477,8 +469,6 @@ def main():
     if rank == 0 and world == 1 and args.table_dtype == "f32" and args.kind == "static" and not args.no_fp16_state:
         t3 = Trainer(kind=args.kind, device=dev, num_samples=args.samples, world_size=1, table_dtype="f16")
         t3.set_step(args.start_step)
-        for s_ in range(args.start_step):
-            t3.requires_grad_fn(s_)
         for _ in range(18):
             t3.train_step(next_batch())
         fp16_timer = _lib.KernelTimer(grid_names)

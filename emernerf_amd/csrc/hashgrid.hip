@@ -232,12 +232,27 @@ struct SlicePlan {
     uint32_t order[EMER_MAX_LEVELS];     // backward: levels in the order an XCD's list walks them (heaviest items first)
     uint32_t items_per_xcd[8];           // backward work items ((level, slice, range) triples) on each XCD's list
     uint32_t total_items;
+    uint32_t sched_shift;                // log2 of the scheduling block: consecutive work items dealt to one XCD
 };
 
 #ifndef EMER_SLICE_THREADS
 #define EMER_SLICE_THREADS 1024   // owner workgroup: 1024 lanes with a 128 KiB slice (one per CU), or -- r4 experiment, see DESIGN 4.1 -- 512 lanes
 #endif                            // with a 64 KiB slice (two per CU: 128 slices per hashed level, 256-row bitmaps)
 constexpr uint32_t kSchedBlock = EMER_SLICE_THREADS == 1024 ? 32 : 64;  // consecutive work items dealt to one XCD (= its resident owners: one round)
+// [r5] Grids WITHOUT dense levels (the xyzt tables: 10 hashed levels x 64 slices = 640 items of 300-450 us for 256 owners) have no
+// small items to fill the tail with: tools/trace_sliced.py showed four XCDs working three rounds and four XCDs two -- 1041 us of work
+// per owner in a 1400 us kernel.  For such grids (a) the levels at the END of the order, whose items make up the last, incomplete
+// round, are cut in EMER_TAIL_SPLIT sample ranges (merged with atomics like the dense levels: half-size items fill the round), and
+// (b) EMER_SCHED_BLOCK_NOFILL = 16 / 8 deals the items to the XCDs in smaller blocks, so that every XCD's list holds a part of MORE
+// levels and the lists' totals even out -- measured and LOST: a level's x / dout lines are then fetched into four L2s instead of two
+// (xyzt table at 1 M samples, same session: 1390 us before; wide pairs 1165; + tail split 2, blocks of 32: 1000; blocks of 16: 1090,
+// of 8: 1120; tail split 4 with blocks of 16: 1025; profiles/r05_grid_schedule.txt).  Default 32 = no change.
+#ifndef EMER_TAIL_SPLIT
+#define EMER_TAIL_SPLIT 2
+#endif
+#ifndef EMER_SCHED_BLOCK_NOFILL
+#define EMER_SCHED_BLOCK_NOFILL 32
+#endif
 static float level_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) {
     // fitted to tools/kbench.py --per-level on MI355X (1M samples, ms on one XCD): coarse levels pay for
     // same-address LDS adds (many samples per cell), dense levels for the ordered scan + run reduction
@@ -300,6 +315,27 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         if (local > max_entries) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
     }
+    // [r5] tail filler for grids without dense levels (see EMER_TAIL_SPLIT above): the levels sorted last by item cost (the finest ones
+    // under the model below) until they cover the items of the incomplete last round
+    p.sched_shift = kSchedBlock == 32u ? 5u : 6u;
+    {
+        uint32_t n_dense = 0, items = 0;
+        for (uint32_t l = 0; l < g->n_levels; ++l) { n_dense += g->hashed[l] ? 0u : 1u; items += p.n_slices[l]; }
+        const uint32_t owners = EMER_SLICE_THREADS == 1024 ? 256u : 512u;
+        const uint32_t rem = items % owners;
+        if (n_dense == 0u && items > owners && EMER_SLICE_THREADS == 1024) {
+            if (EMER_SCHED_BLOCK_NOFILL == 16) p.sched_shift = 4u;
+            else if (EMER_SCHED_BLOCK_NOFILL == 8) p.sched_shift = 3u;
+            if (rem != 0u && EMER_TAIL_SPLIT > 1) {
+                // finest levels first (they sort last: lowest modelled item cost)
+                uint32_t covered = 0;
+                for (uint32_t l = g->n_levels; l-- > 0u && covered < rem;) {
+                    p.n_ranges[l] = (uint32_t)EMER_TAIL_SPLIT;
+                    covered += p.n_slices[l];
+                }
+            }
+        }
+    }
     // Bitmap rows.  The forward emits 64 rows per level, or 256 when some level has more slices (T = 2^20 with F = 4:
     // 256 slices): every slice then still has its OWN bitmap.  (Round 1 / first half of round 2 shared one 64-row bitmap
     // among 2^gsub neighbouring slices, whose owners each scanned -- gathered, hashed and mostly discarded -- the hits of
@@ -323,9 +359,10 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     for (uint32_t l = 0; l < g->n_levels; ++l) total_items += p.n_slices[l] * p.n_ranges[l];
     p.total_items = total_items;
     for (int i = 0; i < 8; ++i) p.items_per_xcd[i] = 0;
-    for (uint32_t blk = 0; blk * kSchedBlock < total_items; ++blk) {
-        const uint32_t left = total_items - blk * kSchedBlock;
-        p.items_per_xcd[blk & 7u] += left < kSchedBlock ? left : kSchedBlock;
+    const uint32_t sched_block = 1u << p.sched_shift;
+    for (uint32_t blk = 0; blk * sched_block < total_items; ++blk) {
+        const uint32_t left = total_items - blk * sched_block;
+        p.items_per_xcd[blk & 7u] += left < sched_block ? left : sched_block;
     }
     for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) p.xcd_of[l] = 0;  // (unused: kept for layout stability of the argument struct)
     // the global order: levels with the most expensive single items first
@@ -1020,10 +1057,16 @@ __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
 }
 // the same with the last three levels replaced by one LDS byte look-up: lut[byte * 8 + k] = position of the k-th set bit
 // of `byte` (2 KiB per workgroup, filled once): 21 VALU instead of 42 per 64 hits in the hottest loop of the backward
+// 0: never, 1: always, 2: three-dimensional grids only.  History: round 2 measured the plain VALU select 1 % faster (the vector pipes
+// were ~40 % busy then, the extra LDS round trip on the hit -> sample chain cost more than 21 instructions); since the run-reduced adds
+// the kernel is vector-issue bound (SQ_ACTIVE_INST_VALU ~70 % of the SIMD cycles, profiles/r04a_grid_counters.json) and the look-up
+// wins on the D = 3 grids -- [r5] same-session A/B: main grid 535 -> 516 us, default static 663 -> 655, proposal grids 252 -> 246 --
+// while the D4 / F4 xyzt tables, whose LDS is the busier unit, lose 0.6 %.
 #ifndef EMER_SELECT_LUT
-#define EMER_SELECT_LUT 0  // r2: the plain VALU select is 1 % faster now (one LDS round trip less on the hit -> sample chain; the vector pipes are ~40 % busy)
+#define EMER_SELECT_LUT 2
 #endif
-constexpr uint32_t kSelectLutBytes = EMER_SELECT_LUT ? 2048u : 0u;
+template <int D> constexpr bool use_select_lut() { return EMER_SELECT_LUT == 1 || (EMER_SELECT_LUT == 2 && D == 3); }
+template <int D> constexpr uint32_t select_lut_bytes() { return use_select_lut<D>() ? 2048u : 0u; }
 __device__ __forceinline__ uint32_t select64_lut(uint64_t w, uint32_t k, const uint8_t *lut) {
     uint32_t x = (uint32_t)w, base = 0, c = (uint32_t)__popc((uint32_t)w);
     if (k >= c) { k -= c; x = (uint32_t)(w >> 32); base = 32; }
@@ -1200,6 +1243,9 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
 #ifndef EMER_PIPELINE
 #define EMER_PIPELINE 1
 #endif
+#ifndef EMER_WIDE_PAIRS
+#define EMER_WIDE_PAIRS 1
+#endif
 // Timing-only ablation builds (tools/ab_grid.sh; results are WRONG, never in the product library): bit 0 = gathers from a
 // 16 K-sample window (L2 hits), bit 1 = gathers from a 1 K-sample window (L1 hits), bit 2 = plain LDS stores instead of
 // ds_add_f64, bit 3 = no LDS accumulation at all, bit 4 = hit -> sample mapping without the compaction look-ups.
@@ -1245,9 +1291,10 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // workgroup whose own list is exhausted steals from the other XCDs' lists, which absorbs whatever the static cost
     // model got wrong for the actual sample distribution.  Placement only affects speed, never results.
     const uint32_t my_xcd = blockIdx.x & 7u;
-#if EMER_SELECT_LUT
     // byte-select table behind everything else in the LDS: lut[b * 8 + k] = index of the k-th set bit of b (0 if none)
-    uint8_t *sel_lut = reinterpret_cast<uint8_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
+    uint8_t *sel_lut = nullptr;
+    if constexpr (use_select_lut<D>()) {
+    sel_lut = reinterpret_cast<uint8_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
                        + (size_t)kSliceWaves * kPairQueue * sizeof(uint32_t);
     for (uint32_t e = threadIdx.x; e < 2048u; e += kSliceThreads) {
         uint32_t b = e >> 3, k = e & 7u, pos = 0;
@@ -1256,7 +1303,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
         sel_lut[e] = (uint8_t)pos;
     }
     __syncthreads();
-#endif
+    }
   for (;;) {
     if (threadIdx.x == 0) {
         uint32_t it = 0xFFFFFFFFu;
@@ -1275,7 +1322,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     const uint32_t xcd = item >> 24;
     // local index on the XCD's list -> global item index (blocks of kSchedBlock dealt round-robin) -> (level, slice, range)
     uint32_t j = item & 0xFFFFFFu;
-    j = ((j / kSchedBlock) * 8u + xcd) * kSchedBlock + (j % kSchedBlock);
+    j = ((((j >> plan.sched_shift) << 3) + xcd) << plan.sched_shift) + (j & ((1u << plan.sched_shift) - 1u));
 #if EMER_PACE
     const uint32_t gj = j;   // global item index: block gj / kSchedBlock is one round of one XCD's CUs
     uint32_t lvl_base = 0;   // global index of the level's first item
@@ -1296,7 +1343,11 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     unsigned long long trace_hits = 0;
 #endif
     const bool dense_rt = !li.hashed;
-    const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && li.res < (1u << plan.shift[level]);
+    // [r5] EMER_WIDE_PAIRS: levels whose resolution reaches the slice width (the xyzt tables' res 4424 / 8192 against 4096-entry slices)
+    // are pairable too -- the x-neighbours still share a slice unless x sits at the last position of a slice-wide block, a 1-in-4096
+    // event handled like the out-of-range wrap (wave-uniform fallback to the per-corner path).  Before, those levels took the per-corner
+    // path for EVERY hit: 680 us per work item against 450 us for the level below them (tools/trace_sliced.py).
+    const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && (EMER_WIDE_PAIRS || li.res < (1u << plan.shift[level]));
     const bool run_reduced = pairable_rt && EMER_DPP_SCANS && F >= 2 && li.res <= (uint32_t)EMER_RUN_RES;  // coarse hashed level: runs of equal cells are summed before the LDS
     const bool consecutive = dense_rt || run_reduced || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
@@ -1470,11 +1521,9 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             const uint32_t rank = hx + (uint32_t)__popcll(hr & upto) - 1u;
             const uint64_t wq = Wl[rank];
             const uint32_t el = El[rank];
-#if EMER_SELECT_LUT
-            const uint32_t bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
-#else
-            const uint32_t bit = select64(wq, j - (el & 0xFFFFu));
-#endif
+            uint32_t bit;
+            if constexpr (use_select_lut<D>()) bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
+            else bit = select64(wq, j - (el & 0xFFFFu));
             n = ((trip_w0 + (uint32_t)wave_word0 + ((el >> 16) << lane_word_shift)) << 6) + bit;  // (32-bit: n < 2^28)
 #if EMER_SKIP_DEAD
             }
@@ -1587,7 +1636,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
                     }
                 }
-            } else if (pairable && !__ballot(valid && gi[0] >= li.res)) {
+            } else if (pairable && !__ballot(valid && (gi[0] >= li.res || (EMER_WIDE_PAIRS && (gi[0] & local_mask) == local_mask)))) {
                 // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
                 // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
                 // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
@@ -1599,7 +1648,8 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 // lanes, instead of running a second, 95 % masked, pair body after every chunk.
                 uint32_t hd[D][2];
                 hash_terms<D>(gi, hd);
-                uint32_t match = valid ? pair_matches<D>(hd, slice_want, slice_bits) : 0u;
+                // (the x index reaches into the slice bits when the resolution exceeds the slice width: it joins the test)
+                uint32_t match = valid ? pair_matches<D>(hd, EMER_WIDE_PAIRS ? slice_want ^ (gi[0] & slice_bits) : slice_want, slice_bits) : 0u;
 #if EMER_ABL & (1 | 2 | 16)
                 match = valid ? 1u : 0u;
 #endif
@@ -2097,9 +2147,10 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
         }
         plan.total_items = left_items;
         for (int i = 0; i < 8; ++i) plan.items_per_xcd[i] = 0;
-        for (uint32_t blk = 0; blk * kSchedBlock < left_items; ++blk) {
-            const uint32_t left = left_items - blk * kSchedBlock;
-            plan.items_per_xcd[blk & 7u] += left < kSchedBlock ? left : kSchedBlock;
+        const uint32_t sched_block = 1u << plan.sched_shift;
+        for (uint32_t blk = 0; blk * sched_block < left_items; ++blk) {
+            const uint32_t left = left_items - blk * sched_block;
+            plan.items_per_xcd[blk & 7u] += left < sched_block ? left : sched_block;
         }
     }
     uint32_t total_items = 0;
@@ -2126,10 +2177,11 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
     uint32_t n_blocks = EMER_SLICE_THREADS == 1024 ? 256 : 512;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
-    const size_t lds = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * (kScanWords * sizeof(uint64_t) + kPairQueue * sizeof(uint32_t)) + kSelectLutBytes;
+    const size_t lds_base = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * (kScanWords * sizeof(uint64_t) + kPairQueue * sizeof(uint32_t));
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
         constexpr int D = decltype(d)::value, FF = decltype(f)::value;
         auto kern = hashgrid_bwd_params_sliced_kernel<D, FF>;
+        const size_t lds = lds_base + select_lut_bytes<D>();
         if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
         const ProfileEvents ev = take_profile_events();
         EMER_LAUNCH_PROFILED(ev, kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,

@@ -104,6 +104,14 @@ def hashgrid_fwd_raw(desc: GridDesc, x: Tensor, params: Tensor, level_major: boo
 # [r4] input gradient of a grid encoding (the flow configs: warped positions) from the Jacobians the forward stores instead of a second
 # gather pass over the table (emer_hashgrid_bwd_input): -0.4 ms per flow step at 2048 rays.  EMER_GRID_JAC=0: the gather pass.
 GRID_JAC = os.environ.get("EMER_GRID_JAC", "1") != "0"
+# The Jacobian is L * F * D * 4 bytes per row that needs dx (640 B for the D4/L10/F4 xyzt tables), held from the forward to the backward
+# (under capture: in the graph's pool).  Evaluations whose Jacobian would exceed this budget take the gather pass instead, so a ray batch
+# that fitted before the Jacobian path existed still fits.  EMER_GRID_JAC_MAX_MB=0: no limit.
+GRID_JAC_MAX_BYTES = int(float(os.environ.get("EMER_GRID_JAC_MAX_MB", "4096")) * (1 << 20))
+
+
+def _jac_fits(desc, rows: int) -> bool:
+    return GRID_JAC_MAX_BYTES <= 0 or rows * desc.n_levels * desc.n_features * desc.n_dims * 4 <= GRID_JAC_MAX_BYTES
 
 
 def prop_density_supported(desc: GridDesc, hidden: int, n_out: int) -> bool:
@@ -324,7 +332,7 @@ class _HashGridLMFn(torch.autograd.Function):
         ctx.sliced = bool(ctx.needs_input_grad[1] and gdt == torch.float32 and sliced_supported(desc))
         k = min(int(skip_dx_rows), xc.shape[0])
         jac = None
-        if GRID_JAC and ctx.needs_input_grad[0] and pc.dtype == torch.float32 and k < xc.shape[0]:
+        if GRID_JAC and ctx.needs_input_grad[0] and pc.dtype == torch.float32 and k < xc.shape[0] and _jac_fits(desc, xc.shape[0] - k):
             res = hashgrid_fwd_raw(desc, xc, pc, level_major=True, want_masks=ctx.sliced, jac_row0=k)
             lm, masks, jac = res if ctx.sliced else (res[0], None, res[1])
         elif ctx.sliced:
@@ -361,7 +369,9 @@ class _HashGridLMFn(torch.autograd.Function):
                     param = ctx.param
                     direct = param is not None and getattr(param, "_emer_grad_fresh", False) and param.grad is not None
                     grad = param.grad.view(-1) if direct else torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
-                    split = getattr(ctx.param_obj, "_emer_table_split", None) if direct else None
+                    # (the cut is taken only by the table's LAST backward of the step: an earlier one would start the collective of a range
+                    # that a later backward of the same table still adds to)
+                    split = getattr(ctx.param_obj, "_emer_table_split", None) if (direct and last) else None
                     if split is not None and 0 < split[0] < L:
                         # data-parallel trainer: the levels [k, L) first, then ITS hook (the collective of that contiguous range of the
                         # table starts on the communication stream), then the levels [0, k) while it runs

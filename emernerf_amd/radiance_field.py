@@ -242,6 +242,7 @@ class RadianceField(nn.Module):
                 self.learnable_pe_map = nn.Parameter(0.05 * torch.randn(1, feature_embedding_dim // 2, 80, 120), requires_grad=True)
                 self.pe_head = nn.Sequential(nn.Linear(feature_embedding_dim // 2, feature_embedding_dim))
         self.time_diff = 0
+        self._time_diff_src, self._time_diff_f = None, 0.0
 
     # ------------------------------------------------------------------ bookkeeping (:219-276)
     def register_normalized_training_timesteps(self, normalized_timesteps: Tensor, time_diff: float = None) -> None:
@@ -254,6 +255,10 @@ class RadianceField(nn.Module):
                 self.time_diff = self.training_timesteps[1] - self.training_timesteps[0]
             else:
                 self.time_diff = 0
+            # ``time_diff`` stays what the reference makes it (a 0-dim tensor on the default route); the one-launch flow warp takes the
+            # same fp32 value as a kernel argument, read back ONCE here -- outside any graph capture -- so that the default registration
+            # takes the fused path too
+            self._time_diff_src, self._time_diff_f = self.time_diff, float(self.time_diff)
 
     def set_aabb(self, aabb: Union[Tensor, List[float]]) -> None:
         if not isinstance(aabb, Tensor):
@@ -469,13 +474,19 @@ class RadianceField(nn.Module):
         forward_flow, backward_flow = flow[..., :3], flow[..., 3:]
         # (2) warped positions and times (:567-580)
         noise = self._noise(forward_flow)
-        fused_warp = (FUSE_FLOW_WARP and self.num_dims == 3 and not isinstance(self.time_diff, Tensor) and not positions.requires_grad
+        if isinstance(self.time_diff, Tensor):
+            if self.time_diff is not self._time_diff_src:   # assigned directly after the registration: one host read, once
+                self._time_diff_src, self._time_diff_f = self.time_diff, float(self.time_diff)
+            td = self._time_diff_f
+        else:
+            td = float(self.time_diff)
+        fused_warp = (FUSE_FLOW_WARP and self.num_dims == 3 and not positions.requires_grad
                       and not x_cur.requires_grad and not noise.requires_grad and flow.is_contiguous())
         if fused_warp:
             # [r4] one launch for both warps, both clamps and the batch assembly (and one for their gradient w.r.t. the flow), instead
             # of 14 elementwise / cat launches and ~18 autograd twins; the flow table's 2N-row batch is a second output, so the two
             # tables' input gradients arrive as two tensors (no pad / copy / add)
-            x3, x2 = ops.flow_warp(positions, normed_positions, ts, flow, noise, float(self.time_diff), self.aabb, self.unbounded)
+            x3, x2 = ops.flow_warp(positions, normed_positions, ts, flow, noise, td, self.aabb, self.unbounded)
         else:
             fwd_pos = self.contract_points(positions + forward_flow * noise)
             bwd_pos = self.contract_points(positions + backward_flow * noise)

@@ -326,20 +326,44 @@ class Trainer:
     def set_step(self, step: int, ticks_per_iter: int = 1) -> None:
         """Fast-forward (or restore on resume) the iteration counter AND the LR-schedule ticks that go with it:
         ``ticks_per_iter`` = 2 when every iteration also takes a lidar step (train_emernerf.py:745,826), else 1.  The proposal
-        schedule keeps its own ``since_last`` state."""
+        schedule's ``since_last`` counter depends on its whole history, so it is replayed from step 0 (``ticks_per_iter`` calls per
+        step, as ``train_step`` / ``lidar_step`` make them): after ``set_step(k)`` the trainer is in the state k iterations leave."""
         self.step_count = int(step)
         self.sched_ticks = int(step) * int(ticks_per_iter)
+        sched = self.requires_grad_fn
+        fresh = type(sched)(sched.target, sched.num_steps)
+        for s_ in range(int(step)):
+            for _ in range(int(ticks_per_iter)):
+                fresh(s_)
+        sched.since_last = fresh.since_last
 
     def state_dict(self) -> Dict[str, object]:
-        """Optimizer-side state of this rank (parameters live in the modules' own state_dicts)."""
-        return {"m": self.m, "v": self.v, "opt_steps": dict(self.opt_steps), "step_count": self.step_count,
-                "sched_ticks": self.sched_ticks, "since_last": self.requires_grad_fn.since_last}
+        """Optimizer-side state of this rank (parameters live in the modules' own state_dicts): a SNAPSHOT -- the moments are cloned,
+        so a dictionary held across further steps does not change -- together with the layout of the flat buffer it belongs to
+        (group ranges incl. the rs_ag padding, world size, exchange mode), the loss scale and the length of the LR schedule."""
+        return {"m": self.m.clone(), "v": self.v.clone(), "opt_steps": dict(self.opt_steps), "step_count": self.step_count,
+                "sched_ticks": self.sched_ticks, "since_last": self.requires_grad_fn.since_last,
+                "ranges": {k: tuple(v) for k, v in self.flat.ranges.items()}, "world_size": self.world_size, "dp_mode": self.dp_mode,
+                "loss_scale": self.loss_scale, "num_iters": self.num_iters}
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
+        """Restore ``state_dict()``.  The moments are indexed by flat-buffer offset, so the saved layout must be this trainer's
+        (same model kind, same rs_ag padding = same world size in that mode); dictionaries of rounds before the layout was recorded
+        are accepted when the buffer length matches."""
+        if "ranges" in sd:
+            mine = {k: tuple(v) for k, v in self.flat.ranges.items()}
+            theirs = {k: tuple(v) for k, v in sd["ranges"].items()}
+            if mine != theirs:
+                raise ValueError(f"optimizer state was saved for flat-buffer ranges {theirs} (world_size {sd.get('world_size')}, "
+                                 f"dp_mode {sd.get('dp_mode')}); this trainer has {mine} (world_size {self.world_size}, dp_mode {self.dp_mode})")
+        if tuple(sd["m"].shape) != tuple(self.m.shape) or tuple(sd["v"].shape) != tuple(self.v.shape):
+            raise ValueError(f"optimizer moments of {tuple(sd['m'].shape)} elements do not fit a flat buffer of {tuple(self.m.shape)}")
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.opt_steps = dict(sd["opt_steps"])
         self.step_count, self.sched_ticks = int(sd["step_count"]), int(sd["sched_ticks"])
         self.requires_grad_fn.since_last = int(sd["since_last"])
+        self.loss_scale = float(sd.get("loss_scale", self.loss_scale))
+        self.num_iters = int(sd.get("num_iters", self.num_iters))
 
     def _with_regularisers(self, base: Tensor, results, data, grad_scale: float = 1.0) -> Tensor:
         """``base`` + the regularisers of the dynamic / flow / feature models (``base`` itself for the static model): dynamic-density
@@ -595,6 +619,11 @@ class Trainer:
             except FloatingPointError:  # EMER_CHECK_FINITE=1: a replayed step saw a non-finite gradient -- not a capture problem
                 raise
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, once
+                if self._dp_on:
+                    # A rank that switched to eager launches on its own would issue the early / table / xyzt buckets while its peers,
+                    # still replaying graphs, issue one all-reduce over the whole range: mismatched collectives hang or corrupt the
+                    # gradients.  With more than one rank a capture failure is therefore an error, not a fallback.
+                    raise RuntimeError("hipGraph capture failed on a data-parallel rank; run every rank with use_graph=False") from e
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({e!r}); continuing with eager launches")
                 self.use_graph = False

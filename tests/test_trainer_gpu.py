@@ -70,8 +70,6 @@ def test_graph_step_survives_a_render_with_another_ray_count(hip_lib):
     other = synthetic_rays(100, torch.device("cuda:0"), seed=9)
     for tr in (eager, graph):
         tr.set_step(1000)
-        for s in range(1000):
-            tr.requires_grad_fn(s)
     jit100 = torch.full((100,), 0.37, device="cuda:0")
     jit512 = torch.full((512,), 0.37, device="cuda:0")
     for tr in (eager, graph):
@@ -250,3 +248,108 @@ def test_batched_xyzt_evaluations_equal_call_by_call(hip_lib, monkeypatch, kind)
     (la, ga), (lb, gb) = grads
     assert abs(la - lb) <= 1e-5 * abs(lb)
     assert float((ga - gb).abs().max()) <= 2e-4 * float(gb.abs().max())
+
+
+def test_table_split_is_taken_by_the_last_backward_only(hip_lib):
+    """The level cut of the data-parallel exchange (``_emer_table_split``) hands a range of the table's gradient to a collective while
+    the rest is still being computed, so it may only be taken by a backward after which nothing writes that range again: the table's
+    LAST backward of the step, writing the table's buffer directly.  One evaluation per step: the cut is taken and the range is final
+    when the hook runs.  Two evaluations (warped positions, chunked training): the first backward to run is not the last one and the
+    last one ADDS to what the first wrote -- no cut, the whole table goes with the late bucket."""
+    from emernerf_amd import fused, ops
+    from emernerf_amd.tcnn_modules import Encoding
+    dev = torch.device("cuda:0")
+    enc = Encoding(3, dict(otype="HashGrid", n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                           per_level_scale=1.3819)).to(dev)
+    desc, tab = enc.desc, enc.params
+    with torch.no_grad():
+        tab.copy_(torch.rand_like(tab) - 0.5)
+    assert ops.sliced_supported(desc)
+    k = ops.sliced_split_level(desc)
+    assert 0 < k < desc.n_levels
+    g = torch.Generator().manual_seed(1)
+    xa, xb = torch.rand(4096, 3, generator=g).to(dev), torch.rand(2048, 3, generator=g).to(dev)
+    da, db = torch.randn(16, 4096, 2, generator=g).to(dev), torch.randn(16, 2048, 2, generator=g).to(dev)
+
+    def run(with_hooks, two):
+        tab.grad = torch.full_like(tab, float("nan"))   # the first backward of a step overwrites (no zero fill)
+        tab._emer_grad_fresh, tab._emer_pending_evals = True, 0
+        seen = []
+        if with_hooks:
+            tab._emer_before_table_grad = lambda: seen.append(("before",))
+            tab._emer_table_split = (k, lambda p, lo, hi: seen.append(("split", tab.grad.view(-1)[lo:hi].clone(), lo, hi)))
+        else:
+            tab._emer_before_table_grad = tab._emer_table_split = None
+        with fused.grad_sinks(True):
+            loss = (ops.hashgrid_encode_lm(xa, tab, desc) * da).sum()
+            if two:
+                loss = loss + (ops.hashgrid_encode_lm(xb, tab, desc) * db).sum()
+            loss.backward()
+        torch.cuda.synchronize()
+        return tab.grad.detach().clone().view(-1), seen
+    try:
+        for two in (False, True):
+            ref, _ = run(False, two)
+            got, seen = run(True, two)
+            assert torch.isfinite(ref).all()
+            assert float((ref - got).abs().max()) <= 1e-6 * float(ref.abs().max())
+            kinds = [s[0] for s in seen]
+            if two:
+                assert kinds == ["before"], f"two evaluations: no level cut, one 'last backward' callback: {kinds}"
+            else:
+                assert kinds == ["before", "split"], f"one evaluation: both hooks, once each: {kinds}"
+                _, at_hook, lo, hi = seen[1]
+                assert (lo, hi) == (int(desc.offset[k]) * 2, tab.numel())
+                assert float((at_hook - got[lo:hi]).abs().max()) == 0.0, "the level range was written after its collective would have started"
+    finally:
+        tab._emer_before_table_grad = tab._emer_table_split = None
+
+
+def test_default_timestep_registration_takes_the_fused_warp(hip_lib):
+    """``register_normalized_training_timesteps`` without ``time_diff`` leaves a 0-dim tensor (the reference's default route); the
+    one-launch flow warp must be taken on that route too, with the same value as an explicit float."""
+    from emernerf_amd import ops
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = torch.device("cuda:0")
+    tr = Trainer(kind="flow", device=dev, num_samples=16, prop_samples=(16, 8), table_init=0.3, seed=4)
+    data = synthetic_rays(64, dev, seed=2)
+    tr.model.register_normalized_training_timesteps(torch.linspace(0, 1, tr.cfg.num_train_timesteps))
+    assert isinstance(tr.model.time_diff, torch.Tensor)
+    calls, orig = [], ops.flow_warp
+
+    def spy(*a, **kw):
+        calls.append(a[5])
+        return orig(*a, **kw)
+    ops.flow_warp = spy
+    try:
+        tr.train_step(data)
+    finally:
+        ops.flow_warp = orig
+    assert calls and all(isinstance(c, float) for c in calls), "the default registration must take the one-launch warp"
+    assert abs(calls[0] - float(tr.model.time_diff)) == 0.0
+
+
+def test_trainer_state_dict_is_a_snapshot_and_checks_the_layout(hip_lib):
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = torch.device("cuda:0")
+    tr = Trainer(kind="static", device=dev, num_samples=16, prop_samples=(16, 8), table_init=0.3, seed=5)
+    data = synthetic_rays(64, dev, seed=3)
+    tr.train_step(data)
+    sd = tr.state_dict()
+    m0 = sd["m"].clone()
+    tr.train_step(data)
+    assert torch.equal(sd["m"], m0), "state_dict must not alias the live moments"
+    tr2 = Trainer(kind="static", device=dev, num_samples=16, prop_samples=(16, 8), table_init=0.3, seed=5)
+    tr2.load_state_dict(sd)
+    assert torch.equal(tr2.m, m0) and tr2.step_count == 1 and tr2.loss_scale == tr.loss_scale and tr2.num_iters == tr.num_iters
+    bad = dict(sd)
+    bad["ranges"] = {k: (a, b + 4) for k, (a, b) in sd["ranges"].items()}
+    with pytest.raises(ValueError):
+        tr2.load_state_dict(bad)
+    # set_step replays the proposal schedule: the state k iterations leave behind
+    tr3 = Trainer(kind="static", device=dev, num_samples=16, prop_samples=(16, 8), seed=5)
+    fresh = type(tr3.requires_grad_fn)(tr3.requires_grad_fn.target, tr3.requires_grad_fn.num_steps)
+    for s in range(1234):
+        fresh(s)
+    tr3.set_step(1234)
+    assert tr3.requires_grad_fn.since_last == fresh.since_last and tr3.step_count == 1234

@@ -8,8 +8,6 @@ from emernerf_amd.trainer import Trainer, synthetic_rays
 dev = torch.device("cuda:0")
 tr = Trainer(kind="static", device=dev)
 tr.set_step(1000)
-for s in range(1000):
-    tr.requires_grad_fn(s)
 data = synthetic_rays(8192, dev, seed=1000)
 for _ in range(6):
     tr.train_step(data)

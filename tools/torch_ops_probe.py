@@ -10,7 +10,6 @@ rays = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 dev = torch.device("cuda:0")
 tr = Trainer(kind=kind, device=dev)
 tr.set_step(1000)
-for s in range(1000): tr.requires_grad_fn(s)
 kw = dict(num_cams=3, feature_dim=64) if kind == "feature" else {}
 data = synthetic_rays(rays, dev, seed=1, **kw)
 for _ in range(4): tr.train_step(data)

@@ -18,12 +18,13 @@ from emernerf_amd import ops
 from emernerf_amd.trainer import Trainer, synthetic_rays
 
 dev = torch.device("cuda:0")
-D, Lv, base, mx, T, F = 3, 16, 16, 2048, 19, 2
+gs = sys.argv[sys.argv.index("--grid") + 1] if "--grid" in sys.argv else "3,16,16,2048,19,2"   # e.g. --grid 4,10,32,8192,18,4 (xyzt tables)
+D, Lv, base, mx, T, F = (int(v) for v in gs.split(","))
 growth = float(np.exp((np.log(mx) - np.log(base)) / (Lv - 1)))
 desc = L.make_grid_desc(D, Lv, F, T, base, growth)
 N = 8192 * 128
 if "--uniform" in sys.argv:
-    x = torch.rand(N, 3, device=dev)
+    x = torch.rand(N, D, device=dev)
 else:
     tr = Trainer(kind="static", device=dev, table_init=0.3 if "--clustered" in sys.argv else None)
     data = synthetic_rays(8192, dev, seed=1000)
@@ -32,6 +33,8 @@ else:
         tr.train_step(data)
     cap = {"x": capture_main_grid_positions(tr, data)}
     x = cap["x"]
+    if D == 4:
+        x = torch.cat([x, data["normed_timestamps"][:, None].expand(-1, 128).reshape(-1, 1)], -1).contiguous()
     del tr
 p = torch.rand(desc.n_entries * F, device=dev) - 0.5
 dlm = torch.randn(Lv, N, F, device=dev)
