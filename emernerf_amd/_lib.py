@@ -96,6 +96,9 @@ SIGNATURES = {
     "emer_rmlp_supported": [c_int32, c_int32, c_int32, c_int32, c_int32],
     "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],
+    "emer_rmlp_bwd_fused_supported": [c_int32, c_int32, c_int32, c_int32, c_int32],
+    "emer_rmlp_bwd_fused": [_P, c_int64, _P, c_int64, _P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32, c_int32,
+                            _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
     "emer_rgb_head_fwd": [_P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_field_fwd_supported": [c_int32, c_int32],
     "emer_density_bwd_fused": [_P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P],
@@ -129,6 +132,7 @@ SIGNATURES = {
 INT64_FUNCTIONS = {
     "emer_linear_bwd_workspace": [c_int64, c_int32, c_int32],
     "emer_neck_bwd_fused_workspace": [c_int32, c_int32, c_int64, c_int32],
+    "emer_rmlp_bwd_fused_workspace": [c_int32, c_int32, c_int32, c_int64, c_int32],
     "emer_rgb_head_bwd_workspace": [c_int64],
     "emer_rgb_head_bwd_fused_workspace": [c_int64, c_int32],
     "emer_density_bwd_fused_workspace": [c_int32, c_int32, c_int64],

@@ -2073,6 +2073,289 @@ __global__ __launch_bounds__(kNThreads, 4) void rmlp_bwd_kernel(const RMlpBwdArg
     }
 }
 
+// ------------------------------------------- plain 2- / 3-layer heads: backward with the weight gradients fused [r5]
+// The flow MLP (xyzt encoding 40 -> 64 -> 64 -> 6) and the shadow head (64 -> 64 -> 1, sigmoid) ran their backward as rmlp_bwd + one
+// streamed weight-gradient launch and one reduction per layer: 327 us for the flow MLP's 524 288-row call of a flow step, 414 us for the
+// shadow head at 1 M rows, most of it h1 / h2 / dpre tensors making a round trip through HBM.  Here the whole backward is one kernel in
+// the manner of neck_bwdw_kernel: the hidden layers are RECOMPUTED from the input tile (the forward stores no activations), sigmoid'
+// is applied to the incoming gradient in registers, the rows are moved onto the reduction index by the matrix core (to_rows) and
+// dW_last / dW1 / dW0 / the bias gradients stay in accumulator registers for the whole launch.  Outputs up to 16 wide (n_out <= 16).
+// NL == 2: 8 waves, two per SIMD; NL == 3: 144 accumulator registers -> 4 waves, one per SIMD (as rgb_bwdw16_kernel).
+struct RMlpBwdWArgs {
+    const float *dout; int64_t ldd;   // [n][ldd >= n_out] gradient of the OUTPUT (after the final activation)
+    const float *out; int64_t ldo;    // [n][ldo >= n_out] saved output (sigmoid: d_last = dout * out * (1 - out)); unused otherwise
+    const float *x; int64_t ldx;      // the forward's input: row-major [n][ldx] (F == 0) or level-major [L][n][F]
+    int64_t n; int32_t n_levels, k0, n_out, final_act;
+    WSrc w0, w1;                      // forward weights for the recomputation: W0 (64 x k0), W1 (64 x 64, NL == 3)
+    const float *b0, *b1;
+    WSrc wlt, w1t, w0t;               // W_last^T (64 x n_out), W1^T (64 x 64, NL == 3), W0^T (k0 x 64)
+    float *dx; int64_t lddx;          // gradient of the input in the input's own layout (null: not needed)
+    float *partials; int64_t stride;  // [gridDim.x][stride]: dW_last [n_out][64] | db_last [n_out] | (dW1 [64][64] | db1 [64]) | dW0 [64][k0] | db0 [64]
+};
+
+template <int NL> constexpr int rmlp_w_threads() { return NL == 3 ? 256 : 512; }
+
+template <int KT0, int F, int NL>
+__global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bwdw_kernel(const RMlpBwdWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2, QB = (KT0 + 1) / 2, NW = rmlp_w_threads<NL>() / 64;
+    u32x4 *w0fl = smem, *w1fl = w0fl + w3_units(4, KS0), *wltl = w1fl + (NL == 3 ? w3_units(4, 2) : 0), *w1tl = wltl + w3_units(4, 1),
+          *w0tl = w1tl + (NL == 3 ? w3_units(4, 2) : 0);
+    float *b0l = reinterpret_cast<float *>(w0tl + w3_units(KT0, 2)), *b1l = b0l + 64;
+    stage_w3(w0fl, 4, KS0, a.w0);
+    if (NL == 3) stage_w3(w1fl, 4, 2, a.w1);
+    stage_w3(wltl, 4, 1, a.wlt);
+    if (NL == 3) stage_w3(w1tl, 4, 2, a.w1t);
+    stage_w3(w0tl, KT0, 2, a.w0t);
+    stage_b(b0l, 64, a.b0, 64);
+    if (NL == 3) stage_b(b1l, 64, a.b1, 64);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0fp = w3_at(w0fl, 4, KS0, lane), w1fp = w3_at(w1fl, 4, 2, lane), wlp = w3_at(wltl, 4, 1, lane), w1tp = w3_at(w1tl, 4, 2, lane),
+             w0tp = w3_at(w0tl, KT0, 2, lane);
+    const SelE sel = make_sel(lane);
+    // accumulators: dW_last [16][64] as 16 x 16 tiles (lane (j, g), register r: row 4 g + r, column 16 b + j); dW1 [64][64] and
+    // dW0 [64][K0P] as 32 x 32 blocks (lane (j, h), register r: row 32 P + 8 (r >> 2) + 4 h + (r & 3), column 32 Q + j)
+    f32x4 bwl[1][4];
+    f32x16 bw1[NL == 3 ? 2 : 1][2], bw0[2][QB];
+    float abl = 0.0f, ab1[4], ab0[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bwl[0][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (NL == 3) bw1[NL == 3 ? P : 0][Q][r] = 0.0f;
+#pragma unroll
+        for (int Q = 0; Q < QB; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bw0[P][Q][r] = 0.0f;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ab1[p] = 0.0f; ab0[p] = 0.0f; }
+    const int64_t n_tiles = (a.n + 15) >> 4, n_waves = (int64_t)gridDim.x * NW;
+    const int64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const int64_t t_begin = ((int64_t)blockIdx.x * NW + wave) * per_wave;
+    const int64_t t_end = t_begin + per_wave < n_tiles ? t_begin + per_wave : n_tiles;
+    float *stg = b1l + 64 + wave * (384 * KT0);   // per wave: the x operand tiles with the rows on the reduction index [KT0][3][64][2]
+    u32x2 *park = reinterpret_cast<u32x2 *>(stg) + lane;
+    const bool sig = a.final_act == EMER_ACT_SIGMOID;
+    // next tile's inputs ride in registers (x: KT0 x 16 bytes, dout / out: the lane's four columns of its row; lanes whose columns lie
+    // beyond n_out load nothing); loads are unconditional in the row (rows past the end re-read row n - 1 and are zeroed at use)
+    f32x4 xn[KT0], dn, on;
+    auto issue = [&](int64_t tile) {
+        const int64_t row0 = tile * 16;
+        const int64_t row = row0 + m < a.n ? row0 + m : a.n - 1;
+        if constexpr (F == 0) ld_rm_k<KT0>(a.x + row * a.ldx, true, g, a.k0, xn);
+        else ld_lm_t<KT0, F>(a.x + row0 * F, (unsigned)a.n, a.n_levels, (unsigned)(row - row0), g, xn);
+        const float *dp = a.dout + row * a.ldd, *op = a.out + row * a.ldo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool col = 4 * g + i < a.n_out;
+            dn[i] = col ? dp[4 * g + i] : 0.0f;
+            on[i] = (col && sig) ? op[4 * g + i] : 0.0f;
+        }
+    };
+    if (t_begin < t_end) issue(t_begin);
+    f32x4 dep[KT0];
+    int64_t tile_prev = -1;
+    auto store_dx = [&](int64_t tile) {
+        const int64_t row = tile * 16 + m;
+        if constexpr (F == 0) st_rm_k<KT0>(a.dx + row * a.lddx, row < a.n, g, a.k0, dep);
+        else st_lm_t<KT0, F>(a.dx + tile * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, row < a.n, g, dep);
+    };
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs have landed (issued one tile ago)
+        if (a.dx && tile_prev >= 0) store_dx(tile_prev);   // (stores count in vmcnt: issued right behind the wait, see neck_bwdw_kernel)
+        f32x4 x[KT0], d = dn;
+        const f32x4 o = on;
+#pragma unroll
+        for (int b = 0; b < KT0; ++b) x[b] = xn[b];
+        issue(tile + 1 < t_end ? tile + 1 : tile);
+        const bool ok = tile * 16 + m < a.n;
+        // ---- forward recomputation: h1 (and h2), their relu bits, and the operands with the rows on the reduction index
+        unsigned bits1 = 0u, bits2 = 0u;
+        SwP hq1[2];   // h1 as two 32-feature blocks (B operand of dW1; NL == 3)
+        SwT hl[4];    // the last hidden layer as four 16-feature tiles (B operand of dW_last)
+        {
+#pragma unroll
+            for (int b = 0; b < KT0; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[b][i] = ok ? x[b][i] : 0.0f;
+            Opd<KS0> xo;
+            make_opd<KT0>(x, xo);
+            f32x4 h[4];
+            init_bias<4>(b0l, g, h);
+            tgemm<KS0, 4, false>(w0fp, xo, h);
+#pragma unroll
+            for (int b = 0; b < KT0; ++b) {   // operand of dW0, needed at the end of the tile: parked in LDS
+                const SwT t = to_rows<KS0>(xo, b, sel);
+                park[(3 * b + 0) * 64] = t.h; park[(3 * b + 1) * 64] = t.m; park[(3 * b + 2) * 64] = t.l;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[p][i] = (ok && h[p][i] > 0.0f) ? h[p][i] : 0.0f;   // relu; rows past the end contribute nothing
+                    bits1 |= (h[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                }
+            Opd<2> ho;
+            make_opd<4>(h, ho);
+            if constexpr (NL == 3) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) hq1[q] = block32(to_rows<2>(ho, 2 * q, sel), to_rows<2>(ho, 2 * q + 1, sel));
+                f32x4 h2[4];
+                init_bias<4>(b1l, g, h2);
+                tgemm<2, 4, false>(w1fp, ho, h2);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        h2[p][i] = (ok && h2[p][i] > 0.0f) ? h2[p][i] : 0.0f;
+                        bits2 |= (h2[p][i] > 0.0f ? 1u : 0u) << (4 * p + i);
+                    }
+                make_opd<4>(h2, ho);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hl[b] = to_rows<2>(ho, b, sel);
+        }
+        // ---- gradient at the last pre-activation, dW_last, and down the chain
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = ok ? d[i] : 0.0f;
+            if (sig) v = v * o[i] * (1.0f - o[i]);
+            d[i] = v;
+        }
+        f32x4 da[4];
+        zero<4>(da);
+        {
+            f32x4 d1[1] = {d};
+            Opd<1> dop;
+            make_opd<1>(d1, dop);
+            const SwT dt[1] = {to_rows<1>(dop, 0, sel, &abl)};
+            dw_tiles<1, 4>(bwl, dt, hl);
+            tgemm<1, 4, false>(wlp, dop, da);
+        }
+        if constexpr (NL == 3) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) da[p][i] = ((bits2 >> (4 * p + i)) & 1u) ? da[p][i] : 0.0f;
+            Opd<2> dao1;
+            make_opd<4>(da, dao1);
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {   // dW1 rows 32 P .. += dPre1^T h1
+                const SwT t0 = to_rows<2>(dao1, 2 * P, sel, &ab1[2 * P]), t1 = to_rows<2>(dao1, 2 * P + 1, sel, &ab1[2 * P + 1]);
+                dw_blocks<2>(bw1[NL == 3 ? P : 0], block32(t0, t1), hq1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4 db[4];
+            zero<4>(db);
+            tgemm<2, 4, false>(w1tp, dao1, db);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) da[p] = db[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) da[p][i] = ((bits1 >> (4 * p + i)) & 1u) ? da[p][i] : 0.0f;
+        Opd<2> dao0;
+        make_opd<4>(da, dao0);
+        if (a.dx) {
+            f32x4 de[KT0];
+            zero<KT0>(de);
+            tgemm<2, KT0, false>(w0tp, dao0, de);
+#pragma unroll
+            for (int b = 0; b < KT0; ++b) dep[b] = de[b];
+        }
+        tile_prev = tile;
+        {   // dW0 += dPre0^T x
+            SwP xq[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                SwT xa, xb;
+                xa.h = park[(3 * (2 * q) + 0) * 64]; xa.m = park[(3 * (2 * q) + 1) * 64]; xa.l = park[(3 * (2 * q) + 2) * 64];
+                if (2 * q + 1 < KT0) { xb.h = park[(3 * (2 * q + 1) + 0) * 64]; xb.m = park[(3 * (2 * q + 1) + 1) * 64]; xb.l = park[(3 * (2 * q + 1) + 2) * 64]; }
+                else { xb.h = u32x2{0u, 0u}; xb.m = u32x2{0u, 0u}; xb.l = u32x2{0u, 0u}; }
+                xq[q] = block32(xa, xb);
+            }
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const SwT t0 = to_rows<2>(dao0, 2 * P, sel, &ab0[2 * P]), t1 = to_rows<2>(dao0, 2 * P + 1, sel, &ab0[2 * P + 1]);
+                dw_blocks<QB>(bw0[P], block32(t0, t1), xq);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dx && tile_prev >= 0) store_dx(tile_prev);
+    // ---- sum the waves through LDS (the weights are dead), one coalesced partial per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);   // dWl [16][64] | dbl [16] | dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
+    float *rl = red, *rbl = rl + 16 * 64, *r1 = rbl + 16, *rb1 = r1 + (NL == 3 ? 64 * 64 : 0), *r0 = rb1 + (NL == 3 ? 64 : 0), *rb0 = r0 + 64 * K0P;
+    abl += __shfl_xor(abl, 16, 64); abl += __shfl_xor(abl, 32, 64);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64);
+        ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64);
+    }
+    const int j32 = lane & 31, h32 = lane >> 5;
+    for (int w = 0; w < NW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *q = rl + (4 * g + r) * 64 + 16 * b + m;
+                    *q = (w == 0) ? bwl[0][b][r] : *q + bwl[0][b][r];
+                }
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                if constexpr (NL == 3) {
+#pragma unroll
+                    for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float *q = r1 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * 64 + 32 * Q + j32;
+                            *q = (w == 0) ? bw1[NL == 3 ? P : 0][Q][r] : *q + bw1[NL == 3 ? P : 0][Q][r];
+                        }
+                }
+#pragma unroll
+                for (int Q = 0; Q < QB; ++Q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (32 * Q + j32 < K0P) {
+                            float *q = r0 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * K0P + 32 * Q + j32;
+                            *q = (w == 0) ? bw0[P][Q][r] : *q + bw0[P][Q][r];
+                        }
+                    }
+            }
+            if (g == 0) {
+                rbl[m] = (w == 0) ? abl : rbl[m] + abl;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (NL == 3) rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
+                    rb0[16 * p + m] = (w == 0) ? ab0[p] : rb0[16 * p + m] + ab0[p];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
+    const int no = a.n_out;
+    for (int i = threadIdx.x; i < no * 64; i += (int)blockDim.x) part[i] = rl[i];
+    for (int i = threadIdx.x; i < no; i += (int)blockDim.x) part[no * 64 + i] = rbl[i];
+    float *p1 = part + no * 65;
+    if (NL == 3) {
+        for (int i = threadIdx.x; i < 64 * 64 + 64; i += (int)blockDim.x) p1[i] = r1[i];   // (db1 follows dW1 in `red` as in the partial)
+        p1 += 64 * 65;
+    }
+    for (int i = threadIdx.x; i < 64 * a.k0; i += (int)blockDim.x) { const int nn = i / a.k0, kk = i - nn * a.k0; p1[i] = r0[nn * K0P + kk]; }
+    for (int i = threadIdx.x; i < 64; i += (int)blockDim.x) p1[64 * a.k0 + i] = rb0[i];
+}
+
 static inline uint32_t fused_grid(int64_t work_items, int threads = kFThreads) {
     const int waves = threads / 64;
     int64_t blocks = (work_items + waves - 1) / waves;
@@ -2531,4 +2814,94 @@ extern "C" int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, c
     hipStream_t st = as_stream(stream);
     const uint32_t grid = fused_grid((n + 15) / 16, kNThreads);
     EMER_RMLP_DISPATCH(rmlp_bwd_kernel, a, lds, "rmlp_bwd");
+}
+
+// ---- plain 2- / 3-layer heads: backward with the weight gradients fused [r5] ------------------------------------------------
+static inline uint32_t rmlp_bwdw_grid(int64_t n, int n_layers) {
+    const int nw = (n_layers == 3 ? 256 : 512) / 64;
+    const int64_t tiles = (n + 15) / 16;
+    int64_t blocks = (tiles + nw - 1) / nw;
+    if (blocks > 256) blocks = 256;   // persistent: one workgroup per CU
+    return (uint32_t)(blocks < 1 ? 1 : blocks);
+}
+static inline int64_t rmlp_bwdw_stride(int n_layers, int k0, int n_out) {
+    return ((int64_t)n_out * 65 + (n_layers == 3 ? 64 * 65 : 0) + 64 * (int64_t)k0 + 64 + 3) / 4 * 4;
+}
+static inline size_t rmlp_bwdw_lds(int n_layers, int kt0) {
+    const int nw = (n_layers == 3 ? 256 : 512) / 64;
+    const size_t w = (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, 1) + w3_units(kt0, 2) + (n_layers == 3 ? 2 * w3_units(4, 2) : 0)) * 16
+                     + (size_t)(128 + nw * 384 * kt0) * sizeof(float);
+    const size_t r = (size_t)(16 * 64 + 16 + (n_layers == 3 ? 64 * 64 + 64 : 0) + 64 * 16 * kt0 + 64) * sizeof(float);
+    return w > r ? w : r;
+}
+// 1 when emer_rmlp_bwd_fused covers this stack: what emer_rmlp_fwd covers, with at most 16 outputs (the flow MLP's 6, the shadow head's 1;
+// the 64-wide feature heads keep emer_rmlp_bwd + streamed weight gradients: their dW_last would not fit the registers)
+extern "C" int emer_rmlp_bwd_fused_supported(int32_t n_layers, int32_t k0, int32_t n_feat, int32_t hidden, int32_t n_out) {
+    return (emer_rmlp_supported(n_layers, k0, n_feat, hidden, n_out) && n_out <= 16) ? 1 : 0;
+}
+// floats of workspace emer_rmlp_bwd_fused needs (per-workgroup partial weight gradients); 0: not supported for this call
+extern "C" int64_t emer_rmlp_bwd_fused_workspace(int32_t n_layers, int32_t k0, int32_t n_feat, int64_t n, int32_t n_out) {
+    if (n <= 0 || !emer_rmlp_bwd_fused_supported(n_layers, k0, n_feat, 64, n_out)) return 0;
+    if (n_feat != 0 && n * k0 >= (1ll << 30)) return 0;   // level-major input: 32-bit lane offsets
+    return (int64_t)rmlp_bwdw_grid(n, n_layers) * rmlp_bwdw_stride(n_layers, k0, n_out);
+}
+// Backward of emer_rmlp_fwd INCLUDING the weight gradients.  dout [n][ldd]: gradient of the OUTPUT (sigmoid' is applied here from the
+// saved `out` [n][ldo]; final_act none: `out` may be NULL).  x: the forward's input (the hidden layers are recomputed from it: pass
+// h1 = h2 = NULL to emer_rmlp_fwd).  Writes dx in x's layout when non-null; ACCUMULATES (+=) dw0 [64][ld_dw0 >= k0], db0 [64],
+// dw1 / db1 (three layers: [64][ld_dw1 >= 64], [64]; two layers: the output layer [n_out][ld_dw1 >= 64], [n_out]) and, for three layers,
+// dw2 [n_out][ld_dw2 >= 64], db2 [n_out] -- torch Linear layouts.  Bias pointers may be NULL (layer without a bias gradient).
+extern "C" int emer_rmlp_bwd_fused(const float *dout, int64_t ldd, const float *out, int64_t ldo, const float *x, int64_t ldx, int32_t n_levels,
+                                   int32_t n_feat, int32_t k0, int64_t n, int32_t n_layers, const float *w0, const float *b0, const float *w1,
+                                   const float *b1, const float *w2, int32_t n_out, int32_t final_act, float *dx, int64_t lddx, float *workspace,
+                                   float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1, float *db1, float *dw2, int64_t ld_dw2,
+                                   float *db2, void *stream) {
+    EMER_REQUIRE(n >= 0, "rmlp_bwd_fused: negative n");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE(emer_rmlp_bwd_fused_supported(n_layers, k0, n_feat, 64, n_out), "rmlp_bwd_fused: unsupported stack (layers=%d k0=%d F=%d n_out=%d)", n_layers, k0, n_feat, n_out);
+    EMER_REQUIRE(dout && x && w0 && b0 && w1 && workspace && dw0 && dw1 && ldd >= n_out && (n_layers == 2 || (w2 && b1 && dw2)), "rmlp_bwd_fused: bad arguments");
+    EMER_REQUIRE(final_act == EMER_ACT_NONE || (final_act == EMER_ACT_SIGMOID && out && ldo >= n_out), "rmlp_bwd_fused: final activation must be none, or sigmoid with the saved output");
+    EMER_REQUIRE(n_feat != 0 || (ldx >= k0 && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0), "rmlp_bwd_fused: row-major input needs ldx %% 4 == 0 and 16-byte alignment");
+    EMER_REQUIRE(n_feat == 0 || (n_levels * n_feat == k0 && n * k0 < (1ll << 30)), "rmlp_bwd_fused: level-major input needs k0 == n_levels * n_feat and n * k0 < 2^30");
+    EMER_REQUIRE(!dx || n_feat != 0 || (lddx >= k0 && lddx % 4 == 0 && ((uintptr_t)dx % 16) == 0), "rmlp_bwd_fused: row-major dx needs lddx %% 4 == 0 and 16-byte alignment");
+    EMER_REQUIRE(ld_dw0 >= k0 && ld_dw1 >= 64 && (n_layers == 2 || ld_dw2 >= 64), "rmlp_bwd_fused: leading dimension smaller than the row");
+    RMlpBwdWArgs a;
+    a.dout = dout; a.ldd = ldd; a.out = out; a.ldo = ldo; a.x = x; a.ldx = ldx; a.n = n; a.n_levels = n_levels; a.k0 = k0; a.n_out = n_out;
+    a.final_act = final_act;
+    const float *wl = n_layers == 2 ? w1 : w2;
+    a.w0 = WSrc{w0, k0, 1, 64, k0};
+    a.w1 = WSrc{w1, 64, 1, 64, 64};
+    a.b0 = b0; a.b1 = b1;
+    a.wlt = WSrc{wl, 1, 64, 64, n_out};   // (n = hidden, k = output) = wl[k][n]
+    a.w1t = WSrc{w1, 1, 64, 64, 64};
+    a.w0t = WSrc{w0, 1, k0, k0, 64};      // (n = input feature, k = hidden) = w0[k][n]
+    a.dx = dx; a.lddx = lddx; a.partials = workspace; a.stride = rmlp_bwdw_stride(n_layers, k0, n_out);
+    const int kt0 = n_feat == 0 ? 4 : ((k0 + 15) / 16 <= 2 ? 2 : (k0 + 15) / 16);
+    const uint32_t grid = rmlp_bwdw_grid(n, n_layers);
+    const size_t lds = rmlp_bwdw_lds(n_layers, kt0);
+    hipStream_t st = as_stream(stream);
+    int rc = EMER_E_INVALID;
+    auto go = [&](auto kern, int threads) {
+        if (int r = set_lds(kern, lds, "rmlp_bwd_fused")) return r;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+        return check_launch("rmlp_bwd_fused");
+    };
+    if (n_feat == 0) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 0, 2>, 512) : go(rmlp_bwdw_kernel<4, 0, 3>, 256);
+    else if (kt0 == 2) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<2, 4, 2>, 512) : go(rmlp_bwdw_kernel<2, 4, 3>, 256);
+    else if (kt0 == 3) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<3, 4, 2>, 512) : go(rmlp_bwdw_kernel<3, 4, 3>, 256);
+    else rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 4, 2>, 512) : go(rmlp_bwdw_kernel<4, 4, 3>, 256);
+    if (rc) return rc;
+    DwReduceJob jb[3];
+    int nj = 0;
+    int64_t off = 0;
+    if (n_layers == 2) {
+        jb[nj++] = DwReduceJob{off, n_out, 64, dw1, ld_dw1, db1, 0, {0}, {0}, {0}};
+        off += (int64_t)n_out * 65;
+    } else {
+        jb[nj++] = DwReduceJob{off, n_out, 64, dw2, ld_dw2, db2, 0, {0}, {0}, {0}};
+        off += (int64_t)n_out * 65;
+        jb[nj++] = DwReduceJob{off, 64, 64, dw1, ld_dw1, db1, 0, {0}, {0}, {0}};
+        off += 64 * 65;
+    }
+    jb[nj++] = DwReduceJob{off, 64, k0, dw0, ld_dw0, db0, 0, {0}, {0}, {0}};
+    return launch_dw_reduce_multi(workspace, (int32_t)grid, a.stride, nj, jb, st);
 }

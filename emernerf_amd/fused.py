@@ -193,6 +193,7 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
 
 
 FUSED_WGRAD = True   # weight gradients inside the backward kernels where the library has them (emer_neck_bwd_fused); False: separate pass
+FUSED_RMLP_WGRAD = os.environ.get("EMER_FUSE_RMLP_WGRAD", "1") != "0"  # ... of the plain 2- / 3-layer heads with <= 16 outputs (emer_rmlp_bwd_fused) [r5]
 FUSED_RGB_WGRAD = os.environ.get("EMER_FUSE_RGB_WGRAD", "1") != "0"   # ... of the rgb head's layers 0 / 1 too (emer_rgb_head_bwd_fused) [r4]
 RGB_WGRAD_PAIR = os.environ.get("EMER_RGBW_PAIR", "0") == "1"         # its variant that pairs two row tiles per weight-gradient step
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
@@ -918,14 +919,22 @@ class _RMlpFn(torch.autograd.Function):
         dev = X.device
         n_out = Ws[-1].shape[0]
         need_bwd = any(ctx.needs_input_grad)
-        h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if need_bwd else None
-        h2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (need_bwd and n == 3) else None
+        # [r5] stacks with at most 16 outputs (flow MLP, shadow head): the backward is ONE kernel that recomputes the hidden layers from x and
+        # keeps the weight gradients in registers (emer_rmlp_bwd_fused) -- the forward then stores no activations
+        ctx.fused_bwd = bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and need_bwd and all(b is not None for b in Bs[:n - 1])
+                             and _lib.load().emer_rmlp_bwd_fused_workspace(n, K0, F, N, n_out) > 0)
+        keep = need_bwd and not ctx.fused_bwd
+        h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if keep else None
+        h2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (keep and n == 3) else None
         out = torch.empty((N, n_out), device=dev, dtype=torch.float32)
         w2, b2 = (Ws[2], Bs[2]) if n == 3 else (None, None)
         with torch.cuda.device(dev):
             _lib.call("emer_rmlp_fwd", _p(X), ldx, L, F, K0, N, n, _p(Ws[0]), _p(Bs[0]), _p(Ws[1]), _p(Bs[1]), _p(w2), _p(b2),
                       n_out, final_act, _p(h1), _p(h2), _p(out), n_out, _stream(X))
-        ctx.save_for_backward(X, out, *Ws, *([h1] if h1 is not None else []), *([h2] if h2 is not None else []))
+        if ctx.fused_bwd:
+            ctx.save_for_backward(X, out, *Ws, *Bs[:n - 1])
+        else:
+            ctx.save_for_backward(X, out, *Ws, *([h1] if h1 is not None else []), *([h2] if h2 is not None else []))
         ctx.n, ctx.final_act, ctx.level_major = n, final_act, level_major
         ctx.sinks = tuple(_sink(p) for p in wb)
         ctx.need_dx = ctx.needs_input_grad[0]
@@ -938,8 +947,6 @@ class _RMlpFn(torch.autograd.Function):
             return (None,) * (3 + 2 * n)
         saved = ctx.saved_tensors
         X, out, Ws = saved[0], saved[1], saved[2:2 + n]
-        h1 = saved[2 + n]
-        h2 = saved[3 + n] if n == 3 else None
         dev = X.device
         if ctx.level_major:
             L, N, F = X.shape
@@ -949,6 +956,30 @@ class _RMlpFn(torch.autograd.Function):
             L, F = 0, 0
         n_out = Ws[-1].shape[0]
         d = _c(dout)
+        if ctx.fused_bwd:
+            Bh = saved[2 + n:2 + n + n - 1]   # biases of the hidden layers (the recomputation needs them)
+            dx = torch.empty_like(X) if ctx.need_dx else None
+            tgt = []
+            for i in range(n):
+                tw, rw = _target(ctx.sinks[2 * i], tuple(Ws[i].shape), dev)
+                has_b = ctx.needs_input_grad[3 + 2 * i + 1]
+                tb, rb = _target(ctx.sinks[2 * i + 1], (Ws[i].shape[0],), dev) if has_b else (None, None)
+                tgt.append((tw, rw, tb, rb))
+            ws = torch.empty((int(_lib.load().emer_rmlp_bwd_fused_workspace(n, K0, F, N, n_out)),), device=dev, dtype=torch.float32)
+            w2 = Ws[2] if n == 3 else None
+            b1 = Bh[1] if n == 3 else None
+            t2 = tgt[2] if n == 3 else (None, None, None, None)
+            with torch.cuda.device(dev):
+                _lib.call("emer_rmlp_bwd_fused", _p(d), d.stride(0), _p(out), out.stride(0), _p(X), (0 if ctx.level_major else X.stride(0)), L, F, K0, N, n,
+                          _p(Ws[0]), _p(Bh[0]), _p(Ws[1]), _p(b1), _p(w2), n_out, ctx.final_act, _p(dx), (0 if ctx.level_major else K0), _p(ws),
+                          _p(tgt[0][0]), tgt[0][0].stride(0), _p(tgt[0][2]), _p(tgt[1][0]), tgt[1][0].stride(0), _p(tgt[1][2]),
+                          _p(t2[0]), (t2[0].stride(0) if t2[0] is not None else 0), _p(t2[2]), _stream(X))
+            grads = []
+            for tw, rw, tb, rb in tgt:
+                grads += [rw, rb]
+            return (dx, None, None, *grads)
+        h1 = saved[2 + n]
+        h2 = saved[3 + n] if n == 3 else None
         dlast = (d * out * (1.0 - out)).contiguous() if ctx.final_act == ACT_SIGMOID else d
         dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
         dpre1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if n == 3 else None
@@ -969,6 +1000,13 @@ class _RMlpFn(torch.autograd.Function):
             wgrad(dpre[i], operands[i], Ws[i].shape[1], want_bias=has_b, out_w=tw, out_b=tb)
             grads += [rw, rb]
         return (dx, None, None, *grads)
+
+
+def rmlp_bwd_fused_supported(weights, k0: int, n_feat: int, n_rows: int) -> bool:
+    """True when the backward of this stack runs as emer_rmlp_bwd_fused (weight gradients in the kernel, hidden layers recomputed)."""
+    n = len(weights)
+    return bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and n in (2, 3)
+                and _lib.load().emer_rmlp_bwd_fused_workspace(n, int(k0), int(n_feat), int(n_rows), int(weights[-1].shape[0])) > 0)
 
 
 def seq_mlp(x: Tensor, weights, biases, final_act: int = ACT_NONE) -> Tensor:

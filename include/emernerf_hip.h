@@ -500,6 +500,21 @@ int emer_rmlp_fwd(const float *x, int64_t ldx, int32_t n_levels, int32_t n_feat,
 int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float *h2, int32_t n_levels, int32_t n_feat,
                   int32_t k0, int64_t n, int32_t n_layers, const float *w0, const float *w1, const float *w2, int32_t n_out,
                   float *dpre1, float *dpre0, float *dx, int64_t lddx, void *stream);
+/* [r5] The whole backward of emer_rmlp_fwd in ONE kernel, weight gradients included (replaces autograd of the flow MLP,
+ * radiance_field.py:101-111, and of the shadow head, :148-153: torch's sigmoid backward, emer_rmlp_bwd, one weight-gradient launch
+ * and one reduction per layer).  Stacks with n_out <= 16 (emer_rmlp_bwd_fused_supported).  dout [n][ldd]: gradient of the OUTPUT;
+ * sigmoid' is applied from the saved `out` [n][ldo] (final_act == EMER_ACT_NONE: out may be NULL).  The hidden layers are
+ * recomputed from x (pass h1 = h2 = NULL to emer_rmlp_fwd).  Writes dx in x's layout when non-NULL; ACCUMULATES (+=) dw0
+ * [64][ld_dw0 >= k0], db0 [64], dw1 / db1 (three layers: [64][ld_dw1 >= 64], [64]; two layers: the output layer, [n_out][ld_dw1], [n_out])
+ * and, for three layers, dw2 [n_out][ld_dw2 >= 64], db2 [n_out]; bias gradient pointers may be NULL.  workspace:
+ * emer_rmlp_bwd_fused_workspace(...) floats (0: this call is not covered -- use emer_rmlp_bwd). */
+int emer_rmlp_bwd_fused_supported(int32_t n_layers, int32_t k0, int32_t n_feat, int32_t hidden, int32_t n_out);
+int64_t emer_rmlp_bwd_fused_workspace(int32_t n_layers, int32_t k0, int32_t n_feat, int64_t n, int32_t n_out);
+int emer_rmlp_bwd_fused(const float *dout, int64_t ldd, const float *out, int64_t ldo, const float *x, int64_t ldx, int32_t n_levels,
+                        int32_t n_feat, int32_t k0, int64_t n, int32_t n_layers, const float *w0, const float *b0, const float *w1,
+                        const float *b1, const float *w2, int32_t n_out, int32_t final_act, float *dx, int64_t lddx, float *workspace,
+                        float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1, float *db1, float *dw2, int64_t ld_dw2,
+                        float *db2, void *stream);
 
 /* rgb head: mlp.MLP(in = kh + 64, hidden 64, 3 layers, skip connection at layer 1) + sigmoid
  * (radiance_field.py:130-143,622-658, mlp.py:20-46) on input [hray[ray] | geo[sample]], where hray

@@ -234,9 +234,19 @@ def test_skip_mlp3(hip_lib, N, K0, act):
         _close(name, a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
 
 
+@pytest.fixture(params=[True, False], ids=["fusedw", "streamedw"])
+def rmlp_wgrad_mode(request):
+    """Both backward paths of the plain heads: weight gradients inside the backward kernel (emer_rmlp_bwd_fused, the default for
+    stacks with <= 16 outputs) and emer_rmlp_bwd + streamed weight gradients."""
+    from emernerf_amd import fused
+    prev, fused.FUSED_RMLP_WGRAD = fused.FUSED_RMLP_WGRAD, request.param
+    yield request.param
+    fused.FUSED_RMLP_WGRAD = prev
+
+
 @pytest.mark.parametrize("dims,sig,N", [((64, 64, 1), True, 1000), ((40, 64, 64, 6), False, 777), ((64, 64, 64, 64), False, 4096),
-                                        ((43, 32, 5), False, 17)])
-def test_seq_mlp(hip_lib, dims, sig, N):
+                                        ((43, 32, 5), False, 17), ((64, 64, 1), True, 10000), ((64, 64, 64, 3), True, 5000), ((32, 64, 16), False, 3001)])
+def test_seq_mlp(hip_lib, dims, sig, N, rmlp_wgrad_mode):
     """fused.seq_mlp (shadow / flow / dino heads) vs fp64 torch, including dx."""
     from emernerf_amd import fused, _lib
     dev = torch.device("cuda:0")
@@ -264,7 +274,7 @@ def test_seq_mlp(hip_lib, dims, sig, N):
 
 @pytest.mark.parametrize("L,F,dims,N", [(10, 4, (64, 64, 6), 1000), (10, 4, (64, 6), 333), (4, 4, (64, 64, 64), 50), (16, 4, (64, 64, 3), 4099),
                                          (10, 4, (64, 64, 6), 262144)])
-def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
+def test_seq_mlp_level_major(hip_lib, L, F, dims, N, rmlp_wgrad_mode):
     """fused.seq_mlp_lm (flow MLP on the level-major xyzt encoding, radiance_field.py:359-389) vs fp64 torch on the
     row-major view of the same encoding, including the level-major input gradient."""
     from emernerf_amd import fused, _lib
@@ -287,8 +297,16 @@ def test_seq_mlp_level_major(hip_lib, L, F, dims, N):
     def pack(x):
         saved.append(x)
         return x
+    # (the fused backward recomputes the hidden layers -- bitwise the forward's values -- and saves none: the masks then come from a
+    # forward of the other path on the same inputs)
+    mode, fused.FUSED_RMLP_WGRAD = fused.FUSED_RMLP_WGRAD, False
     with torch.autograd.graph.saved_tensors_hooks(pack, lambda x: x):
         out = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
+    fused.FUSED_RMLP_WGRAD = mode
+    if mode and fused.rmlp_bwd_fused_supported(Ws, K0, F, N):
+        out_f = fused.seq_mlp_lm(t[0], t[1:1 + n], t[1 + n:])
+        assert torch.equal(out_f, out), "the two paths share the forward kernel"
+        out = out_f
     acts = [x for x in saved if x.dim() == 2 and tuple(x.shape) == (N, 64) and x.data_ptr() != out.data_ptr()]
     assert len(acts) == n - 1, [tuple(x.shape) for x in saved]
     h = r[0].permute(1, 0, 2).reshape(N, K0)

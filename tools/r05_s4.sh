@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-5 session 4: fused rmlp backward -- parity, then same-session step A/B (flow at the 2048-ray shard, dynamic at 8192)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05s4; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_fused_gpu.py -x -q -k "seq_mlp" > $O/pytest_rmlp.log 2>&1; echo "pytest rc $?" >> $O/pytest_rmlp.log
+tail -15 $O/pytest_rmlp.log
+B="--no-cpu-baseline --no-extras --no-second-state --no-secondary --no-fp16-state --steps 16 --warmup 4"
+for r in 1 2; do
+  for v in 1 0; do
+    EMER_FUSE_RMLP_WGRAD=$v timeout 300 python bench.py --kind flow --rays 2048 $B 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('flow2048 fuse_rmlp=$v', round(d['ms_per_step'],3))" >> $O/ab_rmlp.txt
+    EMER_FUSE_RMLP_WGRAD=$v timeout 300 python bench.py --kind dynamic $B 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dynamic8192 fuse_rmlp=$v', round(d['ms_per_step'],3))" >> $O/ab_rmlp.txt
+  done
+done
+cat $O/ab_rmlp.txt
