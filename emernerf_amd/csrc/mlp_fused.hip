@@ -615,6 +615,15 @@ __device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const
 #undef EMER_DWB
 }
 
+// [r5 experiment, off] encodings of 33-64 features (KT0 >= 3: the dynamic / flow necks on the 40-feature xyzt encoding) need more than the
+// 256 registers two waves per SIMD leave (hipcc spills 26-73 dwords per lane).  EMER_NECKW_WPS1_KT = 3 runs those instantiations with 4
+// waves per workgroup = one per SIMD and 512 registers (348 used, no scratch), as rgb_bwdw16_kernel does.  Same-session A/B: flow step at
+// 2048 rays 0.451 vs 0.450 ms of neck backward, dynamic step at 8192 rays 0.818 vs 0.784 ms -- the second wave hides more than the
+// spills cost.  Default 5 = never.
+#ifndef EMER_NECKW_WPS1_KT
+#define EMER_NECKW_WPS1_KT 5
+#endif
+constexpr int neckw_threads(int kt0) { return kt0 >= EMER_NECKW_WPS1_KT ? 256 : 512; }
 constexpr int kWThreads = 512;  // fused backward: 8 waves, ONE workgroup per CU = 2 waves per SIMD (<= 256 registers); the weights (48-72 KB) are
                                 // staged once per CU and leave room for 7-10 KB of per-wave staging
 
@@ -632,7 +641,7 @@ struct NeckBwdWArgs {
 };
 
 template <int KT0, int F>
-__global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWArgs a) {
+__global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 : 2) void neck_bwdw_kernel(const NeckBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2;
     u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2), *w0fl = w1l + w3_units(4, 2);
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(kWThreads, 2) void neck_bwdw_kernel(const NeckBwdWA
         ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64);
     }
     const int j32 = lane & 31, h32 = lane >> 5;
-    for (int w = 0; w < kWThreads / 64; ++w) {
+    for (int w = 0; w < neckw_threads(KT0) / 64; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int P = 0; P < 2; ++P) {
@@ -2467,14 +2476,15 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
 }
 
 // ---- neck backward with the weight gradients fused [r3] --------------------------------------------------------------------
-static inline uint32_t neck_bwdw_grid(int64_t n) {
+static inline uint32_t neck_bwdw_grid(int64_t n, int kt0) {
     const int64_t tiles = (n + 15) / 16;
-    int64_t blocks = (tiles + kWThreads / 64 - 1) / (kWThreads / 64);
+    const int nw = neckw_threads(kt0) / 64;
+    int64_t blocks = (tiles + nw - 1) / nw;
     if (blocks > 256) blocks = 256;   // persistent: one 8-wave workgroup per CU
     return (uint32_t)(blocks < 1 ? 1 : blocks);
 }
 static inline size_t neck_bwdw_lds(int kt0) {   // weights + bias + a staging buffer of 4 KB per wave; the final reduction reuses the front
-    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2) + w3_units(4, (kt0 + 1) / 2)) * 16 + (size_t)(64 + (kWThreads / 64) * (1024 + 384 * kt0)) * sizeof(float);
+    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2) + w3_units(4, (kt0 + 1) / 2)) * 16 + (size_t)(64 + (neckw_threads(kt0) / 64) * (1024 + 384 * kt0)) * sizeof(float);
     const size_t r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
     return w > r ? w : r;
 }
@@ -2489,7 +2499,7 @@ static inline bool neck_bwdw_fits(int32_t n_levels, int32_t n_feat, int64_t n) {
 // floats of workspace emer_neck_bwd_fused needs (per-workgroup partial weight gradients)
 extern "C" int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out) {
     if (n <= 0 || !emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out) || !neck_bwdw_fits(n_levels, n_feat, n)) return 0;
-    return (int64_t)neck_bwdw_grid(n) * neck_bwdw_stride(n_levels * n_feat);
+    return (int64_t)neck_bwdw_grid(n, (n_levels * n_feat + 15) / 16) * neck_bwdw_stride(n_levels * n_feat);
 }
 // Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
 // [64][ld_dw0 >= L*F], db0 [64], dw1 [64][ld_dw1 >= 64], db1 [64] (torch Linear layouts; what autograd's AccumulateGrad would
@@ -2515,12 +2525,12 @@ extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const fl
     a.denc = denc_lm; a.partials = workspace; a.stride = neck_bwdw_stride(k0);
     hipStream_t st = as_stream(stream);
     const int kt0 = (k0 + 15) / 16;
-    const uint32_t grid = neck_bwdw_grid(n);
+    const uint32_t grid = neck_bwdw_grid(n, kt0);
     const size_t lds = neck_bwdw_lds(kt0);
     int rc = EMER_E_INVALID;
     auto go = [&](auto kern) {
         if (int r = set_lds(kern, lds, "neck_bwd_fused")) return r;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kWThreads), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(neckw_threads(kt0)), lds, st, a);
         return check_launch("neck_bwd_fused");
     };
 #define EMER_NBW(FF) (kt0 == 1 ? go(neck_bwdw_kernel<1, FF>) : kt0 == 2 ? go(neck_bwdw_kernel<2, FF>) : kt0 == 3 ? go(neck_bwdw_kernel<3, FF>) : go(neck_bwdw_kernel<4, FF>))
