@@ -158,7 +158,8 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     batches = [synthetic_rays(rays, dev, seed=3000 + i, **kw) for i in range(4)]
     for i in range(init_steps + warmup):
         tr.train_step(batches[i % 4])
-    names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_input", "emer_hashgrid_bwd_input_jac"]
+    names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add", "emer_hashgrid_bwd_input",
+             "emer_hashgrid_bwd_input_jac"]
     timer = _lib.KernelTimer(names)
     graphed = tr.use_graph   # (False if the capture failed: Trainer falls back to eager launches with a warning)
     if not graphed:
@@ -191,7 +192,7 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
     def xyzt(*ks):   # launches on the xyzt grids; the evaluations whose positions need a gradient run the Jacobian-storing forward and
         return [u for k in ks for u, tg in zip(us[k], tags[k]) if tg == (D4, L4, F4)]   # the streaming input gradient [r4]
     f4 = xyzt("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac")
-    b4 = xyzt("emer_hashgrid_bwd_params_sliced")
+    b4 = xyzt("emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add")   # (_add: a table's second evaluation in the step)
     i4 = xyzt("emer_hashgrid_bwd_input", "emer_hashgrid_bwd_input_jac")
     if f4 and b4:
         fb4, bb4 = grid_alg_bytes(D4, L4, F4)
@@ -309,7 +310,7 @@ def main():
     # HIP events inside the timed region only around the roofline kernels (the grid encode + its backward: five
     # launches per step).  Timing every entry point costs ~1.4 ms/step in event records, so the full per-kernel
     # breakdown comes from a second, separately instrumented pass after the timed region.
-    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels",
+    grid_names = ["emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add", "emer_hashgrid_bwd_params_sliced_levels",
                   "emer_hashgrid_bwd_params", "emer_hashgrid_bwd_input_jac"]
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
@@ -319,7 +320,8 @@ def main():
                               "emer_prop_loss", "emer_ray_epilogue_fwd", "emer_ray_epilogue_bwd", "emer_pixel_loss_fwd", "emer_pixel_loss_bwd",
                               "emer_trunc_exp_fwd", "emer_trunc_exp_bwd", "emer_ray_inputs_fwd", "emer_embed_grad", "emer_ray_pre_fwd",
                               "emer_ray_pre_bwd", "emer_ray_head_fwd", "emer_ray_head_bwd", "emer_ray_wgrad", "emer_lidar_loss", "emer_field_fwd",
-                              "emer_density_bwd_fused"]
+                              "emer_density_bwd_fused", "emer_rmlp_bwd_fused", "emer_composite_rgb_fwd", "emer_composite_rgb_bwd", "emer_reg_losses_fwd6",
+                              "emer_reg_losses_bwd6", "emer_aggregate3_density_fwd", "emer_aggregate3_density_bwd", "emer_flow_warp_fwd", "emer_flow_warp_bwd"]
     # (graph replay launches no kernel from Python, so there is nothing to bracket inside the timed region: with --graph
     # the roofline kernels are timed in the eager instrumented pass below instead)
     timer = _lib.KernelTimer(grid_names) if (rank == 0 and not args.graph) else None
@@ -561,7 +563,7 @@ def main():
         if args.kind != "static" and dyn is not None:
             D4, L4, F4 = dyn.n_input_dims, dyn.n_levels, dyn.n_features_per_level
             f4 = [u for u, tg in zip(us["emer_hashgrid_fwd"], tags["emer_hashgrid_fwd"]) if tg == (D4, L4, F4)]
-            b4 = [u for u, tg in zip(us["emer_hashgrid_bwd_params_sliced"], tags["emer_hashgrid_bwd_params_sliced"]) if tg == (D4, L4, F4)]
+            b4 = [u for k4 in ("emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add") for u, tg in zip(us[k4], tags[k4]) if tg == (D4, L4, F4)]
             if f4 and b4:
                 fb4, bb4 = grid_alg_bytes(D4, L4, F4)
                 fa4, ba4 = sum(f4) / len(f4), sum(b4) / len(b4)

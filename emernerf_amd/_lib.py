@@ -43,6 +43,7 @@ SIGNATURES = {
     "emer_hashgrid_fwd": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_hashgrid_bwd_params": [_GP, _P, _P, c_int64, c_int64, _P, c_int, c_int64, _P],
     "emer_hashgrid_bwd_params_sliced": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
+    "emer_hashgrid_bwd_params_sliced_add": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
     "emer_hashgrid_bwd_params_sliced_levels": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_int32, _P],
     "emer_hashgrid_sliced_split_level": [_GP],
     "emer_hashgrid_slice_masks": [_GP, _P, _P, c_int64, _P],
@@ -80,6 +81,9 @@ SIGNATURES = {
     "emer_reg_losses_fwd": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P],
     "emer_reg_losses_bwd": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, _P, _P, c_int64, c_float, _P, c_float,
                             _P, _P, _P, _P, _P, _P],
+    "emer_reg_losses_fwd6": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, _P, _P],
+    "emer_reg_losses_bwd6": [_P, c_int64, c_float, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, _P, c_int64, c_float, _P, c_float,
+                             _P, _P, _P, _P, _P],
     "emer_lidar_loss": [_P, _P, _P, _P, c_int64, c_int32, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P],
     "emer_accumulate_fwd": [_P, _P, c_int64, c_int32, c_int32, _P, _P],
     "emer_accumulate_bwd": [_P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P],
@@ -191,7 +195,7 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer to enable
 
 
-_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
+_TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
 
 
 def call(name: str, *args) -> None:

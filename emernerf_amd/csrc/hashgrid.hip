@@ -315,24 +315,38 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
         if (local > max_entries) p.ok = 0;
         if (local > p.max_local) p.max_local = local;
     }
-    // [r5] tail filler for grids without dense levels (see EMER_TAIL_SPLIT above): the levels sorted last by item cost (the finest ones
-    // under the model below) until they cover the items of the incomplete last round
+    // [r5] tail filler (see EMER_TAIL_SPLIT above).  The hashed items (one per level and slice, ~equal cost) are taken in rounds of
+    // `owners`; the last round is incomplete when their count is not a multiple of it, and the idle owners can only be fed with the
+    // small items of the dense levels (~0.12 of a hashed item each, tools/trace_sliced.py).  Where that filler covers less than half of
+    // the hole, the levels whose items make up the incomplete round -- the finest ones: they sort last -- are cut in R sample
+    // ranges, R in {2, 4} chosen to minimise the tail ceil(rem R / owners) / R (dynamic xyzt table: 640 items -> rem 128 -> R = 2;
+    // flow xyzt table: 576 hashed items + one dense level -> rem 64 -> R = 4; cfg-2 main grid: 1900 dense items -> no cut).
     p.sched_shift = kSchedBlock == 32u ? 5u : 6u;
     {
-        uint32_t n_dense = 0, items = 0;
-        for (uint32_t l = 0; l < g->n_levels; ++l) { n_dense += g->hashed[l] ? 0u : 1u; items += p.n_slices[l]; }
+        uint32_t hashed_items = 0, dense_items = 0;
+        for (uint32_t l = 0; l < g->n_levels; ++l) {
+            if (g->hashed[l]) hashed_items += p.n_slices[l];
+            else dense_items += p.n_slices[l] * p.n_ranges[l];
+        }
         const uint32_t owners = EMER_SLICE_THREADS == 1024 ? 256u : 512u;
-        const uint32_t rem = items % owners;
-        if (n_dense == 0u && items > owners && EMER_SLICE_THREADS == 1024) {
-            if (EMER_SCHED_BLOCK_NOFILL == 16) p.sched_shift = 4u;
-            else if (EMER_SCHED_BLOCK_NOFILL == 8) p.sched_shift = 3u;
-            if (rem != 0u && EMER_TAIL_SPLIT > 1) {
-                // finest levels first (they sort last: lowest modelled item cost)
-                uint32_t covered = 0;
-                for (uint32_t l = g->n_levels; l-- > 0u && covered < rem;) {
-                    p.n_ranges[l] = (uint32_t)EMER_TAIL_SPLIT;
-                    covered += p.n_slices[l];
-                }
+        const uint32_t rem = hashed_items % owners;
+        const float hole = (float)(owners - rem), filler = 0.12f * (float)dense_items;
+        if (EMER_TAIL_SPLIT > 1 && EMER_SLICE_THREADS == 1024 && hashed_items > owners && rem != 0u && filler < 0.5f * hole) {
+            if (dense_items == 0u) {   // (scheduling block experiment: only ever measured on a grid without dense levels)
+                if (EMER_SCHED_BLOCK_NOFILL == 16) p.sched_shift = 4u;
+                else if (EMER_SCHED_BLOCK_NOFILL == 8) p.sched_shift = 3u;
+            }
+            uint32_t best_r = 1; float best_t = 1.0f;
+            for (uint32_t r = 2; r <= 4u; r *= 2u) {
+                const float t = (float)((rem * r + owners - 1u) / owners) / (float)r;
+                if (t < best_t - 1e-6f) { best_t = t; best_r = r; }
+            }
+            if (EMER_TAIL_SPLIT != 2) best_r = (uint32_t)EMER_TAIL_SPLIT;   // (A/B builds force a factor; 2 = automatic)
+            uint32_t covered = 0;
+            for (uint32_t l = g->n_levels; l-- > 0u && covered < rem;) {
+                if (!g->hashed[l]) continue;
+                p.n_ranges[l] = best_r;
+                covered += p.n_slices[l];
             }
         }
     }
@@ -1283,7 +1297,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                                                                                    const uint64_t *__restrict__ masks,
                                                                                    uint32_t *__restrict__ work_ctr,
                                                                                    float *__restrict__ grad, int64_t N,
-                                                                                   uint32_t *__restrict__ pace, uint32_t pace_trips) {
+                                                                                   uint32_t *__restrict__ pace, uint32_t pace_trips, uint32_t accumulate) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ uint32_t s_item;
     // Persistent workgroups with XCD-affine work lists.  Each XCD has a list of (level, slice, range) items -- whole
@@ -1737,7 +1751,10 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // Several ranges (dense levels): the host zeroed the level; merge the non-zero entries with L2 atomics.
     float *__restrict__ out = grad + ((size_t)li.offset + first) * F;
     if (n_ranges == 1u) {
-        for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) out[i] = (float)acc[i];
+        // (accumulate: a further evaluation of the same table in this step ADDS to what the first one wrote -- every entry still has one
+        // owner, so a plain read-modify-write)
+        if (accumulate) { for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) out[i] += (float)acc[i]; }
+        else { for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) out[i] = (float)acc[i]; }
     } else {
         for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) {
             const float v = (float)acc[i];
@@ -2086,12 +2103,21 @@ extern "C" int emer_hashgrid_slice_masks(const emer_grid_desc *g, const float *x
 // once, so the caller does not zero the buffer.  The slice bitmaps come from emer_hashgrid_fwd (or
 // emer_hashgrid_slice_masks) for the SAME x.
 static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
-                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream);
+                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream,
+                                            bool accumulate = false);
 
 extern "C" int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
                                                int64_t sl, uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
     return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, 0u, g->n_levels, stream);
+}
+
+// [r5] grad += the table gradient of this evaluation (a further evaluation of the same encoder in one step: warped positions, chunked
+// training) -- the write-out adds instead of storing, so the caller needs no second 40 MB buffer and no add launch.
+extern "C" int emer_hashgrid_bwd_params_sliced_add(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
+                                                   int64_t sl, uint64_t *slice_masks, float *grad, int64_t n, void *stream) {
+    if (int rc = check_desc(g)) return rc;
+    return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, 0u, g->n_levels, stream, true);
 }
 
 // The same for the levels [level_begin, level_end) only: the entries of the other levels are neither read nor written.  Two calls
@@ -2130,7 +2156,8 @@ extern "C" int emer_hashgrid_sliced_split_level(const emer_grid_desc *g) {
 }
 
 static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn, int64_t sl,
-                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream) {
+                                            uint64_t *slice_masks, float *grad, int64_t n, uint32_t level_begin, uint32_t level_end, void *stream,
+                                            bool accumulate) {
     EMER_REQUIRE(n >= 0 && n < (1ll << 28), "hashgrid_bwd_params_sliced: n out of range (byte offsets of the gathers are 32-bit: n < 2^28)");
     EMER_REQUIRE(sn == (int64_t)g->n_features, "hashgrid_bwd_params_sliced: dout must be level-major with packed features (stride_n == n_features)");
     EMER_REQUIRE(x && dout && grad && slice_masks, "hashgrid_bwd_params_sliced: null pointer");
@@ -2168,7 +2195,7 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
     const uint32_t pace_trips = (EMER_PACE && n_trips <= 64u && n_blk <= 64u && n_trips > (uint32_t)EMER_PACE_LEAD) ? n_trips : 0u;
     zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = pace_trips ? 16u + 64u * 64u : 8u; ++zr.count;
     for (uint32_t l = level_begin; l < level_end; ++l) {
-        if (plan.n_ranges[l] > 1u) {
+        if (plan.n_ranges[l] > 1u && !accumulate) {   // (accumulate: the merging atomics add onto what is there)
             zr.p[zr.count] = grad + (size_t)g->offset[l] * F; zr.n[zr.count] = g->size[l] * F; ++zr.count;
         }
     }
@@ -2185,7 +2212,7 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
         if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
         const ProfileEvents ev = take_profile_events();
         EMER_LAUNCH_PROFILED(ev, kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
-                           slice_masks, work_ctr, grad, n, pace, pace_trips);
+                           slice_masks, work_ctr, grad, n, pace, pace_trips, accumulate ? 1u : 0u);
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }

@@ -188,7 +188,21 @@ struct RegArgs {
     const float *shadow; int64_t n_shadow; float c_shadow;
     const float *feat, *feat_gt; int64_t n_feat; float c_feat;
     const float *ff, *fpb, *bf, *bpf; int64_t n_flow; float c_cycle;
+    // [r5] packed != 0: ff = the flow MLP's output at the sample positions [n_flow / 3][6] = (forward | backward flow) and fpb = its output at
+    // the two warped sets [2 n_flow / 3][6] = (rows 0..N: at the forward-warped points, rows N..2N: at the backward-warped points); the four
+    // operands of the cycle term are column blocks of those two tensors (no slice copies, and ONE gradient tensor in the backward)
+    int32_t packed;
 };
+__device__ __forceinline__ void cycle_operands(const RegArgs &a, int64_t i, float &ff, float &fpb, float &bf, float &bpf) {
+    if (a.packed) {
+        const int64_t row = i / 3, n_rows = a.n_flow / 3;
+        const int c = (int)(i - 3 * row);
+        ff = a.ff[row * 6 + c]; bf = a.ff[row * 6 + 3 + c];
+        fpb = a.fpb[row * 6 + 3 + c]; bpf = a.fpb[(n_rows + row) * 6 + c];
+    } else {
+        ff = a.ff[i]; fpb = a.fpb[i]; bf = a.bf[i]; bpf = a.bpf[i];
+    }
+}
 
 constexpr int kRegThreads = 256;
 
@@ -213,7 +227,9 @@ __global__ __launch_bounds__(kRegThreads) void reg_losses_fwd_kernel(const RegAr
     if (a.fpb) {
         float s = 0.0f;
         for (int64_t i = tid; i < a.n_flow; i += stride) {
-            const float u = a.ff[i] + a.fpb[i], v = a.bf[i] + a.bpf[i];
+            float ff, fpb, bf, bpf;
+            cycle_operands(a, i, ff, fpb, bf, bpf);
+            const float u = ff + fpb, v = bf + bpf;
             s += u * u + v * v;
         }
         l += a.c_cycle / (float)a.n_flow * s;
@@ -262,7 +278,18 @@ __global__ __launch_bounds__(kRegThreads) void reg_losses_bwd_kernel(const RegAr
         const float g = up * (2.0f * a.c_feat / (float)a.n_feat);
         for (int64_t i = tid; i < a.n_feat; i += stride) d_feat[i] = g * (a.feat[i] - a.feat_gt[i]);
     }
-    if (d_fpb || d_bpf) {
+    if (a.packed && d_fpb) {   // d_fpb: the gradient of the whole [2 N][6] tensor (zero in the column blocks the loss does not read)
+        const float g = up * (2.0f * a.c_cycle / (float)a.n_flow);
+        const int64_t n_rows = a.n_flow / 3;
+        for (int64_t j = tid; j < 12 * n_rows; j += stride) {
+            const int64_t row2 = j / 6;
+            const int c = (int)(j - 6 * row2);
+            float v = 0.0f;
+            if (row2 < n_rows) { if (c >= 3) v = g * (a.ff[row2 * 6 + c - 3] + a.fpb[j]); }
+            else if (c < 3) v = g * (a.ff[(row2 - n_rows) * 6 + 3 + c] + a.fpb[j]);
+            d_fpb[j] = v;
+        }
+    } else if (d_fpb || d_bpf) {
         const float g = up * (2.0f * a.c_cycle / (float)a.n_flow);
         for (int64_t i = tid; i < a.n_flow; i += stride) {
             if (d_fpb) d_fpb[i] = g * (a.ff[i] + a.fpb[i]);
@@ -335,20 +362,20 @@ extern "C" int emer_lidar_loss(const float *depth, const float *lidar_ranges, co
 static inline RegArgs make_reg_args(const float *dyn, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
                                     const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *ff, const float *fpb,
                                     const float *bf, const float *bpf, int64_t n_flow, float c_cycle) {
-    return RegArgs{dyn, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, ff, fpb, bf, bpf, n_flow, c_cycle};
+    return RegArgs{dyn, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, ff, fpb, bf, bpf, n_flow, c_cycle, 0};
 }
 static inline uint32_t reg_blocks(const RegArgs &a) {
     int64_t n = 1;
     if (a.dyn && a.n_dyn > n) n = a.n_dyn;
     if (a.shadow && a.n_shadow > n) n = a.n_shadow;
     if (a.feat && a.n_feat > n) n = a.n_feat;
-    if (a.fpb && a.n_flow > n) n = a.n_flow;
+    if (a.fpb && a.n_flow * (a.packed ? 4 : 1) > n) n = a.n_flow * (a.packed ? 4 : 1);
     const int64_t b = ceil_div(n, (int64_t)kRegThreads * 4);   // >= 4 elements per thread; at most 1024 blocks
     return (uint32_t)(b < 1 ? 1 : b > EMER_REG_MAX_BLOCKS ? EMER_REG_MAX_BLOCKS : b);
 }
 static bool reg_args_ok(const RegArgs &a) {
     return (!a.dyn || a.n_dyn >= 1) && (!a.shadow || a.n_shadow >= 1) && (!a.feat || (a.feat_gt && a.n_feat >= 1)) &&
-           (!a.fpb || (a.ff && a.bf && a.bpf && a.n_flow >= 1));
+           (!a.fpb || (a.ff && (a.packed || (a.bf && a.bpf)) && a.n_flow >= 1));
 }
 
 extern "C" int emer_reg_losses_fwd(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
@@ -379,4 +406,38 @@ extern "C" int emer_reg_losses_bwd(const float *dyn_density, int64_t n_dyn, floa
     hipLaunchKernelGGL(reg_losses_bwd_kernel, dim3(reg_blocks(a)), dim3(kRegThreads), 0, as_stream(stream), a, upstream, grad_scale,
                        d_dyn_density, d_shadow, d_feat, d_fwd_pred_bwd_flow, d_bwd_pred_fwd_flow);
     return check_launch("reg_losses_bwd");
+}
+
+// [r5] The same pair with the flow cycle term read from the flow MLP's own outputs: flow6 [n_rows][6] (at the sample positions: forward |
+// backward flow, constants) and flow2_6 [2 n_rows][6] (at the forward-warped, then the backward-warped points: the predicted backward flow is
+// columns 3..5 of the first half, the predicted forward flow columns 0..2 of the second).  Same value as emer_reg_losses_fwd on the four
+// slices (same summation order); the backward writes the gradient of the WHOLE flow2_6 tensor.  flow2_6 == NULL: no cycle term.
+extern "C" int emer_reg_losses_fwd6(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
+                                    const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *flow6, const float *flow2_6,
+                                    int64_t n_rows, float c_cycle, const float *base, float *workspace, float *loss_out, void *stream) {
+    RegArgs a = make_reg_args(dyn_density, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, flow6, flow2_6, nullptr, nullptr,
+                              3 * n_rows, c_cycle);
+    a.packed = 1;
+    EMER_REQUIRE(reg_args_ok(a), "reg_losses_fwd6: a term's companion pointer is null or its count is < 1");
+    EMER_REQUIRE(workspace && loss_out, "reg_losses_fwd6: null pointer");
+    const uint32_t blocks = reg_blocks(a);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(reg_losses_fwd_kernel, dim3(blocks), dim3(kRegThreads), 0, st, a, workspace);
+    hipLaunchKernelGGL(reg_losses_finish_kernel, dim3(1), dim3(256), 0, st, workspace, (int32_t)blocks, base, loss_out);
+    return check_launch("reg_losses_fwd6");
+}
+
+extern "C" int emer_reg_losses_bwd6(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow, float c_shadow,
+                                    const float *feat, const float *feat_gt, int64_t n_feat, float c_feat, const float *flow6, const float *flow2_6,
+                                    int64_t n_rows, float c_cycle, const float *upstream, float grad_scale, float *d_dyn_density, float *d_shadow,
+                                    float *d_feat, float *d_flow2_6, void *stream) {
+    RegArgs a = make_reg_args(dyn_density, n_dyn, c_dyn, shadow, n_shadow, c_shadow, feat, feat_gt, n_feat, c_feat, flow6, flow2_6, nullptr, nullptr,
+                              3 * n_rows, c_cycle);
+    a.packed = 1;
+    EMER_REQUIRE(reg_args_ok(a), "reg_losses_bwd6: a term's companion pointer is null or its count is < 1");
+    EMER_REQUIRE((!d_dyn_density || n_dyn >= 1) && (!d_shadow || n_shadow >= 1) && (!d_feat || feat) && (!d_flow2_6 || flow2_6),
+                 "reg_losses_bwd6: gradient requested for an absent term");
+    hipLaunchKernelGGL(reg_losses_bwd_kernel, dim3(reg_blocks(a)), dim3(kRegThreads), 0, as_stream(stream), a, upstream, grad_scale,
+                       d_dyn_density, d_shadow, d_feat, d_flow2_6, (float *)nullptr);
+    return check_launch("reg_losses_bwd6");
 }

@@ -368,7 +368,9 @@ class _HashGridLMFn(torch.autograd.Function):
                 if gdt == torch.float32 and masks is not None:
                     param = ctx.param
                     direct = param is not None and getattr(param, "_emer_grad_fresh", False) and param.grad is not None
-                    grad = param.grad.view(-1) if direct else torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
+                    # [r5] a further evaluation of the same encoder in this step adds to the table's buffer in the kernel's write-out
+                    add = (not direct) and param is not None and param.grad is not None and param.grad.is_contiguous()
+                    grad = param.grad.view(-1) if (direct or add) else torch.empty(pc.numel(), device=xc.device, dtype=torch.float32)
                     # (the cut is taken only by the table's LAST backward of the step: an earlier one would start the collective of a range
                     # that a later backward of the same table still adds to)
                     split = getattr(ctx.param_obj, "_emer_table_split", None) if (direct and last) else None
@@ -382,10 +384,12 @@ class _HashGridLMFn(torch.autograd.Function):
                         _lib.call("emer_hashgrid_bwd_params_sliced_levels", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
                                   _ptr(grad), N, 0, k, st)
                     else:
-                        _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc), _ptr(dlm), F, N * F, _ptr(masks),
-                                  _ptr(grad), N, st)
+                        _lib.call("emer_hashgrid_bwd_params_sliced_add" if add else "emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), _ptr(xc),
+                                  _ptr(dlm), F, N * F, _ptr(masks), _ptr(grad), N, st)
                     if direct:
                         param._emer_grad_fresh = False
+                        grad = None
+                    elif add:
                         grad = None
                     elif param is not None and param.grad is not None:
                         param.grad.view(-1).add_(grad)  # a further evaluation of the same encoder in this step
@@ -864,15 +868,69 @@ class _RegLossesFn(torch.autograd.Function):
         return gb, d_dyn, d_sh, d_ft, None, None, d_fpb, None, d_bpf, None, None
 
 
+class _RegLosses6Fn(torch.autograd.Function):
+    """_RegLossesFn with the cycle term read from the flow MLP's own outputs: ``flow`` [N, 6] at the sample positions (constants, as the
+    reference detaches them) and ``flow2`` [2 N, 6] at the two warped sets -- no slice copies forward, ONE gradient tensor backward
+    (the four slices cost four contiguous copies, two zero fills, two copies and a cat per step)."""
+
+    @staticmethod
+    def forward(ctx, base: Optional[Tensor], dyn: Optional[Tensor], shadow: Optional[Tensor], feat: Optional[Tensor], feat_gt: Optional[Tensor],
+                flow: Tensor, flow2: Tensor, coefs, grad_scale: float):
+        c_dyn, c_shadow, c_feat, c_cycle = (float(c) for c in coefs)
+        dyn_c, sh_c, ft_c, gt_c = (None if t is None else _f32c(t) for t in (dyn, shadow, feat, feat_gt))
+        f6, f26 = _f32c(flow).view(-1, 6), _f32c(flow2).view(-1, 6)
+        assert f26.shape[0] == 2 * f6.shape[0], "flow cycle loss: the warped evaluations must hold two rows per sample"
+        if ft_c is not None:
+            assert gt_c is not None and gt_c.numel() == ft_c.numel(), "feature loss: prediction / target size mismatch"
+        n = lambda t: 0 if t is None else t.numel()
+        bc = None if base is None else _f32c(base).reshape(1)
+        dev = f6.device
+        with torch.cuda.device(dev):
+            ws = torch.empty((REG_MAX_BLOCKS,), device=dev, dtype=torch.float32)
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            ctx.args = (n(dyn_c), c_dyn, n(sh_c), c_shadow, n(ft_c), c_feat, f6.shape[0], c_cycle)
+            _lib.call("emer_reg_losses_fwd6", _ptr(dyn_c), n(dyn_c), c_dyn, _ptr(sh_c), n(sh_c), c_shadow, _ptr(ft_c), _ptr(gt_c), n(ft_c), c_feat,
+                      _ptr(f6), _ptr(f26), f6.shape[0], c_cycle, _ptr(bc), _ptr(ws), _ptr(loss), _stream(f6))
+        ctx.save_for_backward(ft_c, gt_c, f6, f26)
+        ctx.present = (dyn_c is not None, sh_c is not None)
+        ctx.shapes = tuple(None if t is None else t.shape for t in (dyn, shadow, feat, flow2))
+        ctx.grad_scale, ctx.dev = float(grad_scale), dev
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        ft_c, gt_c, f6, f26 = ctx.saved_tensors
+        n_dyn, c_dyn, n_sh, c_shadow, n_ft, c_feat, n_rows, c_cycle = ctx.args
+        ni = ctx.needs_input_grad
+        gc = _f32c(g).reshape(1)
+        with torch.cuda.device(ctx.dev):
+            new = lambda shape: torch.empty(shape, device=ctx.dev, dtype=torch.float32)
+            d_dyn = new(ctx.shapes[0]) if ctx.present[0] and ni[1] else None
+            d_sh = new(ctx.shapes[1]) if ctx.present[1] and ni[2] else None
+            d_ft = new(ctx.shapes[2]) if ft_c is not None and ni[3] else None
+            d_f2 = new(ctx.shapes[3]) if ni[6] else None
+            if any(t is not None for t in (d_dyn, d_sh, d_ft, d_f2)):
+                _lib.call("emer_reg_losses_bwd6", _ptr(d_dyn), n_dyn if d_dyn is not None else 0, c_dyn, _ptr(d_sh), n_sh if d_sh is not None else 0,
+                          c_shadow, _ptr(ft_c), _ptr(gt_c), n_ft, c_feat, _ptr(f6), _ptr(f26), n_rows, c_cycle, _ptr(gc), ctx.grad_scale,
+                          _ptr(d_dyn), _ptr(d_sh), _ptr(d_ft), _ptr(d_f2), _stream(gc))
+        gb = g if ni[0] else None
+        return gb, d_dyn, d_sh, d_ft, None, None, d_f2, None, None
+
+
 def reg_losses(base: Optional[Tensor] = None, dynamic_density: Optional[Tensor] = None, shadow_ratio: Optional[Tensor] = None,
                feat: Optional[Tensor] = None, feat_gt: Optional[Tensor] = None, forward_flow: Optional[Tensor] = None,
                forward_pred_backward_flow: Optional[Tensor] = None, backward_flow: Optional[Tensor] = None,
                backward_pred_forward_flow: Optional[Tensor] = None, c_dyn: float = 0.01, c_shadow: float = 0.01, c_feat: float = 0.5,
-               c_cycle: float = 0.005, grad_scale: float = 1.0) -> Tensor:
+               c_cycle: float = 0.005, grad_scale: float = 1.0, flow_pair=None) -> Tensor:
     """``base + c_dyn mean(dynamic_density) + c_shadow mean(shadow_ratio) + c_feat mse(feat, feat_gt) + c_cycle mean((ff + fpb)^2 +
     (bf + bpf)^2)`` as a 0-dim tensor: loss/base.py:394-398 (sparsity), :83-146 (feature L2), train_emernerf.py:700-716 (cycle;
     forward_flow / backward_flow are constants, as the reference detaches them).  Absent terms are None.  ``grad_scale`` multiplies
     the regularisers' GRADIENTS only (``base`` passes its gradient through unscaled: its own kernel already folded the scale)."""
+    if flow_pair is not None:
+        # [r5] (flow at the samples [., 6], flow at the two warped sets [2 N, 6]): the four flow arguments are column blocks of this pair
+        flow, flow2 = flow_pair
+        _check_cuda(*[t for t in (base, dynamic_density, shadow_ratio, feat, feat_gt, flow, flow2) if t is not None])
+        return _RegLosses6Fn.apply(base, dynamic_density, shadow_ratio, feat, feat_gt, flow.detach(), flow2, (c_dyn, c_shadow, c_feat, c_cycle), grad_scale)
     present = [t for t in (dynamic_density, shadow_ratio, feat, forward_pred_backward_flow) if t is not None]
     if not present:
         if base is None:

@@ -519,6 +519,9 @@ class RadianceField(nn.Module):
         out = {"forward_flow": forward_flow, "backward_flow": backward_flow,
                "dynamic_feats": dyn, "_dynamic_density": dyn_density,
                "forward_pred_backward_flow": fwd_pred[..., 3:], "backward_pred_forward_flow": bwd_pred[..., :3]}
+        # [r5] the cycle loss reads its four operands as column blocks of these two tensors (ops.reg_losses(flow_pair=...)).  The result
+        # dictionary keeps the reference's keys exactly, so the pair rides along as an attribute of one of the four views
+        out["forward_pred_backward_flow"]._emer_flow_pair = (flow, flow2)
         if want_hash:  # row-major copies of the encodings: part of forward()'s contract (:453-459, 615-617), consumed by nobody
             cur_h, fwd_h, bwd_h = (t.view(*lead, -1) for t in ops.lm_to_rm(enc3).split(N, dim=0))
             out.update({"forward_dynamic_hash_encodings": fwd_h, "backward_dynamic_hash_encodings": bwd_h,

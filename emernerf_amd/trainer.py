@@ -373,6 +373,11 @@ class Trainer:
         ex = results["extras"]
         flows = "forward_flow" in ex
         feat = "dino_feat" in results and "features" in data
+        pair = getattr(ex["forward_pred_backward_flow"], "_emer_flow_pair", None) if flows else None
+        if pair is not None:   # batched flow branch: the cycle term from the flow MLP's two outputs, unsliced
+            return ops.reg_losses(base, dynamic_density=ex.get("dynamic_density"), shadow_ratio=results.get("shadow_ratio"),
+                                  feat=results["dino_feat"] if feat else None, feat_gt=data["features"] if feat else None,
+                                  flow_pair=pair, c_dyn=0.01, c_shadow=0.01, c_feat=0.5, c_cycle=0.01 * 0.5, grad_scale=grad_scale)
         return ops.reg_losses(base, dynamic_density=ex.get("dynamic_density"), shadow_ratio=results.get("shadow_ratio"),
                               feat=results["dino_feat"] if feat else None, feat_gt=data["features"] if feat else None,
                               forward_flow=ex["forward_flow"] if flows else None,

@@ -107,6 +107,11 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
                                     const float *dout, int64_t dout_stride_n,
                                     int64_t dout_stride_l, uint64_t *slice_masks,
                                     float *grad, int64_t n, void *stream);
+/* [r5] emer_hashgrid_bwd_params_sliced that ADDS to grad instead of overwriting it: the second and later evaluations of one encoder in
+ * a step (the flow table is evaluated at the sample positions and at the warped positions, radiance_field.py:553-620; chunked training).
+ * Replaces a table-sized temporary and autograd's add. */
+int emer_hashgrid_bwd_params_sliced_add(const emer_grid_desc *g, const float *x, const float *dout, int64_t stride_n,
+                                        int64_t stride_l, uint64_t *slice_masks, float *grad, int64_t n, void *stream);
 /* The same for the levels [level_begin, level_end) only (a contiguous range of the table: entries offset[level_begin] ..): the other
  * levels' entries are neither read nor written.  Calls that partition the levels give the one-call result; a data-parallel trainer
  * starts the collective of the first call's range while the second call computes. */
@@ -341,6 +346,21 @@ int emer_reg_losses_bwd(const float *dyn_density, int64_t n_dyn, float c_dyn, co
                         const float *bwd_pred_fwd_flow, int64_t n_flow, float c_cycle, const float *upstream,
                         float grad_scale, float *d_dyn_density, float *d_shadow, float *d_feat,
                         float *d_fwd_pred_bwd_flow, float *d_bwd_pred_fwd_flow, void *stream);
+/* [r5] The same pair with the cycle term read straight from the flow MLP's outputs (no slice copies, ONE gradient tensor): flow6
+ * [n_rows][6] = (forward | backward flow) at the sample positions (constants), flow2_6 [2 n_rows][6] = the flow at the
+ * forward-warped points (rows 0..n_rows: its columns 3..5 are forward_pred_backward_flow) and at the backward-warped points (rows
+ * n_rows..: columns 0..2 are backward_pred_forward_flow), radiance_field.py:585-592, train_emernerf.py:700-716.  Same value and
+ * summation order as emer_reg_losses_fwd on the four slices; d_flow2_6 [2 n_rows][6] is written entirely (zeros in the unread
+ * column blocks).  flow2_6 == NULL: no cycle term. */
+int emer_reg_losses_fwd6(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow,
+                         float c_shadow, const float *feat, const float *feat_gt, int64_t n_feat, float c_feat,
+                         const float *flow6, const float *flow2_6, int64_t n_rows, float c_cycle, const float *base,
+                         float *workspace, float *loss_out, void *stream);
+int emer_reg_losses_bwd6(const float *dyn_density, int64_t n_dyn, float c_dyn, const float *shadow, int64_t n_shadow,
+                         float c_shadow, const float *feat, const float *feat_gt, int64_t n_feat, float c_feat,
+                         const float *flow6, const float *flow2_6, int64_t n_rows, float c_cycle, const float *upstream,
+                         float grad_scale, float *d_dyn_density, float *d_shadow, float *d_feat, float *d_flow2_6,
+                         void *stream);
 /* Lidar-ray supervision (train_emernerf.py:770-808): depth loss (loss/base.py:188-271, "l2", normalised by max_depth,
  * mean over rays with 0.01 < range < max_depth) + line-of-sight loss (loss/base.py:430-464: empty-space and near-surface
  * terms with margin epsilon, times the fraction of rays with range > 0).

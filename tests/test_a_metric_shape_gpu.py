@@ -186,6 +186,35 @@ def test_hashgrid_sliced_level_ranges_partition_the_launch(hip_lib, oracle, name
         assert d <= 1e-6 * one.abs().max().item(), f"{name}: split at level {k}: {d:.3e}"
 
 
+@pytest.mark.parametrize("name", ["cfg2_static", "flow_xyzt", "default_static", "prop1"])
+def test_hashgrid_sliced_add_accumulates(hip_lib, oracle, name):
+    """emer_hashgrid_bwd_params_sliced_add (a table's second evaluation in a step) adds its gradient to what the buffer holds: after
+    sliced(x1, d1) and sliced_add(x2, d2) the buffer equals the two single-launch gradients summed -- on the levels written with plain
+    stores as on the ones merged with atomics (dense levels, the xyzt tables' half-size tail items)."""
+    from emernerf_amd import _lib, ops
+    meta, desc = _mk(oracle, name)
+    D, L, F = meta.n_dims, meta.n_levels, meta.n_features
+    dev = _dev()
+    N1, N2 = 1 << 16, (1 << 15) + 77
+    xs = _positions("training", D, 0)
+    x1, x2 = xs[:N1].contiguous().to(dev), xs[N1:N1 + N2].contiguous().to(dev)
+    g = torch.Generator().manual_seed(8)
+    p = (torch.rand(meta.n_params, generator=g) - 0.5).to(dev)
+    d1, d2 = torch.randn(L, N1, F, generator=g).to(dev), torch.randn(L, N2, F, generator=g).to(dev)
+    _, m1 = ops.hashgrid_fwd_raw(desc, x1, p, level_major=True, want_masks=True)
+    _, m2 = ops.hashgrid_fwd_raw(desc, x2, p, level_major=True, want_masks=True)
+    st = ops._stream(x1)
+    a, b = torch.empty(meta.n_params, device=dev), torch.empty(meta.n_params, device=dev)
+    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x1), ops._ptr(d1), F, N1 * F, ops._ptr(m1), ops._ptr(a), N1, st)
+    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x2), ops._ptr(d2), F, N2 * F, ops._ptr(m2), ops._ptr(b), N2, st)
+    both = torch.full((meta.n_params,), float("nan"), device=dev)
+    _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(x1), ops._ptr(d1), F, N1 * F, ops._ptr(m1), ops._ptr(both), N1, st)
+    _lib.call("emer_hashgrid_bwd_params_sliced_add", ctypes.byref(desc), ops._ptr(x2), ops._ptr(d2), F, N2 * F, ops._ptr(m2), ops._ptr(both), N2, st)
+    torch.cuda.synchronize()
+    want = a.double() + b.double()
+    assert float((both.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 # ------------------------------------------------------------------------------------------ fused heads
 @pytest.mark.parametrize("rgbw", ["tile", "paired", "streamed"])
 def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):

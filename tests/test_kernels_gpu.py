@@ -614,6 +614,37 @@ def test_reg_losses_match_the_reference_expressions(hip_lib, R, S, E, terms):
     assert torch.equal(again, out.detach())
 
 
+@pytest.mark.parametrize("R,S,terms", [(64, 16, "dsc"), (333, 7, "c"), (2048, 128, "dc")])
+def test_reg_losses_flow_pair_equals_the_four_slices(hip_lib, R, S, terms):
+    """ops.reg_losses(flow_pair=(flow [R,S,6], flow2 [2 R S, 6])) -- the cycle term read from the flow MLP's own outputs
+    (emer_reg_losses_fwd6 / bwd6) -- gives BITWISE the loss of the four-slice form (same summation order) and the same gradient,
+    delivered as one [2 N, 6] tensor with zeros in the column blocks the loss does not read; the flow at the samples gets none."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + S)
+    N = R * S
+    base = torch.rand((), generator=g).to(dev)
+    dyn, sh = (torch.rand(R, S, generator=g) * 3).to(dev), torch.rand(R, 1, generator=g).to(dev)
+    flow = (torch.randn(R, S, 6, generator=g) * 0.3).to(dev).requires_grad_(True)
+    flow2 = (torch.randn(2 * N, 6, generator=g) * 0.3).to(dev).requires_grad_(True)
+    kw = {}
+    if "d" in terms:
+        kw["dynamic_density"] = dyn
+    if "s" in terms:
+        kw["shadow_ratio"] = sh
+    out = ops.reg_losses(base, grad_scale=1024.0, flow_pair=(flow, flow2), **kw)
+    out.backward()
+    f_ref, f2_ref = flow.detach().clone().requires_grad_(True), flow2.detach().clone().requires_grad_(True)
+    fwd_pred, bwd_pred = (t.view(R, S, 6) for t in f2_ref.split(N, dim=0))
+    want = ops.reg_losses(base, grad_scale=1024.0, forward_flow=f_ref[..., :3], backward_flow=f_ref[..., 3:],
+                          forward_pred_backward_flow=fwd_pred[..., 3:], backward_pred_forward_flow=bwd_pred[..., :3], **kw)
+    want.backward()
+    assert torch.equal(out.detach(), want.detach()), "same terms in the same order: the loss must be bitwise the sliced form's"
+    assert flow.grad is None and f_ref.grad is None
+    assert torch.equal(flow2.grad, f2_ref.grad)
+    assert float(flow2.grad[:N, :3].abs().max()) == 0.0 and float(flow2.grad[N:, 3:].abs().max()) == 0.0
+
+
 def test_reg_losses_argument_errors(hip_lib):
     from emernerf_amd import _lib, ops
     dev = _dev()
