@@ -456,6 +456,7 @@ class Trainer:
             return  # one reduce-scatter per group after the backward
         if self._dp_on and self.dp_debug and not self._early_done and not self._hold_buckets:
             # debug: record what the early ranges hold NOW instead of reducing them; _exchange_grads checks nothing wrote later
+            fused.join_side_stream()   # (as the real bucket does: launches moved to a side stream count as enqueued)
             self._early_snapshot = [self.flat.grads[a:b].clone() for a, b in self._early_ranges]
             return
         if self._dp_on and not self._early_done and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
