@@ -624,8 +624,8 @@ __device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const
 #define EMER_NECKW_WPS1_KT 5
 #endif
 constexpr int neckw_threads(int kt0) { return kt0 >= EMER_NECKW_WPS1_KT ? 256 : 512; }
-constexpr int kWThreads = 512;  // fused backward: 8 waves, ONE workgroup per CU = 2 waves per SIMD (<= 256 registers); the weights (48-72 KB) are
-                                // staged once per CU and leave room for 7-10 KB of per-wave staging
+// (512 threads = 8 waves, ONE workgroup per CU = 2 waves per SIMD, <= 256 registers; the weights, 48-72 KB, are staged once per CU and
+// leave room for 7-10 KB of per-wave staging)
 
 struct NeckBwdWArgs {
     const float *d0;     // [n][64] gradient of output features 0..63 (null: zero)
