@@ -96,7 +96,7 @@ SIGNATURES = {
     "emer_neck_fwd": [_P, c_int32, c_int32, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P],
     "emer_neck_bwd": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P],
     "emer_neck_bwd_fused_supported": [c_int32, c_int32, c_int32, c_int32],
-    "emer_neck_bwd_fused": [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
+    "emer_neck_bwd_fused": [_P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P],
     "emer_rmlp_supported": [c_int32, c_int32, c_int32, c_int32, c_int32],
     "emer_rmlp_fwd": [_P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int64, _P],
     "emer_rmlp_bwd": [_P, c_int64, _P, _P, c_int32, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, c_int32, _P, _P, _P, c_int64, _P],

@@ -623,56 +623,62 @@ __device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const
 #ifndef EMER_NECKW_WPS1_KT
 #define EMER_NECKW_WPS1_KT 5
 #endif
-constexpr int neckw_threads(int kt0) { return kt0 >= EMER_NECKW_WPS1_KT ? 256 : 512; }
+constexpr int neckw_threads(int kt0, int no = 1) { return (no == 2 || kt0 >= EMER_NECKW_WPS1_KT) ? 256 : 512; }
 // (512 threads = 8 waves, ONE workgroup per CU = 2 waves per SIMD, <= 256 registers; the weights, 48-72 KB, are staged once per CU and
 // leave room for 7-10 KB of per-wave staging)
 
 struct NeckBwdWArgs {
     const float *d0;     // [n][64] gradient of output features 0..63 (null: zero)
+    const float *d1;     // [n][64] gradient of output features 64..127 (128-output necks; null: zero)
     const float *ddens;  // [n] gradient of the density (null: none)
     const float *dens;   // [n] saved density
     const float *enc;    // level-major [L][n][F]: the forward's input (operand of dW0; the hidden layer is recomputed from it)
     const float *b0;     // [64] bias of the first layer
     int64_t n; int32_t n_levels, k0;
-    WSrc w1t, w0t, w0;   // W1^T (64 x 64), W0^T (K0 x 64), W0 (64 x K0, for the recomputation)
+    WSrc w1t, w0t, w0;   // W1^T (64 x 64, or 64 x 128 for the 128-output neck), W0^T (K0 x 64), W0 (64 x K0, for the recomputation)
     float *denc;         // level-major [L][n][F]
-    float *partials;     // [gridDim.x][stride]: dW1 [64][64] | db1 [64] | dW0 [64][k0] | db0 [64]
+    float *partials;     // [gridDim.x][stride]: dW1 [64 NO][64] | db1 [64 NO] | dW0 [64][k0] | db0 [64]
     int64_t stride;
 };
 
-template <int KT0, int F>
-__global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 : 2) void neck_bwdw_kernel(const NeckBwdWArgs a) {
+// NO = 1: 64 outputs (geometry features).  NO = 2 [r5]: the 128-output neck of the feature configs (geometry | semantic features): dW1 [128][64]
+// as eight 32 x 32 blocks -- 192 accumulator registers with dW0, so four waves, one per SIMD (neckw_threads).
+template <int KT0, int F, int NO = 1>
+__global__ __launch_bounds__((neckw_threads(KT0, NO)), (neckw_threads(KT0, NO) == 256 ? 1 : 2)) void neck_bwdw_kernel(const NeckBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2;
-    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2), *w0fl = w1l + w3_units(4, 2);
+    u32x4 *w0l = smem, *w1l = w0l + w3_units(KT0, 2), *w0fl = w1l + w3_units(4, 2 * NO);
     float *b0l = reinterpret_cast<float *>(w0fl + w3_units(4, KS0));
     stage_w3(w0l, KT0, 2, a.w0t);
-    stage_w3(w1l, 4, 2, a.w1t);
+    stage_w3(w1l, 4, 2 * NO, a.w1t);
     stage_w3(w0fl, 4, KS0, a.w0);
     stage_b(b0l, 64, a.b0, 64);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2, lane), w0fp = w3_at(w0fl, 4, KS0, lane);
+    const W3 w0p = w3_at(w0l, KT0, 2, lane), w1p = w3_at(w1l, 4, 2 * NO, lane), w0fp = w3_at(w0fl, 4, KS0, lane);
     const SelE sel = make_sel(lane);
     // [r4] dW1 [64][64] and dW0 [64][K0P] as 32 x 32 blocks on v_mfma_f32_32x32x16_bf16 (one instruction per block and partial product
     // where the 16 x 16 x 16 shape needed four at the same issue cost each; operands: two transposer outputs joined by v_permlane16_swap,
     // see block32): lane (j, h), register r = dW[32 P + 8 (r >> 2) + 4 h + (r & 3)][32 Q + j]
     constexpr int QB = (KT0 + 1) / 2;   // 32-feature blocks of the encoding (the last one half empty when KT0 is odd)
-    f32x16 bw1[2][2], bw0[2][QB];
-    float ab1[4], ab0[4];           // bias gradients: this lane's rows 4 g .. 4 g + 3 of feature 16 p + m
+    f32x16 bw1[2 * NO][2], bw0[2][QB];
+    float ab1[4 * NO], ab0[4];      // bias gradients: this lane's rows 4 g .. 4 g + 3 of feature 16 p + m
 #pragma unroll
-    for (int P = 0; P < 2; ++P) {
+    for (int P = 0; P < 2 * NO; ++P)
 #pragma unroll
         for (int Q = 0; Q < 2; ++Q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) bw1[P][Q][r] = 0.0f;
 #pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
         for (int Q = 0; Q < QB; ++Q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) bw0[P][Q][r] = 0.0f;
-    }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { ab1[p] = 0.0f; ab0[p] = 0.0f; }
+    for (int p = 0; p < 4 * NO; ++p) ab1[p] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ab0[p] = 0.0f;
     // Each wave owns a contiguous range of 16-row tiles.  With two waves per SIMD nothing else hides the HBM latency, so the
     // inputs of tile t + 1 are in flight while tile t is in the matrix pipe -- WITHOUT holding them in registers (the
     // accumulators leave none: a register prefetch was spilled to scratch by the compiler, i.e. loaded, waited for and
@@ -686,8 +692,8 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
     const int64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
     const int64_t t_begin = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * per_wave;
     const int64_t t_end = t_begin + per_wave < n_tiles ? t_begin + per_wave : n_tiles;
-    float *stg = b0l + 64 + wave * (1024 + 384 * KT0);   // per wave: d0 tile [4][64][4] | parked enc operand tiles [KT0][3][64][2]
-    u32x2 *park = reinterpret_cast<u32x2 *>(stg + 1024) + lane;
+    float *stg = b0l + 64 + wave * (1024 * NO + 384 * KT0);   // per wave: d0 (| d1) tile [4 NO][64][4] | parked enc operand tiles [KT0][3][64][2]
+    u32x2 *park = reinterpret_cast<u32x2 *>(stg + 1024 * NO) + lane;
     using gptr = const __attribute__((address_space(1))) void *;
     using lptr = __attribute__((address_space(3))) void *;
     f32x4 xn[KT0];
@@ -701,11 +707,16 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
 #pragma unroll
             for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(d0 + (o64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
         }
+        if (NO == 2 && a.d1) {
+            const float *d1 = a.d1 + row0 * 64;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(d1 + (o64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
+        }
         ld_lm_t<KT0, F>(a.enc + row0 * F, (unsigned)a.n, a.n_levels, mrow, g, xn);
         ddn = a.ddens ? (a.ddens + row0)[mrow] : 0.0f;
         den = a.ddens ? (a.dens + row0)[mrow] : 0.0f;
     };
-    struct Raw { f32x4 d[4], x[KT0]; float dd, de; };
+    struct Raw { f32x4 d[4 * NO], x[KT0]; float dd, de; };
     if (t_begin < t_end) issue(t_begin);
     // [r4] denc of a tile is stored at the START of the next tile, behind that tile's wait: stores count in vmcnt like loads here, so a
     // store issued mid-tile would still be in flight at the next `s_waitcnt vmcnt(0)` and the wave would sit out its acknowledgement
@@ -718,6 +729,11 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             cur.d[p] = a.d0 ? *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (NO == 2) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                cur.d[4 + p] = a.d1 ? *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
         for (int b = 0; b < KT0; ++b) cur.x[b] = xn[b];
         cur.dd = ddn; cur.de = den;
@@ -761,16 +777,16 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
             zero<4>(da);
             {
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4 * NO; ++p)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) cur.d[p][i] = ok ? cur.d[p][i] : 0.0f;
                 if (g == 0) cur.d[0][0] += fix;
-                Opd<2> dop;
-                make_opd<4>(cur.d, dop);
-                tgemm<2, 4, false>(w1p, dop, da);
+                Opd<2 * NO> dop;
+                make_opd<4 * NO>(cur.d, dop);
+                tgemm<2 * NO, 4, false>(w1p, dop, da);
 #pragma unroll
-                for (int P = 0; P < 2; ++P) {   // dW1 rows 32 P .. += d^T h1
-                    const SwT t0 = to_rows<2>(dop, 2 * P, sel, &ab1[2 * P]), t1 = to_rows<2>(dop, 2 * P + 1, sel, &ab1[2 * P + 1]);
+                for (int P = 0; P < 2 * NO; ++P) {   // dW1 rows 32 P .. += d^T h1
+                    const SwT t0 = to_rows<2 * NO>(dop, 2 * P, sel, &ab1[2 * P]), t1 = to_rows<2 * NO>(dop, 2 * P + 1, sel, &ab1[2 * P + 1]);
                     dw_blocks<2>(bw1[P], block32(t0, t1), hq);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -809,18 +825,17 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
     if (tile_prev >= 0) st_lm_t<KT0, F>(a.denc + tile_prev * 16 * F, (unsigned)a.n, a.n_levels, (unsigned)m, tile_prev * 16 + m < a.n, g, dep);
     // ---- sum the waves through LDS (the weights are dead: the buffer takes their place), one coalesced partial per workgroup
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);   // dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
-    float *r1 = red, *rb1 = r1 + 64 * 64, *r0 = rb1 + 64, *rb0 = r0 + 64 * K0P;
+    float *red = reinterpret_cast<float *>(smem);   // dW1 [64 NO][64] | db1 [64 NO] | dW0 [64][K0P] | db0 [64]
+    float *r1 = red, *rb1 = r1 + 64 * NO * 64, *r0 = rb1 + 64 * NO, *rb0 = r0 + 64 * K0P;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {   // bias: rows 4 g .. 4 g + 3 of the four lane groups -> every lane holds the column sum
-        ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64);
-        ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64);
-    }
+    for (int p = 0; p < 4 * NO; ++p) { ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64); }   // bias: every lane holds the column sum
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { ab0[p] += __shfl_xor(ab0[p], 16, 64); ab0[p] += __shfl_xor(ab0[p], 32, 64); }
     const int j32 = lane & 31, h32 = lane >> 5;
-    for (int w = 0; w < neckw_threads(KT0) / 64; ++w) {
+    for (int w = 0; w < neckw_threads(KT0, NO) / 64; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int P = 0; P < 2; ++P) {
+            for (int P = 0; P < 2 * NO; ++P)
 #pragma unroll
                 for (int Q = 0; Q < 2; ++Q)
 #pragma unroll
@@ -828,6 +843,8 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
                         float *q = r1 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * 64 + 32 * Q + j32;
                         *q = (w == 0) ? bw1[P][Q][r] : *q + bw1[P][Q][r];
                     }
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
 #pragma unroll
                 for (int Q = 0; Q < QB; ++Q)
 #pragma unroll
@@ -838,18 +855,18 @@ __global__ __launch_bounds__(neckw_threads(KT0), neckw_threads(KT0) == 256 ? 1 :
                         }
                     }
             }
+            if (g == 0) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (g == 0) {
-                    rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
-                    rb0[16 * p + m] = (w == 0) ? ab0[p] : rb0[16 * p + m] + ab0[p];
-                }
+                for (int p = 0; p < 4 * NO; ++p) rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rb0[16 * p + m] = (w == 0) ? ab0[p] : rb0[16 * p + m] + ab0[p];
+            }
         }
         __syncthreads();
     }
     float *part = a.partials + (int64_t)blockIdx.x * a.stride;
-    for (int i = threadIdx.x; i < 64 * 64 + 64; i += (int)blockDim.x) part[i] = red[i];
-    float *part0 = part + 64 * 64 + 64;
+    for (int i = threadIdx.x; i < 64 * NO * 65; i += (int)blockDim.x) part[i] = red[i];
+    float *part0 = part + 64 * NO * 65;
     for (int i = threadIdx.x; i < 64 * a.k0; i += (int)blockDim.x) { const int nn = i / a.k0, kk = i - nn * a.k0; part0[i] = r0[nn * K0P + kk]; }
     for (int i = threadIdx.x; i < 64; i += (int)blockDim.x) part0[64 * a.k0 + i] = rb0[i];
 }
@@ -2102,32 +2119,35 @@ struct RMlpBwdWArgs {
     float *partials; int64_t stride;  // [gridDim.x][stride]: dW_last [n_out][64] | db_last [n_out] | (dW1 [64][64] | db1 [64]) | dW0 [64][k0] | db0 [64]
 };
 
-template <int NL> constexpr int rmlp_w_threads() { return NL == 3 ? 256 : 512; }
+template <int NL, int NTO> constexpr int rmlp_w_threads() { return (NL == 3 || NTO == 4) ? 256 : 512; }
 
-template <int KT0, int F, int NL>
-__global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bwdw_kernel(const RMlpBwdWArgs a) {
+// NTO = 1: outputs up to 16 wide (dW_last as four 16 x 16 tiles); NTO = 4 [r5]: outputs up to 64 wide (the feature heads' 64 -> 64 -> 64 -> E:
+// dW_last as 32 x 32 blocks like dW1 -- 192 accumulator registers, one wave per SIMD)
+template <int KT0, int F, int NL, int NTO>
+__global__ __launch_bounds__((rmlp_w_threads<NL, NTO>()), (rmlp_w_threads<NL, NTO>() == 256 ? 1 : 2)) void rmlp_bwdw_kernel(const RMlpBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-    constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2, QB = (KT0 + 1) / 2, NW = rmlp_w_threads<NL>() / 64;
-    u32x4 *w0fl = smem, *w1fl = w0fl + w3_units(4, KS0), *wltl = w1fl + (NL == 3 ? w3_units(4, 2) : 0), *w1tl = wltl + w3_units(4, 1),
+    constexpr int K0P = 16 * KT0, KS0 = (KT0 + 1) / 2, QB = (KT0 + 1) / 2, NW = rmlp_w_threads<NL, NTO>() / 64, KSL = (NTO + 1) / 2;
+    u32x4 *w0fl = smem, *w1fl = w0fl + w3_units(4, KS0), *wltl = w1fl + (NL == 3 ? w3_units(4, 2) : 0), *w1tl = wltl + w3_units(4, KSL),
           *w0tl = w1tl + (NL == 3 ? w3_units(4, 2) : 0);
     float *b0l = reinterpret_cast<float *>(w0tl + w3_units(KT0, 2)), *b1l = b0l + 64;
     stage_w3(w0fl, 4, KS0, a.w0);
     if (NL == 3) stage_w3(w1fl, 4, 2, a.w1);
-    stage_w3(wltl, 4, 1, a.wlt);
+    stage_w3(wltl, 4, KSL, a.wlt);
     if (NL == 3) stage_w3(w1tl, 4, 2, a.w1t);
     stage_w3(w0tl, KT0, 2, a.w0t);
     stage_b(b0l, 64, a.b0, 64);
     if (NL == 3) stage_b(b1l, 64, a.b1, 64);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const W3 w0fp = w3_at(w0fl, 4, KS0, lane), w1fp = w3_at(w1fl, 4, 2, lane), wlp = w3_at(wltl, 4, 1, lane), w1tp = w3_at(w1tl, 4, 2, lane),
+    const W3 w0fp = w3_at(w0fl, 4, KS0, lane), w1fp = w3_at(w1fl, 4, 2, lane), wlp = w3_at(wltl, 4, KSL, lane), w1tp = w3_at(w1tl, 4, 2, lane),
              w0tp = w3_at(w0tl, KT0, 2, lane);
     const SelE sel = make_sel(lane);
-    // accumulators: dW_last [16][64] as 16 x 16 tiles (lane (j, g), register r: row 4 g + r, column 16 b + j); dW1 [64][64] and
-    // dW0 [64][K0P] as 32 x 32 blocks (lane (j, h), register r: row 32 P + 8 (r >> 2) + 4 h + (r & 3), column 32 Q + j)
+    // accumulators: dW_last [16][64] as 16 x 16 tiles (NTO = 1: lane (j, g), register r: row 4 g + r, column 16 b + j) or [64][64] as 32 x 32
+    // blocks (NTO = 4); dW1 [64][64] and dW0 [64][K0P] as 32 x 32 blocks (lane (j, h), register r: row 32 P + 8 (r >> 2) + 4 h + (r & 3),
+    // column 32 Q + j)
     f32x4 bwl[1][4];
-    f32x16 bw1[NL == 3 ? 2 : 1][2], bw0[2][QB];
-    float abl = 0.0f, ab1[4], ab0[4];
+    f32x16 bwlb[NTO == 4 ? 2 : 1][2], bw1[NL == 3 ? 2 : 1][2], bw0[2][QB];
+    float abl[NTO], ab1[4], ab0[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) bwl[0][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -2135,8 +2155,10 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
 #pragma unroll
         for (int Q = 0; Q < 2; ++Q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
                 if (NL == 3) bw1[NL == 3 ? P : 0][Q][r] = 0.0f;
+                if (NTO == 4) bwlb[NTO == 4 ? P : 0][Q][r] = 0.0f;
+            }
 #pragma unroll
         for (int Q = 0; Q < QB; ++Q)
 #pragma unroll
@@ -2144,6 +2166,8 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) { ab1[p] = 0.0f; ab0[p] = 0.0f; }
+#pragma unroll
+    for (int p = 0; p < NTO; ++p) abl[p] = 0.0f;
     const int64_t n_tiles = (a.n + 15) >> 4, n_waves = (int64_t)gridDim.x * NW;
     const int64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
     const int64_t t_begin = ((int64_t)blockIdx.x * NW + wave) * per_wave;
@@ -2151,20 +2175,29 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
     float *stg = b1l + 64 + wave * (384 * KT0);   // per wave: the x operand tiles with the rows on the reduction index [KT0][3][64][2]
     u32x2 *park = reinterpret_cast<u32x2 *>(stg) + lane;
     const bool sig = a.final_act == EMER_ACT_SIGMOID;
-    // next tile's inputs ride in registers (x: KT0 x 16 bytes, dout / out: the lane's four columns of its row; lanes whose columns lie
-    // beyond n_out load nothing); loads are unconditional in the row (rows past the end re-read row n - 1 and are zeroed at use)
-    f32x4 xn[KT0], dn, on;
+    // next tile's inputs ride in registers (x: KT0 x 16 bytes, dout / out: the lane's columns of its row; lanes whose columns lie beyond
+    // n_out load nothing); loads are unconditional in the row (rows past the end re-read row n - 1 and are zeroed at use)
+    f32x4 xn[KT0], dn[NTO], on[NTO];
     auto issue = [&](int64_t tile) {
         const int64_t row0 = tile * 16;
         const int64_t row = row0 + m < a.n ? row0 + m : a.n - 1;
         if constexpr (F == 0) ld_rm_k<KT0>(a.x + row * a.ldx, true, g, a.k0, xn);
         else ld_lm_t<KT0, F>(a.x + row0 * F, (unsigned)a.n, a.n_levels, (unsigned)(row - row0), g, xn);
         const float *dp = a.dout + row * a.ldd, *op = a.out + row * a.ldo;
+        if constexpr (NTO == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool col = 4 * g + i < a.n_out;
-            dn[i] = col ? dp[4 * g + i] : 0.0f;
-            on[i] = (col && sig) ? op[4 * g + i] : 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                const bool col = 4 * g + i < a.n_out;
+                dn[0][i] = col ? dp[4 * g + i] : 0.0f;
+                on[0][i] = (col && sig) ? op[4 * g + i] : 0.0f;
+            }
+        } else {   // wide outputs: n_out and the leading dimensions are multiples of 4 (host check): 16-byte loads
+            ld_rm_k<NTO>(dp, true, g, a.n_out, dn);
+            if (sig) ld_rm_k<NTO>(op, true, g, a.n_out, on);
+            else {
+#pragma unroll
+                for (int p = 0; p < NTO; ++p) on[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
         }
     };
     if (t_begin < t_end) issue(t_begin);
@@ -2178,16 +2211,18 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs have landed (issued one tile ago)
         if (a.dx && tile_prev >= 0) store_dx(tile_prev);   // (stores count in vmcnt: issued right behind the wait, see neck_bwdw_kernel)
-        f32x4 x[KT0], d = dn;
-        const f32x4 o = on;
+        f32x4 x[KT0], d[NTO], o[NTO];
 #pragma unroll
         for (int b = 0; b < KT0; ++b) x[b] = xn[b];
+#pragma unroll
+        for (int p = 0; p < NTO; ++p) { d[p] = dn[p]; o[p] = on[p]; }
         issue(tile + 1 < t_end ? tile + 1 : tile);
         const bool ok = tile * 16 + m < a.n;
         // ---- forward recomputation: h1 (and h2), their relu bits, and the operands with the rows on the reduction index
         unsigned bits1 = 0u, bits2 = 0u;
         SwP hq1[2];   // h1 as two 32-feature blocks (B operand of dW1; NL == 3)
-        SwT hl[4];    // the last hidden layer as four 16-feature tiles (B operand of dW_last)
+        SwT hl[4];    // the last hidden layer as four 16-feature tiles (B operand of dW_last, NTO == 1)
+        SwP hql[2];   // ... or as two 32-feature blocks (NTO == 4)
         {
 #pragma unroll
             for (int b = 0; b < KT0; ++b)
@@ -2227,25 +2262,40 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
                     }
                 make_opd<4>(h2, ho);
             }
+            if constexpr (NTO == 1) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hl[b] = to_rows<2>(ho, b, sel);
+                for (int b = 0; b < 4; ++b) hl[b] = to_rows<2>(ho, b, sel);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) hql[q] = block32(to_rows<2>(ho, 2 * q, sel), to_rows<2>(ho, 2 * q + 1, sel));
+            }
         }
         // ---- gradient at the last pre-activation, dW_last, and down the chain
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = ok ? d[i] : 0.0f;
-            if (sig) v = v * o[i] * (1.0f - o[i]);
-            d[i] = v;
-        }
+        for (int p = 0; p < NTO; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = ok ? d[p][i] : 0.0f;
+                if (sig) v = v * o[p][i] * (1.0f - o[p][i]);
+                d[p][i] = v;
+            }
         f32x4 da[4];
         zero<4>(da);
         {
-            f32x4 d1[1] = {d};
-            Opd<1> dop;
-            make_opd<1>(d1, dop);
-            const SwT dt[1] = {to_rows<1>(dop, 0, sel, &abl)};
-            dw_tiles<1, 4>(bwl, dt, hl);
-            tgemm<1, 4, false>(wlp, dop, da);
+            Opd<KSL> dop;
+            make_opd<NTO>(d, dop);
+            if constexpr (NTO == 1) {
+                const SwT dt[1] = {to_rows<KSL>(dop, 0, sel, &abl[0])};
+                dw_tiles<1, 4>(bwl, dt, hl);
+            } else {
+#pragma unroll
+                for (int P = 0; P < 2; ++P) {   // dW_last rows 32 P .. += d^T h_last
+                    const SwT t0 = to_rows<KSL>(dop, 2 * P, sel, &abl[(2 * P) % NTO]), t1 = to_rows<KSL>(dop, 2 * P + 1, sel, &abl[(2 * P + 1) % NTO]);
+                    dw_blocks<2>(bwlb[NTO == 4 ? P : 0], block32(t0, t1), hql);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tgemm<KSL, 4, false>(wlp, dop, da);
         }
         if constexpr (NL == 3) {
 #pragma unroll
@@ -2302,9 +2352,11 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
     if (a.dx && tile_prev >= 0) store_dx(tile_prev);
     // ---- sum the waves through LDS (the weights are dead), one coalesced partial per workgroup
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem);   // dWl [16][64] | dbl [16] | dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
-    float *rl = red, *rbl = rl + 16 * 64, *r1 = rbl + 16, *rb1 = r1 + (NL == 3 ? 64 * 64 : 0), *r0 = rb1 + (NL == 3 ? 64 : 0), *rb0 = r0 + 64 * K0P;
-    abl += __shfl_xor(abl, 16, 64); abl += __shfl_xor(abl, 32, 64);
+    constexpr int NLR = 16 * NTO;   // rows of dW_last in the reduction buffer
+    float *red = reinterpret_cast<float *>(smem);   // dWl [NLR][64] | dbl [NLR] | dW1 [64][64] | db1 [64] | dW0 [64][K0P] | db0 [64]
+    float *rl = red, *rbl = rl + NLR * 64, *r1 = rbl + NLR, *rb1 = r1 + (NL == 3 ? 64 * 64 : 0), *r0 = rb1 + (NL == 3 ? 64 : 0), *rb0 = r0 + 64 * K0P;
+#pragma unroll
+    for (int p = 0; p < NTO; ++p) { abl[p] += __shfl_xor(abl[p], 16, 64); abl[p] += __shfl_xor(abl[p], 32, 64); }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         ab1[p] += __shfl_xor(ab1[p], 16, 64); ab1[p] += __shfl_xor(ab1[p], 32, 64);
@@ -2313,15 +2365,26 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
     const int j32 = lane & 31, h32 = lane >> 5;
     for (int w = 0; w < NW; ++w) {
         if (wave == w) {
+            if constexpr (NTO == 1) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float *q = rl + (4 * g + r) * 64 + 16 * b + m;
-                    *q = (w == 0) ? bwl[0][b][r] : *q + bwl[0][b][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        float *q = rl + (4 * g + r) * 64 + 16 * b + m;
+                        *q = (w == 0) ? bwl[0][b][r] : *q + bwl[0][b][r];
+                    }
+            }
 #pragma unroll
             for (int P = 0; P < 2; ++P) {
+                if constexpr (NTO == 4) {
+#pragma unroll
+                    for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float *q = rl + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * 64 + 32 * Q + j32;
+                            *q = (w == 0) ? bwlb[NTO == 4 ? P : 0][Q][r] : *q + bwlb[NTO == 4 ? P : 0][Q][r];
+                        }
+                }
                 if constexpr (NL == 3) {
 #pragma unroll
                     for (int Q = 0; Q < 2; ++Q)
@@ -2342,7 +2405,8 @@ __global__ __launch_bounds__(rmlp_w_threads<NL>(), NL == 3 ? 1 : 2) void rmlp_bw
                     }
             }
             if (g == 0) {
-                rbl[m] = (w == 0) ? abl : rbl[m] + abl;
+#pragma unroll
+                for (int p = 0; p < NTO; ++p) rbl[16 * p + m] = (w == 0) ? abl[p] : rbl[16 * p + m] + abl[p];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     if (NL == 3) rb1[16 * p + m] = (w == 0) ? ab1[p] : rb1[16 * p + m] + ab1[p];
@@ -2476,36 +2540,38 @@ extern "C" int emer_neck_bwd(const float *d0, const float *d1, const float *dden
 }
 
 // ---- neck backward with the weight gradients fused [r3] --------------------------------------------------------------------
-static inline uint32_t neck_bwdw_grid(int64_t n, int kt0) {
+static inline uint32_t neck_bwdw_grid(int64_t n, int kt0, int no) {
     const int64_t tiles = (n + 15) / 16;
-    const int nw = neckw_threads(kt0) / 64;
+    const int nw = neckw_threads(kt0, no) / 64;
     int64_t blocks = (tiles + nw - 1) / nw;
-    if (blocks > 256) blocks = 256;   // persistent: one 8-wave workgroup per CU
+    if (blocks > 256) blocks = 256;   // persistent: one workgroup per CU
     return (uint32_t)(blocks < 1 ? 1 : blocks);
 }
-static inline size_t neck_bwdw_lds(int kt0) {   // weights + bias + a staging buffer of 4 KB per wave; the final reduction reuses the front
-    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2) + w3_units(4, (kt0 + 1) / 2)) * 16 + (size_t)(64 + (neckw_threads(kt0) / 64) * (1024 + 384 * kt0)) * sizeof(float);
-    const size_t r = (size_t)(64 * 64 + 64 + 64 * 16 * kt0 + 64) * sizeof(float);
+static inline size_t neck_bwdw_lds(int kt0, int no) {   // weights + bias + a staging buffer of 4-8 KB per wave; the final reduction reuses the front
+    const size_t w = (size_t)(w3_units(kt0, 2) + w3_units(4, 2 * no) + w3_units(4, (kt0 + 1) / 2)) * 16
+                     + (size_t)(64 + (neckw_threads(kt0, no) / 64) * (1024 * no + 384 * kt0)) * sizeof(float);
+    const size_t r = (size_t)(64 * no * 65 + 64 * 16 * kt0 + 64) * sizeof(float);
     return w > r ? w : r;
 }
-static inline int64_t neck_bwdw_stride(int k0) { return (int64_t)64 * 64 + 64 + 64 * (int64_t)k0 + 64; }
+static inline int64_t neck_bwdw_stride(int k0, int n_out) { return (int64_t)n_out * 65 + 64 * (int64_t)k0 + 64; }
 
-// 1 when emer_neck_bwd_fused covers this neck: 64 outputs (the geometry features; the 128-output neck of the feature
-// configs and the density MLP, n_out == 1, stay on emer_neck_bwd + emer_wgrad_segmented -- their dW would not fit the registers)
+// 1 when emer_neck_bwd_fused covers this neck: 64 outputs (the geometry features) or [r5] 128 (geometry | semantic features of the feature
+// configs); the density MLP, n_out == 1, has emer_density_bwd_fused
 extern "C" int emer_neck_bwd_fused_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out) {
-    return (emer_neck_supported(n_levels, n_feat, hidden, n_out) && n_out == 64) ? 1 : 0;
+    return (emer_neck_supported(n_levels, n_feat, hidden, n_out) && (n_out == 64 || n_out == 128)) ? 1 : 0;
 }
 static inline bool neck_bwdw_fits(int32_t n_levels, int32_t n_feat, int64_t n) { return n * n_levels * n_feat < (1ll << 30); }  // 32-bit lane offsets
 // floats of workspace emer_neck_bwd_fused needs (per-workgroup partial weight gradients)
 extern "C" int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out) {
     if (n <= 0 || !emer_neck_bwd_fused_supported(n_levels, n_feat, 64, n_out) || !neck_bwdw_fits(n_levels, n_feat, n)) return 0;
-    return (int64_t)neck_bwdw_grid(n, (n_levels * n_feat + 15) / 16) * neck_bwdw_stride(n_levels * n_feat);
+    return (int64_t)neck_bwdw_grid(n, (n_levels * n_feat + 15) / 16, n_out / 64) * neck_bwdw_stride(n_levels * n_feat, n_out);
 }
-// Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
-// [64][ld_dw0 >= L*F], db0 [64], dw1 [64][ld_dw1 >= 64], db1 [64] (torch Linear layouts; what autograd's AccumulateGrad would
-// add).  d0 / ddens as in emer_neck_bwd.  enc_lm: the forward's input; the hidden activations are recomputed from it (the
-// forward need not store them: pass h1 = NULL to emer_neck_fwd).
-extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *enc_lm,
+// Backward of emer_neck_fwd (n_out == 64 or 128) INCLUDING the weight gradients: writes denc_lm [L][n][F]; ACCUMULATES (+=) dw0
+// [64][ld_dw0 >= L*F], db0 [64], dw1 [n_out][ld_dw1 >= 64], db1 [n_out] (torch Linear layouts; what autograd's AccumulateGrad would
+// add).  d0 / d1 [n][64]: gradients of output features 0..63 / 64..127 (either may be NULL = zero; d1 only with n_out == 128); ddens as
+// in emer_neck_bwd.  enc_lm: the forward's input; the hidden activations are recomputed from it (the forward need not store them: pass
+// h1 = NULL to emer_neck_fwd).
+extern "C" int emer_neck_bwd_fused(const float *d0, const float *d1, const float *ddens, const float *dens, const float *enc_lm,
                                    int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *b0, const float *w1, int32_t n_out,
                                    float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1,
                                    float *db1, void *stream) {
@@ -2515,29 +2581,31 @@ extern "C" int emer_neck_bwd_fused(const float *d0, const float *ddens, const fl
     EMER_REQUIRE(neck_bwdw_fits(n_levels, n_feat, n), "neck_bwd_fused: n * L * F must stay below 2^30 (32-bit lane offsets); split the batch or use emer_neck_bwd");
     EMER_REQUIRE(enc_lm && w0 && b0 && w1 && denc_lm && workspace && dw0 && db0 && dw1 && db1, "neck_bwd_fused: null pointer");
     EMER_REQUIRE(!ddens || dens, "neck_bwd_fused: ddens needs the saved density");
+    EMER_REQUIRE(!d1 || n_out == 128, "neck_bwd_fused: d1 is the gradient of outputs 64..127 of a 128-output neck");
     const int k0 = n_levels * n_feat;
     EMER_REQUIRE(ld_dw0 >= k0 && ld_dw1 >= 64, "neck_bwd_fused: leading dimension smaller than the row");
     NeckBwdWArgs a;
-    a.d0 = d0; a.ddens = ddens; a.dens = dens; a.enc = enc_lm; a.b0 = b0; a.n = n; a.n_levels = n_levels; a.k0 = k0;
+    a.d0 = d0; a.d1 = d1; a.ddens = ddens; a.dens = dens; a.enc = enc_lm; a.b0 = b0; a.n = n; a.n_levels = n_levels; a.k0 = k0;
     a.w0 = WSrc{w0, k0, 1, 64, k0};
     a.w0t = WSrc{w0, 1, k0, k0, 64};          // (n = input feature, k = hidden) = w0[k][n]
-    a.w1t = WSrc{w1, 1, 64, 64, 64};          // (n = hidden, k = output) = w1[k][n]
-    a.denc = denc_lm; a.partials = workspace; a.stride = neck_bwdw_stride(k0);
+    a.w1t = WSrc{w1, 1, 64, 64, n_out};       // (n = hidden, k = output) = w1[k][n]
+    a.denc = denc_lm; a.partials = workspace; a.stride = neck_bwdw_stride(k0, n_out);
     hipStream_t st = as_stream(stream);
-    const int kt0 = (k0 + 15) / 16;
-    const uint32_t grid = neck_bwdw_grid(n, kt0);
-    const size_t lds = neck_bwdw_lds(kt0);
+    const int kt0 = (k0 + 15) / 16, no = n_out / 64;
+    const uint32_t grid = neck_bwdw_grid(n, kt0, no);
+    const size_t lds = neck_bwdw_lds(kt0, no);
     int rc = EMER_E_INVALID;
     auto go = [&](auto kern) {
         if (int r = set_lds(kern, lds, "neck_bwd_fused")) return r;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(neckw_threads(kt0)), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(neckw_threads(kt0, no)), lds, st, a);
         return check_launch("neck_bwd_fused");
     };
-#define EMER_NBW(FF) (kt0 == 1 ? go(neck_bwdw_kernel<1, FF>) : kt0 == 2 ? go(neck_bwdw_kernel<2, FF>) : kt0 == 3 ? go(neck_bwdw_kernel<3, FF>) : go(neck_bwdw_kernel<4, FF>))
-    if (n_feat == 1) rc = EMER_NBW(1); else if (n_feat == 2) rc = EMER_NBW(2); else if (n_feat == 4) rc = EMER_NBW(4); else rc = EMER_NBW(8);
+#define EMER_NBW(FF, NN) (kt0 == 1 ? go(neck_bwdw_kernel<1, FF, NN>) : kt0 == 2 ? go(neck_bwdw_kernel<2, FF, NN>) : kt0 == 3 ? go(neck_bwdw_kernel<3, FF, NN>) : go(neck_bwdw_kernel<4, FF, NN>))
+    if (no == 1) { if (n_feat == 1) rc = EMER_NBW(1, 1); else if (n_feat == 2) rc = EMER_NBW(2, 1); else if (n_feat == 4) rc = EMER_NBW(4, 1); else rc = EMER_NBW(8, 1); }
+    else { if (n_feat == 1) rc = EMER_NBW(1, 2); else if (n_feat == 2) rc = EMER_NBW(2, 2); else if (n_feat == 4) rc = EMER_NBW(4, 2); else rc = EMER_NBW(8, 2); }
 #undef EMER_NBW
     if (rc) return rc;
-    const DwReduceJob jb[2] = {{0, 64, 64, dw1, ld_dw1, db1, 0, {0}, {0}, {0}}, {64 * 64 + 64, 64, k0, dw0, ld_dw0, db0, 0, {0}, {0}, {0}}};
+    const DwReduceJob jb[2] = {{0, n_out, 64, dw1, ld_dw1, db1, 0, {0}, {0}, {0}}, {(int64_t)n_out * 65, 64, k0, dw0, ld_dw0, db0, 0, {0}, {0}, {0}}};
     return launch_dw_reduce_multi(workspace, (int32_t)grid, a.stride, 2, jb, st);
 }
 
@@ -2827,8 +2895,10 @@ extern "C" int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, c
 }
 
 // ---- plain 2- / 3-layer heads: backward with the weight gradients fused [r5] ------------------------------------------------
-static inline uint32_t rmlp_bwdw_grid(int64_t n, int n_layers) {
-    const int nw = (n_layers == 3 ? 256 : 512) / 64;
+static inline int rmlp_bwdw_nto(int n_out) { return n_out <= 16 ? 1 : 4; }
+static inline int rmlp_bwdw_threads(int n_layers, int n_out) { return (n_layers == 3 || rmlp_bwdw_nto(n_out) == 4) ? 256 : 512; }
+static inline uint32_t rmlp_bwdw_grid(int64_t n, int n_layers, int n_out) {
+    const int nw = rmlp_bwdw_threads(n_layers, n_out) / 64;
     const int64_t tiles = (n + 15) / 16;
     int64_t blocks = (tiles + nw - 1) / nw;
     if (blocks > 256) blocks = 256;   // persistent: one workgroup per CU
@@ -2837,23 +2907,25 @@ static inline uint32_t rmlp_bwdw_grid(int64_t n, int n_layers) {
 static inline int64_t rmlp_bwdw_stride(int n_layers, int k0, int n_out) {
     return ((int64_t)n_out * 65 + (n_layers == 3 ? 64 * 65 : 0) + 64 * (int64_t)k0 + 64 + 3) / 4 * 4;
 }
-static inline size_t rmlp_bwdw_lds(int n_layers, int kt0) {
-    const int nw = (n_layers == 3 ? 256 : 512) / 64;
-    const size_t w = (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, 1) + w3_units(kt0, 2) + (n_layers == 3 ? 2 * w3_units(4, 2) : 0)) * 16
+static inline size_t rmlp_bwdw_lds(int n_layers, int kt0, int n_out) {
+    const int nw = rmlp_bwdw_threads(n_layers, n_out) / 64, nto = rmlp_bwdw_nto(n_out);
+    const size_t w = (size_t)(w3_units(4, (kt0 + 1) / 2) + w3_units(4, (nto + 1) / 2) + w3_units(kt0, 2) + (n_layers == 3 ? 2 * w3_units(4, 2) : 0)) * 16
                      + (size_t)(128 + nw * 384 * kt0) * sizeof(float);
-    const size_t r = (size_t)(16 * 64 + 16 + (n_layers == 3 ? 64 * 64 + 64 : 0) + 64 * 16 * kt0 + 64) * sizeof(float);
+    const size_t r = (size_t)(16 * nto * 65 + (n_layers == 3 ? 64 * 64 + 64 : 0) + 64 * 16 * kt0 + 64) * sizeof(float);
     return w > r ? w : r;
 }
-// 1 when emer_rmlp_bwd_fused covers this stack: what emer_rmlp_fwd covers, with at most 16 outputs (the flow MLP's 6, the shadow head's 1;
-// the 64-wide feature heads keep emer_rmlp_bwd + streamed weight gradients: their dW_last would not fit the registers)
+// 1 when emer_rmlp_bwd_fused covers this stack: what emer_rmlp_fwd covers with at most 16 outputs (the flow MLP's 6, the shadow head's 1),
+// or three layers on a row-major input with up to 64 outputs in multiples of 4 (the feature heads 64 -> 64 -> 64 -> E)
 extern "C" int emer_rmlp_bwd_fused_supported(int32_t n_layers, int32_t k0, int32_t n_feat, int32_t hidden, int32_t n_out) {
-    return (emer_rmlp_supported(n_layers, k0, n_feat, hidden, n_out) && n_out <= 16) ? 1 : 0;
+    if (!emer_rmlp_supported(n_layers, k0, n_feat, hidden, n_out)) return 0;
+    if (n_out <= 16) return 1;
+    return (n_layers == 3 && n_feat == 0 && n_out % 4 == 0 && n_out <= 64) ? 1 : 0;
 }
 // floats of workspace emer_rmlp_bwd_fused needs (per-workgroup partial weight gradients); 0: not supported for this call
 extern "C" int64_t emer_rmlp_bwd_fused_workspace(int32_t n_layers, int32_t k0, int32_t n_feat, int64_t n, int32_t n_out) {
     if (n <= 0 || !emer_rmlp_bwd_fused_supported(n_layers, k0, n_feat, 64, n_out)) return 0;
     if (n_feat != 0 && n * k0 >= (1ll << 30)) return 0;   // level-major input: 32-bit lane offsets
-    return (int64_t)rmlp_bwdw_grid(n, n_layers) * rmlp_bwdw_stride(n_layers, k0, n_out);
+    return (int64_t)rmlp_bwdw_grid(n, n_layers, n_out) * rmlp_bwdw_stride(n_layers, k0, n_out);
 }
 // Backward of emer_rmlp_fwd INCLUDING the weight gradients.  dout [n][ldd]: gradient of the OUTPUT (sigmoid' is applied here from the
 // saved `out` [n][ldo]; final_act none: `out` may be NULL).  x: the forward's input (the hidden layers are recomputed from it: pass
@@ -2874,6 +2946,9 @@ extern "C" int emer_rmlp_bwd_fused(const float *dout, int64_t ldd, const float *
     EMER_REQUIRE(n_feat == 0 || (n_levels * n_feat == k0 && n * k0 < (1ll << 30)), "rmlp_bwd_fused: level-major input needs k0 == n_levels * n_feat and n * k0 < 2^30");
     EMER_REQUIRE(!dx || n_feat != 0 || (lddx >= k0 && lddx % 4 == 0 && ((uintptr_t)dx % 16) == 0), "rmlp_bwd_fused: row-major dx needs lddx %% 4 == 0 and 16-byte alignment");
     EMER_REQUIRE(ld_dw0 >= k0 && ld_dw1 >= 64 && (n_layers == 2 || ld_dw2 >= 64), "rmlp_bwd_fused: leading dimension smaller than the row");
+    const int nto = rmlp_bwdw_nto(n_out);
+    EMER_REQUIRE(nto == 1 || (ldd % 4 == 0 && ((uintptr_t)dout % 16) == 0 && (final_act == EMER_ACT_NONE || (ldo % 4 == 0 && ((uintptr_t)out % 16) == 0))),
+                 "rmlp_bwd_fused: wide outputs need 16-byte aligned rows of dout (and of out for a sigmoid)");
     RMlpBwdWArgs a;
     a.dout = dout; a.ldd = ldd; a.out = out; a.ldo = ldo; a.x = x; a.ldx = ldx; a.n = n; a.n_levels = n_levels; a.k0 = k0; a.n_out = n_out;
     a.final_act = final_act;
@@ -2886,19 +2961,21 @@ extern "C" int emer_rmlp_bwd_fused(const float *dout, int64_t ldd, const float *
     a.w0t = WSrc{w0, 1, k0, k0, 64};      // (n = input feature, k = hidden) = w0[k][n]
     a.dx = dx; a.lddx = lddx; a.partials = workspace; a.stride = rmlp_bwdw_stride(n_layers, k0, n_out);
     const int kt0 = n_feat == 0 ? 4 : ((k0 + 15) / 16 <= 2 ? 2 : (k0 + 15) / 16);
-    const uint32_t grid = rmlp_bwdw_grid(n, n_layers);
-    const size_t lds = rmlp_bwdw_lds(n_layers, kt0);
+    const uint32_t grid = rmlp_bwdw_grid(n, n_layers, n_out);
+    const size_t lds = rmlp_bwdw_lds(n_layers, kt0, n_out);
+    const int threads = rmlp_bwdw_threads(n_layers, n_out);
     hipStream_t st = as_stream(stream);
     int rc = EMER_E_INVALID;
-    auto go = [&](auto kern, int threads) {
+    auto go = [&](auto kern) {
         if (int r = set_lds(kern, lds, "rmlp_bwd_fused")) return r;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
         return check_launch("rmlp_bwd_fused");
     };
-    if (n_feat == 0) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 0, 2>, 512) : go(rmlp_bwdw_kernel<4, 0, 3>, 256);
-    else if (kt0 == 2) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<2, 4, 2>, 512) : go(rmlp_bwdw_kernel<2, 4, 3>, 256);
-    else if (kt0 == 3) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<3, 4, 2>, 512) : go(rmlp_bwdw_kernel<3, 4, 3>, 256);
-    else rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 4, 2>, 512) : go(rmlp_bwdw_kernel<4, 4, 3>, 256);
+    if (nto == 4) rc = go(rmlp_bwdw_kernel<4, 0, 3, 4>);
+    else if (n_feat == 0) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 0, 2, 1>) : go(rmlp_bwdw_kernel<4, 0, 3, 1>);
+    else if (kt0 == 2) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<2, 4, 2, 1>) : go(rmlp_bwdw_kernel<2, 4, 3, 1>);
+    else if (kt0 == 3) rc = n_layers == 2 ? go(rmlp_bwdw_kernel<3, 4, 2, 1>) : go(rmlp_bwdw_kernel<3, 4, 3, 1>);
+    else rc = n_layers == 2 ? go(rmlp_bwdw_kernel<4, 4, 2, 1>) : go(rmlp_bwdw_kernel<4, 4, 3, 1>);
     if (rc) return rc;
     DwReduceJob jb[3];
     int nj = 0;

@@ -199,6 +199,7 @@ def wgrad(dpre: Tensor, segs, k_total: int, want_bias: bool = True, col0: Option
 
 FUSED_WGRAD = True   # weight gradients inside the backward kernels where the library has them (emer_neck_bwd_fused); False: separate pass
 FUSED_RMLP_WGRAD = os.environ.get("EMER_FUSE_RMLP_WGRAD", "1") != "0"  # ... of the plain 2- / 3-layer heads with <= 16 outputs (emer_rmlp_bwd_fused) [r5]
+FUSED_RMLP_WIDE = os.environ.get("EMER_FUSE_RMLP_WIDE", "1") != "0"    # ... incl. the 64-wide feature heads (one wave per SIMD, 192 accumulator registers)
 FUSED_RGB_WGRAD = os.environ.get("EMER_FUSE_RGB_WGRAD", "1") != "0"   # ... of the rgb head's layers 0 / 1 too (emer_rgb_head_bwd_fused) [r4]
 RGB_WGRAD_PAIR = os.environ.get("EMER_RGBW_PAIR", "0") == "1"         # its variant that pairs two row tiles per weight-gradient step
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
@@ -437,7 +438,7 @@ class _NeckFn(torch.autograd.Function):
             # data gradients AND weight gradients in one kernel: neither h1 nor dpre0 reaches memory, enc / d are read once
             ws = torch.empty((int(_lib.load().emer_neck_bwd_fused_workspace(L, F, N, n_out)),), device=dev, dtype=torch.float32)
             with torch.cuda.device(dev):
-                _lib.call("emer_neck_bwd_fused", _p(d0c), _p(fa), _p(dens), _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), n_out,
+                _lib.call("emer_neck_bwd_fused", _p(d0c), _p(d1c), _p(fa), _p(dens), _p(enc), L, F, N, _p(W0), _p(B0), _p(W1), n_out,
                           _p(denc), _p(ws), _p(tw0), tw0.stride(0), _p(tb0), _p(tw1), tw1.stride(0), _p(tb1), _stream(enc))
             return denc, rw0, rb0, rw1, rb1, None
         dpre0 = torch.empty((N, 64), device=dev, dtype=torch.float32)
@@ -966,9 +967,10 @@ class _RMlpFn(torch.autograd.Function):
         dev = X.device
         n_out = Ws[-1].shape[0]
         need_bwd = any(ctx.needs_input_grad)
-        # [r5] stacks with at most 16 outputs (flow MLP, shadow head): the backward is ONE kernel that recomputes the hidden layers from x and
-        # keeps the weight gradients in registers (emer_rmlp_bwd_fused) -- the forward then stores no activations
-        ctx.fused_bwd = bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and need_bwd and all(b is not None for b in Bs[:n - 1])
+        # [r5] stacks with at most 16 outputs (flow MLP, shadow head) and the three-layer feature heads: the backward is ONE kernel that
+        # recomputes the hidden layers from x and keeps the weight gradients in registers (emer_rmlp_bwd_fused) -- the forward then stores
+        # no activations
+        ctx.fused_bwd = bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and (n_out <= 16 or FUSED_RMLP_WIDE) and need_bwd and all(b is not None for b in Bs[:n - 1])
                              and _lib.load().emer_rmlp_bwd_fused_workspace(n, K0, F, N, n_out) > 0)
         keep = need_bwd and not ctx.fused_bwd
         h1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if keep else None
@@ -1052,7 +1054,7 @@ class _RMlpFn(torch.autograd.Function):
 def rmlp_bwd_fused_supported(weights, k0: int, n_feat: int, n_rows: int) -> bool:
     """True when the backward of this stack runs as emer_rmlp_bwd_fused (weight gradients in the kernel, hidden layers recomputed)."""
     n = len(weights)
-    return bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and n in (2, 3)
+    return bool(FUSED_WGRAD and FUSED_RMLP_WGRAD and n in (2, 3) and (weights[-1].shape[0] <= 16 or FUSED_RMLP_WIDE)
                 and _lib.load().emer_rmlp_bwd_fused_workspace(n, int(k0), int(n_feat), int(n_rows), int(weights[-1].shape[0])) > 0)
 
 

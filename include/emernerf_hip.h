@@ -490,16 +490,17 @@ int emer_neck_bwd(const float *d0, const float *d1, const float *ddens, const fl
                   int32_t n_levels, int32_t n_feat, int64_t n, const float *w0, const float *w1,
                   int32_t n_out, float *dpre1, float *dcol0, float *dpre0, float *denc_lm, void *stream);
 
-/* Backward of emer_neck_fwd (n_out == 64) INCLUDING the weight gradients (autograd of radiance_field.py:74-80,89-96): one
- * kernel reads d0 / ddens and the forward's input enc_lm once, RECOMPUTES the hidden layer from enc_lm (the forward need not
+/* Backward of emer_neck_fwd (n_out == 64, or [r5] 128: geometry | semantic features of the feature configs, d1 = the gradient of
+ * outputs 64..127) INCLUDING the weight gradients (autograd of radiance_field.py:74-80,89-96): one
+ * kernel reads d0 / d1 / ddens and the forward's input enc_lm once, RECOMPUTES the hidden layer from enc_lm (the forward need not
  * store it: h1 = NULL there), writes denc_lm [L][n][F] and keeps dW1 = d^T h1, db1, dW0 = dpre0^T enc, db0 in the waves'
  * accumulators (neither h1 nor the pre-activation gradient dpre0 ever goes to memory); per-workgroup partials are summed
- * into dw1 [64][ld_dw1 >= 64], db1 [64], dw0 [64][ld_dw0 >= L*F], db0 [64] with += semantics (what AccumulateGrad does; the
+ * into dw1 [n_out][ld_dw1 >= 64], db1 [n_out], dw0 [64][ld_dw0 >= L*F], db0 [64] with += semantics (what AccumulateGrad does; the
  * targets may be a parameter's .grad).  workspace: emer_neck_bwd_fused_workspace(...) floats; n * L * F < 2^30.
- * emer_neck_bwd_fused_supported == 0 (128 outputs, density MLP): emer_neck_bwd + emer_wgrad_segmented. */
+ * emer_neck_bwd_fused_supported == 0 (the density MLP): emer_density_bwd_fused, or emer_neck_bwd + emer_wgrad_segmented. */
 int emer_neck_bwd_fused_supported(int32_t n_levels, int32_t n_feat, int32_t hidden, int32_t n_out);
 int64_t emer_neck_bwd_fused_workspace(int32_t n_levels, int32_t n_feat, int64_t n, int32_t n_out);
-int emer_neck_bwd_fused(const float *d0, const float *ddens, const float *dens, const float *enc_lm, int32_t n_levels,
+int emer_neck_bwd_fused(const float *d0, const float *d1, const float *ddens, const float *dens, const float *enc_lm, int32_t n_levels,
                         int32_t n_feat, int64_t n, const float *w0, const float *b0, const float *w1, int32_t n_out,
                         float *denc_lm, float *workspace, float *dw0, int64_t ld_dw0, float *db0, float *dw1, int64_t ld_dw1,
                         float *db1, void *stream);
@@ -522,7 +523,8 @@ int emer_rmlp_bwd(const float *dlast, int64_t ldd, const float *h1, const float 
                   float *dpre1, float *dpre0, float *dx, int64_t lddx, void *stream);
 /* [r5] The whole backward of emer_rmlp_fwd in ONE kernel, weight gradients included (replaces autograd of the flow MLP,
  * radiance_field.py:101-111, and of the shadow head, :148-153: torch's sigmoid backward, emer_rmlp_bwd, one weight-gradient launch
- * and one reduction per layer).  Stacks with n_out <= 16 (emer_rmlp_bwd_fused_supported).  dout [n][ldd]: gradient of the OUTPUT;
+ * and one reduction per layer).  Stacks with n_out <= 16, or three layers on a row-major input with n_out <= 64 in multiples of 4 --
+ * the feature heads, :192-198 (emer_rmlp_bwd_fused_supported; wide outputs need 16-byte aligned rows of dout / out).  dout [n][ldd]: gradient of the OUTPUT;
  * sigmoid' is applied from the saved `out` [n][ldo] (final_act == EMER_ACT_NONE: out may be NULL).  The hidden layers are
  * recomputed from x (pass h1 = h2 = NULL to emer_rmlp_fwd).  Writes dx in x's layout when non-NULL; ACCUMULATES (+=) dw0
  * [64][ld_dw0 >= k0], db0 [64], dw1 / db1 (three layers: [64][ld_dw1 >= 64], [64]; two layers: the output layer, [n_out][ld_dw1], [n_out])

@@ -251,6 +251,19 @@ def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):
         geo, sem, dens = fused.neck(enc, *wn)
         rgb = fused.rgb_head(hray, geo, S, *wc)
     acts = [t for t in saved if t.shape == (N, 64) and t.data_ptr() != geo.data_ptr()]
+    if len(acts) == 2:
+        # [r5] the 128-output neck's backward recomputes its hidden layer too (bitwise the forward's values) and saves none: its mask
+        # comes from a forward of the unfused path on the same inputs
+        saved.clear()
+        monkeypatch.setattr(fused, "FUSED_WGRAD", False)
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
+            geo_u, _, _ = fused.neck(enc, *wn)
+        monkeypatch.setattr(fused, "FUSED_WGRAD", True)
+        assert torch.equal(geo_u, geo), "both neck paths share the forward kernel"
+        h1 = [t for t in saved if t.shape == (N, 64) and t.data_ptr() != geo_u.data_ptr()]
+        assert len(h1) == 1
+        acts = h1 + acts
+        del geo_u
     assert len(acts) == 3, [tuple(t.shape) for t in saved]  # h1 (neck), a1, a2 (rgb head)
     m_h1, m_a1, m_a2 = [(t > 0).double() for t in acts]
     ((rgb * gw).sum() + (dens * gd).sum()).backward()

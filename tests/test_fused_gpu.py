@@ -44,7 +44,7 @@ def test_base_mlp(hip_lib, L, Fe, NG, N):
 
 @pytest.mark.parametrize("L,Fe,NG,N,which", [(16, 2, 128, 1000, "all"), (16, 2, 128, 2048, "geo"), (10, 4, 128, 777, "all"),
                                               (4, 2, 64, 16, "all"), (8, 1, 64, 33, "dens"), (3, 8, 64, 100, "all"),
-                                              (16, 4, 128, 50, "sem")])
+                                              (16, 4, 128, 50, "sem"), (10, 4, 128, 20000, "all"), (16, 2, 128, 9000, "sem")])
 @pytest.mark.parametrize("fusedw", [True, False])
 def test_neck_register_resident(hip_lib, monkeypatch, L, Fe, NG, N, which, fusedw):
     """emer_neck_fwd / emer_neck_bwd (+ emer_wgrad_segmented) and emer_neck_bwd_fused (weight gradients accumulated inside
