@@ -206,6 +206,17 @@ def _subtract_ranges(span, holes):
     return out
 
 
+def agree_any(flag: bool, device) -> bool:
+    """True on EVERY rank when ``flag`` is true on ANY rank (one MAX all-reduce of a scalar; no-op without a process group).  Used where
+    ranks must take the same branch although the condition is local: a failed hipGraph capture switches a rank to eager launches, whose
+    gradient buckets differ from the replaying ranks' -- so either all ranks switch or none does."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device, dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0.0)
+
+
 def lr_factor(step: int, num_iters: int) -> float:
     """ChainedScheduler(LinearLR(0.01 -> 1 over num_iters//10), MultiStepLR(gamma 0.33)) of builders.py:64-89."""
     warm = num_iters // 10
@@ -620,20 +631,29 @@ class Trainer:
         step = self.step_count
         prop_grad = self.requires_grad_fn(step)
         if self.use_graph:
+            first = prop_grad not in self._graphs   # the capture of this step type happens in this call (same schedule on every rank)
+            failed, err = False, None
             try:
                 loss = self._graphed_forward_backward(data, prop_grad)
             except FloatingPointError:  # EMER_CHECK_FINITE=1: a replayed step saw a non-finite gradient -- not a capture problem
                 raise
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, once
-                if self._dp_on:
-                    # A rank that switched to eager launches on its own would issue the early / table / xyzt buckets while its peers,
-                    # still replaying graphs, issue one all-reduce over the whole range: mismatched collectives hang or corrupt the
-                    # gradients.  With more than one rank a capture failure is therefore an error, not a fallback.
-                    raise RuntimeError("hipGraph capture failed on a data-parallel rank; run every rank with use_graph=False") from e
+                if self._dp_on and not first:
+                    raise   # a replay that fails later cannot be agreed on (the peers are not at a collective)
+                failed, err = True, e
+            # A rank that switched to eager launches on its own would issue the early / table / xyzt buckets while its peers, still
+            # replaying graphs, issue one all-reduce over the whole range: mismatched collectives hang or corrupt the gradients.  So the
+            # ranks agree right after the capture attempt: if it failed anywhere, everybody falls back.
+            if self._dp_on and first:
+                failed_here, failed = failed, agree_any(failed, self.device)
+                if failed and not failed_here:
+                    err = RuntimeError("a peer rank's hipGraph capture failed")
+            if failed:
                 import warnings
-                warnings.warn(f"hipGraph capture failed ({e!r}); continuing with eager launches")
+                warnings.warn(f"hipGraph capture failed ({err!r}); continuing with eager launches")
                 self.use_graph = False
                 self._hold_buckets = False
+                self._graphs.clear()
                 loss = self._forward_backward(data, prop_grad)
         else:
             loss = self._forward_backward(data, prop_grad)

@@ -177,6 +177,28 @@ def _dp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _agree_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from emernerf_amd.trainer import agree_any
+    ret[rank] = (agree_any(rank == 1, "cpu"), agree_any(False, "cpu"), agree_any(True, "cpu"))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_local_failure_gloo():
+    """trainer.agree_any: a condition that is true on ONE rank (a failed hipGraph capture) becomes true on every rank, so all of them
+    take the eager fallback together and issue the same sequence of gradient buckets; without a process group it is the local flag."""
+    from emernerf_amd.trainer import agree_any
+    assert agree_any(True, "cpu") is True and agree_any(False, "cpu") is False
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_agree_worker, args=(world, port, ret), nprocs=world, join=True)
+        for r in range(world):
+            assert tuple(ret[r]) == (True, False, True), dict(ret)
+
+
 def test_data_parallel_flat_allreduce_gloo():
     world, port = 2, _free_port()
     with mp.Manager() as mgr:
