@@ -46,6 +46,7 @@ SIGNATURES = {
     "emer_hashgrid_bwd_params_sliced_add": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P],
     "emer_hashgrid_bwd_params_sliced_levels": [_GP, _P, _P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_int32, _P],
     "emer_hashgrid_sliced_split_level": [_GP],
+    "emer_hashgrid_sliced_plan": [_GP, _P, _P],
     "emer_hashgrid_slice_masks": [_GP, _P, _P, c_int64, _P],
     "emer_hashgrid_sliced_supported": [_GP],
     "emer_hashgrid_mask_rows": [_P],

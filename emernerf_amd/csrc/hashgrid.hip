@@ -2133,6 +2133,21 @@ extern "C" int emer_hashgrid_bwd_params_sliced_levels(const emer_grid_desc *g, c
     return hashgrid_bwd_params_sliced_range(g, x, dout, sn, sl, slice_masks, grad, n, (uint32_t)level_begin, (uint32_t)level_end, stream);
 }
 
+// The work-item plan of the owner-computes backward, for tests and diagnostics (host arithmetic only: no GPU needed): per level the number
+// of LDS slices and of sample ranges (1 = every entry written once with plain stores; > 1 = merged with atomics: dense levels, and the
+// half- or quarter-size tail items of grids without enough dense filler, EMER_TAIL_SPLIT).  Returns the total number of work items, or a
+// negative error code (EMER_E_INVALID when the grid needs the global-atomic backward).  Arrays of at least n_levels entries; NULL = skip.
+extern "C" int emer_hashgrid_sliced_plan(const emer_grid_desc *g, uint32_t *n_slices, uint32_t *n_ranges) {
+    if (int rc = check_desc(g)) return rc;
+    const SlicePlan plan = make_slice_plan(g);
+    EMER_REQUIRE(plan.ok, "hashgrid_sliced_plan: a level needs more than 256 x 64 LDS slices");
+    for (uint32_t l = 0; l < g->n_levels; ++l) {
+        if (n_slices) n_slices[l] = plan.n_slices[l];
+        if (n_ranges) n_ranges[l] = plan.n_ranges[l];
+    }
+    return (int)plan.total_items;
+}
+
 // Where to cut for emer_hashgrid_bwd_params_sliced_levels: the first level k of the fine range [k, L) that a caller launches
 // first.  The persistent owners take work items in rounds (one item per CU at a time, three rounds for the cfg-2 table), so a
 // cut costs nothing only where it falls between rounds: [k, L) is the largest set of finest levels whose items fill at most ONE

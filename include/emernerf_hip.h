@@ -107,6 +107,10 @@ int emer_hashgrid_bwd_params_sliced(const emer_grid_desc *host_desc, const float
                                     const float *dout, int64_t dout_stride_n,
                                     int64_t dout_stride_l, uint64_t *slice_masks,
                                     float *grad, int64_t n, void *stream);
+/* [r5] The work-item plan of the owner-computes backward (host arithmetic, no GPU): slices and sample ranges per level, total items as
+ * the return value (negative: error).  n_ranges > 1 on a hashed level = the tail items of a grid without enough dense filler (the xyzt
+ * tables: their finest levels are cut in 2 or 4 so that the last round of the 256 owners is full).  Arrays of n_levels entries or NULL. */
+int emer_hashgrid_sliced_plan(const emer_grid_desc *g, uint32_t *n_slices, uint32_t *n_ranges);
 /* [r5] emer_hashgrid_bwd_params_sliced that ADDS to grad instead of overwriting it: the second and later evaluations of one encoder in
  * a step (the flow table is evaluated at the sample positions and at the warped positions, radiance_field.py:553-620; chunked training).
  * Replaces a table-sized temporary and autograd's add. */

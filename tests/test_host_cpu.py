@@ -332,6 +332,34 @@ def test_slice_plan_host_logic(hip_lib, grid, rows):
     assert hip_lib.emer_neck_supported(16, 2, 64, 64) == 1 and hip_lib.emer_neck_supported(10, 4, 64, 128) == 1
 
 
+@pytest.mark.parametrize("grid,split", [((3, 16, 16, 2048, 19, 2), {}),              # cfg-2 main grid: 1900 dense items fill the tail, no hashed level is cut
+                                        ((4, 10, 32, 8192, 18, 4), {8: 2, 9: 2}),   # dynamic xyzt table: 640 hashed items, remainder 128 -> two levels in halves
+                                        ((4, 10, 16, 4096, 18, 4), {9: 4}),         # flow xyzt table: 576 hashed items + one dense level, remainder 64 -> quarters
+                                        ((3, 10, 16, 8192, 20, 4), {}),             # default static table: 7 x 256 hashed items = whole rounds
+                                        ((3, 8, 16, 2048, 20, 1), {})])             # proposal net: 4 x 64 hashed items = one round
+def test_tail_items_of_the_owner_computes_backward(hip_lib, grid, split):
+    """[r5] The hashed work items of the owner-computes grid backward are taken in rounds of 256 owners; where their count leaves a
+    remainder that the dense levels' small items cannot fill, the finest levels are cut in R sample ranges (merged with atomics) so that the
+    last round is full of 1/R-size items (emer_hashgrid_sliced_plan: host arithmetic).  Hashed levels otherwise have ONE range (every entry
+    written once with plain stores); dense levels always have several."""
+    import ctypes
+    from emernerf_amd import _lib
+    D, L, base, mx, T, F = grid
+    growth = float(np.exp((np.log(mx) - np.log(base)) / (L - 1)))
+    desc = _lib.make_grid_desc(D, L, F, T, base, growth)
+    ns, nr = (ctypes.c_uint32 * L)(), (ctypes.c_uint32 * L)()
+    total = hip_lib.emer_hashgrid_sliced_plan(ctypes.byref(desc), ns, nr)
+    assert total == sum(ns[l] * nr[l] for l in range(L)) > 0
+    hashed = [l for l in range(L) if desc.hashed[l]]
+    assert {l: nr[l] for l in hashed if nr[l] != 1} == split, [(l, ns[l], nr[l]) for l in range(L)]
+    assert all(nr[l] > 1 for l in range(L) if not desc.hashed[l] and ns[l] * nr[l] > 1) or not [l for l in range(L) if not desc.hashed[l]]
+    n_hashed = sum(ns[l] for l in hashed)
+    if split:   # the cut levels' items fill the owners' last round exactly or in whole multiples of 1/R rounds
+        rem = n_hashed % 256
+        cut_items = sum(ns[l] * nr[l] for l in split)
+        assert rem != 0 and sum(ns[l] for l in split) >= rem and cut_items % 256 in (0, 128, 64, 192)
+
+
 def test_inputs_are_detached_outside_autograd_recording():
     """A Function's forward sees needs_input_grad == requires_grad whatever the grad mode (and is_grad_enabled() is False inside
     every forward), so the public wrappers detach under torch.no_grad(): nothing is then saved for a backward that cannot run."""
