@@ -353,3 +353,31 @@ def test_trainer_state_dict_is_a_snapshot_and_checks_the_layout(hip_lib):
         fresh(s)
     tr3.set_step(1234)
     assert tr3.requires_grad_fn.since_last == fresh.since_last and tr3.step_count == 1234
+
+
+def test_flow_step_launch_budget(hip_lib):
+    """A flow-model step at a 2048-ray shard is 90 kernel launches, 11 of them torch's (profiles/r05d_flow2048_step_sequence.txt; round 4:
+    116 / 27).  The budget below leaves room for the profiler's own bookkeeping but not for a fusion coming undone (the cycle loss back on
+    four slices: +9 torch launches; the plain heads back on streamed weight gradients: +15 launches)."""
+    from torch.profiler import ProfilerActivity, profile
+    from emernerf_amd.trainer import Trainer, synthetic_rays
+    dev = torch.device("cuda:0")
+    tr = Trainer(kind="flow", device=dev)
+    tr.set_step(1000)
+    data = synthetic_rays(2048, dev, seed=1)
+    for _ in range(3):
+        tr.train_step(data)
+    while tr.requires_grad_fn.since_last >= 5:   # profile a step that does not train the proposal nets (5 in 6 steps)
+        tr.train_step(data)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        out = tr.train_step(data)
+        torch.cuda.synchronize()
+    assert not out["prop_grad"]
+    kernels = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and e.device_time_total > 0]
+    names = [e.name for e in kernels]
+    ours = [n for n in names if n.startswith("emer::") or "emer::" in n]
+    theirs = [n for n in names if n not in ours and "Memcpy" not in n and "Memset" not in n]
+    assert len(ours) >= 60, "the HIP kernels must be the ones that run"
+    assert len(names) <= 100, f"{len(names)} launches in a flow step"
+    assert len(theirs) <= 14, f"{len(theirs)} torch launches in a flow step: {sorted(set(theirs))}"
