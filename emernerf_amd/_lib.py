@@ -62,6 +62,7 @@ SIGNATURES = {
     "emer_flow_warp_bwd": [_P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P],
     "emer_ray_points": [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int64, c_int32, _P],
     "emer_importance_sample": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P],
+    "emer_importance_sample_points": [_P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, c_int, _P, _P, _P],
     "emer_stot": [_P, c_int64, c_float, c_float, c_int, _P, _P],
     "emer_prop_loss": [_P, _P, c_int32, _P, _P, c_int32, c_float, c_int, c_int64, c_float, _P, _P, c_int, _P, _P],
     "emer_reduce_sum": [_P, c_int64, c_int, _P, _P],

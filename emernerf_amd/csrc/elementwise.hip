@@ -9,42 +9,9 @@
 
 #pragma clang fp contract(off)
 
+#include "contract.h"
+
 namespace emer {
-
-struct Aabb { float lo[3], hi[3]; };
-
-__device__ __forceinline__ Aabb load_aabb(const float *__restrict__ aabb) {
-    Aabb a;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { a.lo[d] = aabb[d]; a.hi[d] = aabb[3 + d]; }
-    return a;
-}
-
-// returns inside flag; v = contracted coords (already zeroed when outside)
-__device__ __forceinline__ bool contract_point(const Aabb &bb, bool unbounded, const float (&p)[3], float (&v)[3]) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) v[d] = (p[d] - bb.lo[d]) / (bb.hi[d] - bb.lo[d]);
-    if (unbounded) {
-        float mag = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { v[d] = v[d] * 2.0f - 1.0f; mag = fmaxf(mag, fabsf(v[d])); }
-        if (!(mag < 1.0f)) {
-            const float s = 2.0f - 1.0f / mag;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) v[d] = s * (v[d] / mag);
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) v[d] = v[d] / 4.0f + 0.5f;
-    }
-    bool inside = true;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) inside = inside && (v[d] > 0.0f) && (v[d] < 1.0f);
-    if (!inside) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) v[d] = v[d] * 0.0f;
-    }
-    return inside;
-}
 
 __global__ __launch_bounds__(256) void contract_fwd_kernel(const float *__restrict__ pos, const float *__restrict__ aabb,
                                                            int unbounded, float *__restrict__ out, int64_t n) {
@@ -164,8 +131,7 @@ __global__ __launch_bounds__(256) void ray_points_kernel(const float *__restrict
         const int64_t r = i / S;
         const float tsum = ts[i] + te[i];
         float p[3], v[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) p[d] = origins[r * 3 + d] + dirs[r * 3 + d] * tsum / 2.0f;
+        ray_point(origins + r * 3, dirs + r * 3, tsum, p);
         contract_point(bb, unbounded != 0, p, v);
         if (out_dim == 4) {
             *reinterpret_cast<float4 *>(normed + i * 4) = make_float4(v[0], v[1], v[2], times[r]);

@@ -515,10 +515,15 @@ def ray_points(origins: Tensor, dirs: Tensor, t_starts: Tensor, t_ends: Tensor, 
 
 
 # ---------------------------------------------------------------------------------- sampler
+SAMPLE_POINTS = os.environ.get("EMER_FUSE_SAMPLE_POINTS", "1") != "0"   # [r5] sampler + sample points in one launch (importance_sample(points=...))
+
+
 def importance_sample(vals: Tensor, cdfs: Tensor, n_intervals: int, jitter: Optional[Tensor] = None,
-                      stot: Optional[Tuple[float, float, str]] = None, intervals: bool = False):
+                      stot: Optional[Tuple[float, float, str]] = None, intervals: bool = False, points=None):
     """nerfacc.pdf.importance_sampling (batched).  Returns (s_edges [R,n+1], t_edges | None), or with
-    ``intervals=True`` (s_edges, t_starts [R,n], t_ends [R,n]) written directly by the kernel (no slicing copies)."""
+    ``intervals=True`` (s_edges, t_starts [R,n], t_ends [R,n]) written directly by the kernel (no slicing copies).
+    ``points=(origins, dirs, aabb, unbounded, want_positions)`` with ``intervals=True``: the launch also computes the new intervals' sample
+    points (what ``ray_points`` would from its result, bitwise) and returns (s_edges, t_starts, t_ends, normed [R,n,3], positions | None)."""
     _check_cuda(vals, cdfs)
     v, c = _f32c(vals), _f32c(cdfs)
     R, m = v.shape
@@ -526,6 +531,21 @@ def importance_sample(vals: Tensor, cdfs: Tensor, n_intervals: int, jitter: Opti
     if j is not None:
         assert j.numel() == R
     assert not intervals or stot is not None
+    if points is not None:
+        assert intervals, "points are computed for the interval form"
+        origins, dirs, aabb, unbounded, want_pos = points
+        o, d, ab = _f32c(origins), _f32c(dirs), _f32c(aabb).view(-1)
+        assert o.shape == (R, 3) and d.shape == (R, 3)
+        with torch.cuda.device(v.device):
+            s_out = torch.empty((R, n_intervals + 1), device=v.device, dtype=torch.float32)
+            t_out = torch.empty((R, n_intervals), device=v.device, dtype=torch.float32)
+            t_end = torch.empty_like(t_out)
+            normed = torch.empty((R, n_intervals, 3), device=v.device, dtype=torch.float32)
+            pos = torch.empty((R, n_intervals, 3), device=v.device, dtype=torch.float32) if want_pos else None
+            t_min, t_max, typ = stot
+            _lib.call("emer_importance_sample_points", _ptr(v), _ptr(c), R, m, n_intervals, _ptr(j), _ptr(s_out), _ptr(t_out), _ptr(t_end),
+                      float(t_min), float(t_max), STOT_TYPES[typ], _ptr(o), _ptr(d), _ptr(ab), int(unbounded), _ptr(normed), _ptr(pos), _stream(v))
+        return s_out, t_out, t_end, normed, pos
     with torch.cuda.device(v.device):
         s_out = torch.empty((R, n_intervals + 1), device=v.device, dtype=torch.float32)
         if intervals:

@@ -51,8 +51,13 @@ class PropNetEstimator(AbstractEstimator):
     @torch.no_grad()
     def sampling(self, prop_sigma_fns: List[Callable], prop_samples: List[int], num_samples: int, n_rays: int,
                  near_plane: float, far_plane: float, sampling_type: str = "uniform_lindisp",
-                 stratified: bool = False, requires_grad: bool = False) -> Tuple[Tensor, Tensor]:
-        """Returns (t_starts, t_ends), both (n_rays, num_samples)."""
+                 stratified: bool = False, requires_grad: bool = False, ray_geometry=None) -> Tuple[Tensor, Tensor]:
+        """Returns (t_starts, t_ends), both (n_rays, num_samples).
+
+        ``ray_geometry`` [r5, optional; not in the reference's signature]: (origins [R,3], dirs [R,3], [(aabb, unbounded, want_positions)
+        per proposal level ... and for the final samples]).  The sampler's launch then also computes the sample points of the intervals it
+        produces (``ops.importance_sample(points=...)``) and hands them to the consumer as ``t_starts._emer_points = (normed, positions,
+        aabb, unbounded)``, so ``sigma_fn`` / ``query_fn`` need no ``ray_points`` launch of their own."""
         assert len(prop_sigma_fns) == len(prop_samples), \
             "The number of proposal networks and the number of samples should be the same."
         dev = self.device
@@ -71,9 +76,21 @@ class PropNetEstimator(AbstractEstimator):
         if stratified and self.jitter_fn is None:
             jitters = iter(torch.rand((len(prop_samples) + 1, n_rays), device=dev).unbind(0))
         draw = (lambda: next(jitters)) if jitters is not None else (lambda: self.jitter_fn(n_rays, dev))
+        def sample(edges_in, cdfs_in, n_out, u, slot):
+            geo = None
+            if ray_geometry is not None and ops.SAMPLE_POINTS and 2 * edges_in.shape[-1] + n_out + 1 <= 10240:
+                geo = ray_geometry[2][slot]
+            if geo is None:
+                return ops.importance_sample(edges_in, cdfs_in, n_out, u, stot=planes, intervals=True)
+            aabb, unbounded, want_pos = geo
+            e, a, b, normed, pos = ops.importance_sample(edges_in, cdfs_in, n_out, u, stot=planes, intervals=True,
+                                                         points=(ray_geometry[0], ray_geometry[1], aabb, unbounded, want_pos))
+            a._emer_points = (normed, pos, aabb, bool(unbounded))
+            return e, a, b
+
         for level, (sigma_fn, n_level) in enumerate(zip(prop_sigma_fns, prop_samples)):
             u = draw() if stratified else None
-            edges, t0, t1 = ops.importance_sample(edges, cdfs, n_level, u, stot=planes, intervals=True)
+            edges, t0, t1 = sample(edges, cdfs, n_level, u, level)
             with torch.set_grad_enabled(requires_grad):
                 sigma = sigma_fn(t0, t1)["density"].squeeze(-1)
                 assert sigma.shape == t0.shape
@@ -83,7 +100,7 @@ class PropNetEstimator(AbstractEstimator):
             else:
                 cdfs = cdfs.detach()
         u = draw() if stratified else None
-        edges, t0, t1 = ops.importance_sample(edges, cdfs.detach(), num_samples, u, stot=planes, intervals=True)
+        edges, t0, t1 = sample(edges, cdfs.detach(), num_samples, u, len(prop_samples))
         if requires_grad:
             self.prop_cache.append((RayIntervals(vals=edges), None, None))
         return t0, t1

@@ -165,8 +165,12 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         fused_density = proposal_network.density_from_rays(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends)
         if fused_density is not None:   # outside autograd recording: positions, encoding and MLP in one launch
             return {"density": fused_density}
-        normed, _ = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
-                                   proposal_network.aabb, proposal_network.unbounded)
+        pre = getattr(t_starts, "_emer_points", None)   # [r5] computed by the sampler's launch for exactly this network's box
+        if pre is not None and pre[2] is proposal_network.aabb and pre[3] == bool(proposal_network.unbounded):
+            normed = pre[0]
+        else:
+            normed, _ = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
+                                       proposal_network.aabb, proposal_network.unbounded)
         return {"density": proposal_network.density_from_normed(normed)}
 
     def query_fn(t_starts, t_ends):
@@ -180,8 +184,12 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         # o + d (t0 + t1) / 2 and the contraction in one kernel (sample positions never carry a gradient,
         # nerfacc_prop_net.py:89); the un-contracted positions are only needed by the flow warp (:553-620)
         want_pos = radiance_field.flow_xyz_encoder is not None
-        normed, positions = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
-                                           radiance_field.aabb, radiance_field.unbounded, want_positions=want_pos)
+        pre = getattr(t_starts, "_emer_points", None)   # [r5] computed by the sampler's launch (same expressions, bitwise)
+        if pre is not None and pre[2] is radiance_field.aabb and pre[3] == bool(radiance_field.unbounded) and (pre[1] is not None or not want_pos):
+            normed, positions = pre[0], pre[1]
+        else:
+            normed, positions = ops.ray_points(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends,
+                                               radiance_field.aabb, radiance_field.unbounded, want_positions=want_pos)
         results_dict = radiance_field(positions, t_dirs, sub_dict, return_density_only=(prefix == "lidar_"),
                                       normed_positions=normed, hash_encodings=False)  # rendering() reads none of them
         results_dict["density"] = results_dict["density"].squeeze(-1)
@@ -206,6 +214,11 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
             sampling_type=cfg.nerf.propnet.sampling_type,
             stratified=radiance_field.training,
             requires_grad=proposal_requires_grad,
+            # [r5] the sampler's launch also computes the sample points of its intervals: every proposal level queries the LAST proposal
+            # network (the closures above), the final samples go to the radiance field
+            ray_geometry=(chunk[prefix + "origins"], chunk[prefix + "viewdirs"],
+                          [(proposal_networks[-1].aabb, proposal_networks[-1].unbounded, False)] * len(proposal_networks)
+                          + [(radiance_field.aabb, radiance_field.unbounded, radiance_field.flow_xyz_encoder is not None)]),
         )
         chunk_results = rendering(t_starts, t_ends, query_fn=query_fn, return_decomposition=return_decomposition)
         extras = chunk_results.pop("extras")

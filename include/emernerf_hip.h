@@ -201,6 +201,13 @@ int emer_ray_points(const float *origins, const float *dirs, const float *t_star
  * Proposal sampler (replaces nerfacc.pdf.importance_sampling + _transform_stot:
  *   third_party/nerfacc_prop_net.py:153,156,172-173,299-339).  Frozen spec: SURVEY.md A.2.
  * ---------------------------------------------------------------------------------------------- */
+/* [r5] emer_importance_sample (interval form: t_starts / t_ends [R][n]) and, in the same launch, the sample points of the new intervals:
+ * what emer_ray_points computes from its result (render_utils.py:316-318,341) -- normed [R][n][3] (scene contraction by aabb /
+ * unbounded), positions [R][n][3] or NULL.  Bitwise the two separate calls.  2 m + n + 1 <= 10240. */
+int emer_importance_sample_points(const float *vals, const float *cdfs, int64_t n_rays, int32_t n_edges_in, int32_t n_intervals_out,
+                                  const float *jitter, float *s_out, float *t_starts, float *t_ends, float t_min, float t_max,
+                                  int stot_type, const float *origins, const float *dirs, const float *aabb, int unbounded,
+                                  float *normed, float *positions, void *stream);
 /* vals/cdfs [R,m] -> s_out [R,n+1] (sorted edges in s) and, if t_out != NULL, t = stot(s_out):
  *   t_ends == NULL: t_out [R,n+1] = the edges;
  *   t_ends != NULL: t_out [R,n] = interval starts, t_ends [R,n] = interval ends (what PropNetEstimator.sampling

@@ -614,6 +614,39 @@ def test_reg_losses_match_the_reference_expressions(hip_lib, R, S, E, terms):
     assert torch.equal(again, out.detach())
 
 
+@pytest.mark.parametrize("R,m,n,unbounded,want_pos,jit", [(8192, 129, 64, True, False, True), (100, 2, 128, True, True, True),
+                                                          (1031, 65, 128, False, True, False), (7, 33, 1, True, False, True),
+                                                          (513, 129, 128, True, True, True)])
+def test_importance_sample_points_equals_the_two_launches(hip_lib, R, m, n, unbounded, want_pos, jit):
+    """ops.importance_sample(points=...) -- the sampler and, in the same launch, the sample points of the intervals it produced -- gives
+    BITWISE the edges / interval starts / ends of emer_importance_sample and the contracted points (and world positions) emer_ray_points
+    computes from them (same device functions and expression order, FMA contraction off in both translation units): the sample positions
+    decide the grid cells, so nothing less than bit equality will do."""
+    from emernerf_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + m + n)
+    vals = torch.sort(torch.rand(R, m, generator=g), dim=-1).values
+    vals[:, 0], vals[:, -1] = 0.0, 1.0
+    w = torch.rand(R, m - 1, generator=g) + 1e-3
+    w[R // 3] = 0.0
+    w[R // 3, 0] = 1.0   # a ray whose mass sits in one bin
+    cdfs = torch.cat([torch.zeros(R, 1), torch.cumsum(w / w.sum(-1, keepdim=True), -1)], -1)
+    jitter = torch.rand(R, generator=g).to(dev) if jit else None
+    o = (torch.rand(R, 3, generator=g) * 60 - 10).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    aabb = torch.tensor([-20.0, -40.0, 0.0, 80.0, 40.0, 20.0]).to(dev)
+    planes = (0.1, 1000.0, "uniform_lindisp")
+    e0, a0, b0 = ops.importance_sample(vals.to(dev), cdfs.to(dev), n, jitter, stot=planes, intervals=True)
+    n0, p0 = ops.ray_points(o, d, a0, b0, aabb, unbounded, want_positions=want_pos)
+    e1, a1, b1, n1, p1 = ops.importance_sample(vals.to(dev), cdfs.to(dev), n, jitter, stot=planes, intervals=True,
+                                              points=(o, d, aabb, unbounded, want_pos))
+    for name, x, y in (("edges", e0, e1), ("starts", a0, a1), ("ends", b0, b1), ("normed", n0, n1)):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+    assert (p1 is None) == (not want_pos)
+    if want_pos:
+        assert torch.equal(p0.view(torch.int32), p1.view(torch.int32))
+
+
 @pytest.mark.parametrize("R,S,terms", [(64, 16, "dsc"), (333, 7, "c"), (2048, 128, "dc")])
 def test_reg_losses_flow_pair_equals_the_four_slices(hip_lib, R, S, terms):
     """ops.reg_losses(flow_pair=(flow [R,S,6], flow2 [2 R S, 6])) -- the cycle term read from the flow MLP's own outputs
