@@ -356,7 +356,7 @@ def test_trainer_state_dict_is_a_snapshot_and_checks_the_layout(hip_lib):
 
 
 def test_flow_step_launch_budget(hip_lib):
-    """A flow-model step at a 2048-ray shard is 90 kernel launches, 11 of them torch's (profiles/r05d_flow2048_step_sequence.txt; round 4:
+    """A flow-model step at a 2048-ray shard is 87 kernel launches, 11 of them torch's (profiles/r05e_flow2048_step_sequence.txt; round 4:
     116 / 27).  The budget below leaves room for the profiler's own bookkeeping but not for a fusion coming undone (the cycle loss back on
     four slices: +9 torch launches; the plain heads back on streamed weight gradients: +15 launches)."""
     from torch.profiler import ProfilerActivity, profile
