@@ -128,6 +128,7 @@ SIGNATURES = {
     "emer_ray_head_bwd": [_P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int32, c_int, _P, _P, _P, _P],
     "emer_ray_wgrad": [_P, c_int32, c_int64, _P],
     "emer_sample_uniform": [_P, c_uint64, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P],
+    "emer_lidar_sample_rays": [_P, c_uint64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_sample_importance": [_P, c_int64, _P, c_uint64, c_int64, _P, _P, _P],
     "emer_buffer_to_pixels": [_P, c_int64, c_int32, c_int32, c_int32, _P, c_int32, c_int32, _P, c_uint64, _P, _P, _P, _P],
     "emer_gen_rays": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -82,6 +82,32 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const uint64_t *__r
     y[i] = (int64_t)rnd_below(seed, 3ull * (uint64_t)i + 2, (uint32_t)H);
 }
 
+// ------------------------------------------------------------------------------------------------ lidar rays
+// datasets/base/lidar_source.py:223-308: sample_uniform_rays draws torch.randint(0, len(cached), n) and get_train_rays gathers origins,
+// directions, ranges and normalised timestamps of the cached scans with it (five launches); one launch here.  idx_in != null: gather only
+// (the draw was made elsewhere, e.g. a recording).
+__global__ __launch_bounds__(256) void lidar_sample_kernel(const uint64_t *__restrict__ seed_word, uint64_t salt, int64_t n, int64_t n_points,
+                                                           const int64_t *__restrict__ idx_in, const float *__restrict__ origins,
+                                                           const float *__restrict__ dirs, const float *__restrict__ ranges,
+                                                           const float *__restrict__ ts, int64_t *__restrict__ idx_out, float *__restrict__ o,
+                                                           float *__restrict__ d, float *__restrict__ r, float *__restrict__ t) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t p;
+    if (idx_in) {
+        p = idx_in[i];
+    } else {   // 64-bit product: scans of a whole log may hold more than 2^32 / 2 points
+        const uint64_t seed = seed_word[0] ^ salt;
+        const uint64_t u = mix64(seed + (uint64_t)i * 0x9E3779B97F4A7C15ull);
+        p = (int64_t)__umul64hi(u, (uint64_t)n_points);
+    }
+    if (idx_out) idx_out[i] = p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[i * 3 + c] = origins[p * 3 + c]; d[i * 3 + c] = dirs[p * 3 + c]; }
+    r[i] = ranges[p];
+    if (ts) t[i] = ts[p];
+}
+
 // ------------------------------------------------------------------------------- importance sampling (race)
 // race key of element i as an order-preserving u32 (positive floats compare like their bit patterns); w <= 0 -> +inf
 __device__ __forceinline__ uint32_t race_key(uint64_t seed, int64_t i, float w) {
@@ -198,6 +224,20 @@ extern "C" int emer_sample_uniform(const uint64_t *seed_word, uint64_t salt, int
     hipLaunchKernelGGL(sample_uniform_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), seed_word, salt, n,
                        candidates, n_candidates, height, width, img_idx, y, x);
     return check_launch("sample_uniform");
+}
+
+extern "C" int emer_lidar_sample_rays(const uint64_t *seed_word, uint64_t salt, int64_t n, int64_t n_points, const int64_t *idx_in,
+                                      const float *origins, const float *directions, const float *ranges, const float *timestamps,
+                                      int64_t *idx_out, float *out_origins, float *out_directions, float *out_ranges, float *out_timestamps,
+                                      void *stream) {
+    EMER_REQUIRE(n >= 0 && n_points >= 1, "lidar_sample_rays: need n >= 0 and at least one cached point");
+    if (n == 0) return EMER_OK;
+    EMER_REQUIRE((seed_word || idx_in) && origins && directions && ranges && out_origins && out_directions && out_ranges,
+                 "lidar_sample_rays: null pointer");
+    EMER_REQUIRE((timestamps == nullptr) == (out_timestamps == nullptr), "lidar_sample_rays: timestamps and their output go together");
+    hipLaunchKernelGGL(lidar_sample_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), seed_word, salt, n, n_points, idx_in,
+                       origins, directions, ranges, timestamps, idx_out, out_origins, out_directions, out_ranges, out_timestamps);
+    return check_launch("lidar_sample_rays");
 }
 
 // workspace: 4 + 2048 u32 words

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void importance_sample_kernel(const float *__r
             const int mid = (lo + hi) >> 1;
             if (c[mid] <= u) lo = mid + 1; else hi = mid;
         }
-        int p = lo - 1;
-        p = p < 0 ? 0 : p;
-        p = p > m - 2 ? m - 2 : p;
-        const float cp = c[p], cq = c[p + 1], vp = v[p], vq = v[p + 1];
+        // nerfacc pdf.cu clamps the two bracketing edges separately (p0 = clamp(p - 1), p1 = clamp(p) over [0, m - 1]): an
+        // u at or beyond the last CDF value brackets (m - 1, m - 1) and returns v[m - 1] through the d < 1e-10 branch
+        const int p0 = lo > 0 ? lo - 1 : 0, p1 = lo < m ? lo : m - 1;
+        const float cp = c[p0], cq = c[p1], vp = v[p0], vq = v[p1];
         const float d = cq - cp;
         float s;
         if (d < 1e-10f) s = (vp + vq) * 0.5f;
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void importance_sample_points_kernel(const flo
             const int mid = (lo + hi) >> 1;
             if (c[mid] <= u) lo = mid + 1; else hi = mid;
         }
-        int p = lo - 1;
-        p = p < 0 ? 0 : p;
-        p = p > m - 2 ? m - 2 : p;
-        const float cp = c[p], cq = c[p + 1], vp = v[p], vq = v[p + 1];
+        // nerfacc pdf.cu clamps the two bracketing edges separately (p0 = clamp(p - 1), p1 = clamp(p) over [0, m - 1]): an
+        // u at or beyond the last CDF value brackets (m - 1, m - 1) and returns v[m - 1] through the d < 1e-10 branch
+        const int p0 = lo > 0 ? lo - 1 : 0, p1 = lo < m ? lo : m - 1;
+        const float cp = c[p0], cq = c[p1], vp = v[p0], vq = v[p1];
         const float d = cq - cp;
         float s;
         if (d < 1e-10f) s = (vp + vq) * 0.5f;

@@ -708,6 +708,13 @@ int emer_ray_wgrad(const emer_ray_wgrad_job *jobs, int32_t n_jobs, int64_t m, vo
 int emer_sample_uniform(const uint64_t *seed_word, uint64_t salt, int64_t n, const int64_t *candidates,
                         int32_t n_candidates, int32_t height, int32_t width, int64_t *img_idx, int64_t *y,
                         int64_t *x, void *stream);
+/* Lidar training rays (datasets/base/lidar_source.py:223-308: sample_uniform_rays' torch.randint over the cached scans + the four
+ * gathers of get_train_rays) in one launch: idx = randint(n_points) (or idx_in[i] when given: gather only), out_* = cached_*[idx].
+ * origins / directions [n_points][3], ranges / timestamps [n_points]; idx_out (may be NULL) receives the drawn indices. */
+int emer_lidar_sample_rays(const uint64_t *seed_word, uint64_t salt, int64_t n, int64_t n_points, const int64_t *idx_in,
+                           const float *origins, const float *directions, const float *ranges, const float *timestamps,
+                           int64_t *idx_out, float *out_origins, float *out_directions, float *out_ranges,
+                           float *out_timestamps, void *stream);
 /* k DISTINCT indices into weights[0..n_weights) with probability proportional to the weights, without replacement
  * (torch.multinomial(w, k, replacement=False), pixel_source.py:588-592): Efraimidis-Spirakis keys -log(u)/w, the k
  * smallest found by a 3-pass radix select.  workspace: 4 + 2048 uint32 words.  Order of flat_out is unspecified. */

@@ -234,9 +234,11 @@ void orc_contract(const float *pos, const float *aabb, int unbounded, float *out
  *   step = (cdf_last - cdf_first) / (n+1)          (float division)
  *   u_k  = cdf_first + (k + beta) * step, k = 0..n (separate mul, add)
  *   beta = 0.5 if jitter == NULL else jitter[ray]  (one U(0,1) per ray, an INPUT)
- *   p    = clamp(#{j : cdf_j <= u_k} - 1, 0, m-2)  (upper-bound search)
- *   d    = cdf[p+1] - cdf[p]
- *   out  = d < 1e-10 ? (v[p]+v[p+1])*0.5 : (u_k - cdf[p]) * ((v[p+1]-v[p]) / d) + v[p]
+ *   p    = #{j : cdf_j <= u_k}                      (upper-bound search, 0..m)
+ *   p0   = clamp(p - 1, 0, m-1), p1 = clamp(p, 0, m-1)   (the two edges clamped SEPARATELY, as nerfacc's
+ *          pdf.cu does [UPSTREAM-RECALL]: u_k >= cdf_last brackets (m-1, m-1) and returns v[m-1])
+ *   d    = cdf[p1] - cdf[p0]
+ *   out  = d < 1e-10 ? (v[p0]+v[p1])*0.5 : (u_k - cdf[p0]) * ((v[p1]-v[p0]) / d) + v[p0]
  * Outputs are sorted by construction.  Must stay bit-exact with sampler.hip. */
 void orc_importance_sample(const float *vals, const float *cdfs, int64_t R, int32_t m,
                            int32_t n, const float *jitter, float *out) {
@@ -250,11 +252,11 @@ void orc_importance_sample(const float *vals, const float *cdfs, int64_t R, int3
             const float u = c0 + ((float)k + beta) * step;
             int32_t lo = 0, hi = m; /* first j with c[j] > u */
             while (lo < hi) { int32_t mid = (lo + hi) >> 1; if (c[mid] <= u) lo = mid + 1; else hi = mid; }
-            int32_t p = lo - 1; if (p < 0) p = 0; if (p > m - 2) p = m - 2;
-            const float d = c[p + 1] - c[p];
+            const int32_t p0 = lo > 0 ? lo - 1 : 0, p1 = lo < m ? lo : m - 1;
+            const float d = c[p1] - c[p0];
             float t;
-            if (d < 1e-10f) t = (v[p] + v[p + 1]) * 0.5f;
-            else t = (u - c[p]) * ((v[p + 1] - v[p]) / d) + v[p];
+            if (d < 1e-10f) t = (v[p0] + v[p1]) * 0.5f;
+            else t = (u - c[p0]) * ((v[p1] - v[p0]) / d) + v[p0];
             out[r * (int64_t)(n + 1) + k] = t;
         }
     }

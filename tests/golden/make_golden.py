@@ -26,20 +26,39 @@ sys.path.insert(0, ROOT)
 AABB = [-20.0, -40.0, 0.0, 80.0, 40.0, 20.0]  # configs/default_config.yaml:42
 
 
-def model_cfg(kind: str, tinterp: bool = False):
-    """Nested config equivalent to configs/default_config.yaml:40-105 with small grids.  ``tinterp``: enable_temporal_interpolation
-    (eval-only: the flow field between two training timesteps, radiance_field.py:359-389,844-905)."""
+def model_cfg(kind: str, tinterp: bool = False, grid: str = "toy"):
+    """Nested config equivalent to configs/default_config.yaml:40-105.  ``grid``: "toy" = small tables (log2_hashmap_size 12-13) and
+    narrow feature heads, so that the fixtures of the seven original cases stay small; "default" = the SHIPPED hyper-parameters of
+    configs/default_config.yaml:62-105 (static xyz D3/L10/F4/16->8192/T2^20, dynamic xyzt D4/L10/F4/32->8192/T2^18, neck 64/64/64, heads
+    64 wide; the flow grid is hard-coded by the reference, radiance_field.py:916-923); "encdefaults" = the same model on the
+    ``HashEncoder`` class defaults (encodings.py:110-118: D3/L16/F2/16->2048/T2^19) -- the static grid BASELINE.json configs[1] names
+    and bench.py times.  ``tinterp``: enable_temporal_interpolation (eval-only: the flow field between two training timesteps,
+    radiance_field.py:359-389,844-905)."""
     from oracle.ref_shims import ns
     dyn = kind in ("dynamic", "flow", "feature")
+    if grid == "toy":
+        xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=6, n_features_per_level=4, base_resolution=16,
+                   max_resolution=512, log2_hashmap_size=13)
+        dxyz = dict(type="HashEncoder", n_input_dims=4, n_levels=5, n_features_per_level=4,
+                    base_resolution=8, max_resolution=128, log2_hashmap_size=12)
+        sem, fdim, fwidth = 16, 16, 32
+    else:
+        assert grid in ("default", "encdefaults"), grid
+        xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=10, n_features_per_level=4, base_resolution=16,
+                   max_resolution=8192, log2_hashmap_size=20)
+        if grid == "encdefaults":
+            xyz = dict(type="HashEncoder", n_input_dims=3, n_levels=16, n_features_per_level=2, base_resolution=16,
+                       max_resolution=2048, log2_hashmap_size=19)
+        dxyz = dict(type="HashEncoder", n_input_dims=4, n_levels=10, n_features_per_level=4,
+                    base_resolution=32, max_resolution=8192, log2_hashmap_size=18)
+        sem, fdim, fwidth = 64, 64, 64
     return ns(
-        xyz_encoder=dict(type="HashEncoder", n_input_dims=3, n_levels=6, n_features_per_level=4, base_resolution=16,
-                         max_resolution=512, log2_hashmap_size=13),
-        dynamic_xyz_encoder=dict(type="HashEncoder", n_input_dims=4, n_levels=5, n_features_per_level=4,
-                                 base_resolution=8, max_resolution=128, log2_hashmap_size=12),
-        neck=dict(base_mlp_layer_width=64, geometry_feature_dim=64, semantic_feature_dim=16),
+        xyz_encoder=xyz,
+        dynamic_xyz_encoder=dxyz,
+        neck=dict(base_mlp_layer_width=64, geometry_feature_dim=64, semantic_feature_dim=sem),
         head=dict(head_mlp_layer_width=64, enable_cam_embedding=kind == "feature", enable_img_embedding=kind != "feature",
                   appearance_embedding_dim=16, enable_sky_head=True, enable_feature_head=kind == "feature",
-                  feature_embedding_dim=16, feature_mlp_layer_width=32, enable_learnable_pe=True,
+                  feature_embedding_dim=fdim, feature_mlp_layer_width=fwidth, enable_learnable_pe=True,
                   enable_dynamic_branch=dyn, enable_shadow_head=dyn, interpolate_xyz_encoding=True,
                   enable_temporal_interpolation=tinterp, enable_flow_branch=kind in ("flow", "feature")),
         unbounded=True, num_cams=3 if kind == "feature" else 1, num_train_timesteps=10,
@@ -56,6 +75,13 @@ def render_cfg(prop_samples, num_samples, chunk=100):
 
 PROP_KW = [dict(n_levels=4, max_resolution=64, log2_hashmap_size=11, n_features_per_level=1),
            dict(n_levels=4, max_resolution=128, log2_hashmap_size=12, n_features_per_level=1)]
+# configs/default_config.yaml:51-58 through builders.py:99-108 (base_resolutions_per_prop is ignored by the reference: base 16)
+PROP_KW_SHIPPED = [dict(n_levels=8, max_resolution=512, log2_hashmap_size=20, n_features_per_level=1),
+                   dict(n_levels=8, max_resolution=2048, log2_hashmap_size=20, n_features_per_level=1)]
+
+
+def prop_kw(grid: str = "toy"):
+    return PROP_KW if grid == "toy" else PROP_KW_SHIPPED
 
 
 def make_rays(R, seed, n_timesteps=10, num_cams=1, image_shape=None):
@@ -113,6 +139,11 @@ def put(out: dict, key: str, t: torch.Tensor):
         out[key + "@sample"] = flat[digest_indices(flat.numel())].float().numpy()
         out[key + "@norm"] = flat.norm().numpy()
         out[key + "@sum"] = flat.sum().numpy()
+        # the 4096 entries of largest magnitude with their positions: a gradient of a multi-million-entry table touched by a few
+        # hundred samples is almost all zeros, so a uniform sample of positions says little about the entries that matter
+        top = torch.topk(flat.abs(), min(4096, flat.numel())).indices.sort().values
+        out[key + "@top_idx"] = top.numpy()
+        out[key + "@top_val"] = flat[top].float().numpy()
 
 
 def golden_loss(results, data, prefix=""):
@@ -154,7 +185,8 @@ def _flat(prefix, d, out):
             out[prefix + k] = v.detach().cpu().numpy()
 
 
-def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int, image_shape=None, lidar=False, tinterp=False):
+def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int, image_shape=None, lidar=False, tinterp=False,
+             grid: str = "toy"):
     """mode: 'train' (stratified, prop nets trained, backward) or 'eval' (decomposition, chunked).  ``tinterp``: the model is built
     with enable_temporal_interpolation and the rays carry timestamps BETWEEN the training timesteps."""
     from oracle import ref_shims
@@ -164,11 +196,11 @@ def run_case(kind: str, mode: str, R: int, prop_samples, num_samples, seed: int,
     from third_party import nerfacc_prop_net as ref_prop
 
     torch.manual_seed(seed)
-    cfg = model_cfg(kind, tinterp)
+    cfg = model_cfg(kind, tinterp, grid)
     model = ref_rf.build_radiance_field_from_cfg(cfg, verbose=False)
     model.set_aabb(AABB)
     model.register_normalized_training_timesteps(torch.linspace(0, 1, cfg.num_train_timesteps), time_diff=1 / cfg.num_train_timesteps)
-    props = [ref_rf.build_density_field(aabb=AABB, unbounded=True, **kw) for kw in PROP_KW]
+    props = [ref_rf.build_density_field(aabb=AABB, unbounded=True, **kw) for kw in prop_kw(grid)]
     randomize_tables({"model/": model, **{f"prop{i}/": p for i, p in enumerate(props)}}, seed + 1)
     out_seed = seed + 1
     prop_opt = torch.optim.Adam([p for n in props for p in n.parameters()], lr=0.01, eps=1e-15, weight_decay=1e-5, betas=(0.9, 0.99))
@@ -257,6 +289,17 @@ CASES = {
     "feature_eval_image": dict(kind="feature", mode="eval", R=60, prop_samples=(24, 16), num_samples=16, seed=500, image_shape=(6, 10)),
     "feature_train": dict(kind="feature", mode="train", R=20, prop_samples=(16, 8), num_samples=12, seed=600),
     "static_eval_chunked": dict(kind="static", mode="eval", R=240, prop_samples=(32, 16), num_samples=24, seed=700),
+}
+
+
+# [r6] The same recordings at the SHIPPED grid hyper-parameters -- the level tables the benchmark and a real training run use
+# (VERDICT r5 missing #3: the toy tables above never reach hashed levels of 2^18 .. 2^20 entries, 16 levels, or F = 2).  Tables are
+# seeded, not stored, so the fixtures stay small (R <= 32, S = 16; gradients of the big tables as digests incl. their largest entries).
+SHIPPED_CASES = {
+    "static_encdefaults_train": dict(kind="static", mode="train", R=32, prop_samples=(24, 16), num_samples=16, seed=1400, grid="encdefaults"),
+    "static_shipped_train": dict(kind="static", mode="train", R=32, prop_samples=(24, 16), num_samples=16, seed=1500, grid="default"),
+    "dynamic_shipped_train": dict(kind="dynamic", mode="train", R=24, prop_samples=(24, 16), num_samples=16, seed=1600, grid="default"),
+    "flow_shipped_train": dict(kind="flow", mode="train", R=16, prop_samples=(24, 16), num_samples=16, seed=1700, grid="default"),
 }
 
 
@@ -428,6 +471,63 @@ def run_pixel_source_case(seed: int = 1200, n_imgs: int = 6, hw=(12, 20), num_ca
     return out
 
 
+def run_lidar_source_case(seed: int = 1300, n_steps: int = 6, n_train: int = 80):
+    """datasets/base/lidar_source.py UNMODIFIED (loaded by file path; omegaconf stubbed): ``sample_uniform_rays`` with its cached
+    per-timestep subset (:223-275), ``get_train_rays`` (:277-308; its torch.randint draw is recorded with the batch) for a first
+    candidate list, for a CHANGED list ("Recomputing cached indices") and for the same candidates given as a Tensor, and
+    ``get_render_rays`` (:310-330), on a tiny synthetic log with scans of unequal length."""
+    import importlib.util
+    from oracle import ref_shims
+    ref_shims.install()
+    spec = importlib.util.spec_from_file_location("ref_lidar_source", os.path.join(ref_shims.REFERENCE_ROOT, "datasets", "base", "lidar_source.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Source(mod.SceneLidarSource):   # the abstract hooks read files; the tensors are set directly instead
+        def create_all_filelist(self):
+            pass
+
+        def load_calibrations(self):
+            pass
+
+        def load_lidar(self):
+            pass
+
+    g = torch.Generator().manual_seed(seed)
+    src = Source(ref_shims.ns(), device=torch.device("cpu"))
+    counts = torch.randint(20, 60, (n_steps,), generator=g)
+    steps = torch.arange(n_steps).repeat_interleave(counts)
+    n = steps.numel()
+    src.origins = torch.randn(n, 3, generator=g) * 5
+    d = torch.randn(n, 3, generator=g)
+    src.directions = d / d.norm(dim=-1, keepdim=True)
+    src.ranges = torch.rand(n, 1, generator=g) * 70 + 1     # [n, 1]: torch.norm(..., keepdim=True), datasets/waymo.py:293
+    src._timesteps = steps.long()
+    src.register_normalized_timestamps(steps.float() / (n_steps - 1))
+    out = {"src/origins": src.origins.numpy(), "src/directions": src.directions.numpy(), "src/ranges": src.ranges.numpy(),
+           "src/timesteps": src._timesteps.numpy(), "src/normalized_timestamps": src.normalized_timestamps.numpy(),
+           "num_timesteps": np.array(src.num_timesteps), "closest_0p37": np.array(int(src.find_closest_timestep(0.37)))}
+
+    def record(tag, cand):
+        torch.manual_seed(seed + len(tag))
+        idx = src.sample_uniform_rays(n_train, candidate_indices=cand)
+        torch.manual_seed(seed + len(tag))
+        batch = src.get_train_rays(n_train, candidate_indices=cand)
+        out[tag + "/cand"] = np.asarray(cand if not isinstance(cand, torch.Tensor) else cand.numpy())
+        out[tag + "/lidar_idx"] = idx.numpy()
+        out[tag + "/cached_indices"] = src.cached_indices.numpy()
+        for k in ("cached_origins", "cached_directions", "cached_ranges", "cached_normalized_timestamps"):
+            out[tag + "/" + k] = getattr(src, k).numpy()
+        for k, v in batch.items():
+            out[tag + "/batch/" + k] = v.numpy()
+    record("first", [1, 3, 4])
+    record("changed", [0, 2, 5, 3])              # "Recomputing cached indices"
+    record("tensor", torch.tensor([0, 2, 5, 3]))   # a Tensor equal to the cache: no rebuild
+    for k, v in src.get_render_rays(2).items():
+        out["render2/" + k] = v.numpy()
+    return out
+
+
 RENDER_PIXELS_CASES = {
     "render_pixels_static": dict(kind="static", seed=800),
     "render_pixels_flow": dict(kind="flow", seed=900),
@@ -448,7 +548,12 @@ def main():
         path = os.path.join(HERE, "pixel_source.npz")
         np.savez_compressed(path, **out)
         print(f"pixel_source: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB")
-    for name, kw in {**CASES, **TINTERP_CASES}.items():
+    if not only or "lidar_source" in only:
+        out = run_lidar_source_case()
+        path = os.path.join(HERE, "lidar_source.npz")
+        np.savez_compressed(path, **out)
+        print(f"lidar_source: {len(out)} arrays, {os.path.getsize(path) / 1e3:.0f} kB")
+    for name, kw in {**CASES, **TINTERP_CASES, **SHIPPED_CASES}.items():
         if only and name not in only:
             continue
         out = run_case(**kw)

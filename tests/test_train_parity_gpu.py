@@ -22,44 +22,54 @@ def _run(kind, K, use_graph, table_init):
     from oracle.train_parity import cotrain
     key = (kind, K, use_graph, table_init)
     if key not in _CACHE:
-        _CACHE[key] = cotrain(kind, torch.device("cuda:0"), K=K, rays=512, samples=64, prop_samples=(64, 32), num_iters=200,
-                              table_init=table_init, use_graph=use_graph)
+        # static / dynamic: 512 rays x 64 samples (proposal rounds 64 + 32); flow / feature (seven xyzt evaluations per sample on the
+        # CPU oracle): 256 rays x 32 samples (proposal rounds 32 + 16)
+        shape = dict(rays=256, samples=32, prop_samples=(32, 16)) if kind in ("flow", "feature") else dict(rays=512, samples=64, prop_samples=(64, 32))
+        _CACHE[key] = cotrain(kind, torch.device("cuda:0"), K=K, num_iters=200, table_init=table_init, use_graph=use_graph, **shape)
     return _CACHE[key]
 
 
 @pytest.mark.parametrize("kind,K,use_graph,table_init", [("static", 30, False, 0.3), ("static", 30, True, 0.3), ("static", 30, False, None),
-                                                         ("dynamic", 10, False, 0.3)])
+                                                         ("dynamic", 10, False, 0.3), ("flow", 8, False, 0.3), ("flow", 8, True, 0.3),
+                                                         ("feature", 8, False, 0.3)])
 def test_k_step_training_stays_with_the_oracle(hip_lib, oracle, kind, K, use_graph, table_init):
-    """512 rays x 64 samples (proposal rounds 64 + 32), K steps, num_iters = 200 (so that the K steps cross the LR warm-up:
-    0.01 -> 1 over 20 steps) and a proposal schedule that reaches its one-in-six steady state inside K.  ``table_init`` None = tcnn's
-    +-1e-4 initialisation (the reference's step 0), 0.3 = spatially varying tables."""
+    """K optimizer steps of the HIP trainer and of the oracle from identical parameters, num_iters = 200 (so that the K steps cross
+    the LR warm-up: 0.01 -> 1 over 20 steps) and a proposal schedule that reaches its one-in-six steady state inside K.
+    ``table_init`` None = tcnn's +-1e-4 initialisation (the reference's step 0), 0.3 = spatially varying tables.  flow / feature =
+    BASELINE configs[3] / [4]: flow-warped temporal aggregation with the noise replayed, flow-cycle loss (train_emernerf.py:700-716,
+    radiance_field.py:553-620), feature head + learnable PE with the feature L2 loss."""
     r = _run(kind, K, use_graph, table_init)
     assert r["launch_mode"] == ("hipgraph" if use_graph else "eager"), "graph capture fell back to eager launches"
     assert any(r["prop_flags"]) and not all(r["prop_flags"]), "K steps must contain both step types"
     hl, rl = np.array(r["hip_losses"]), np.array(r["ref_losses"])
     assert np.isfinite(hl).all() and np.isfinite(rl).all()
-    assert hl[-5:].mean() < hl[:5].mean(), "training must reduce the loss"
+    assert hl[-3:].mean() < hl[:3].mean(), "training must reduce the loss"
     print(f"\n[{kind} K={K} graph={use_graph} init={table_init}] loss {hl[0]:.5f} -> {hl[-1]:.5f}; max rel loss diff {r['loss_max_rel_diff']:.2e}; "
           f"PSNR vs GT hip {r['hip_psnr_vs_gt_db']:.4f} dB / oracle {r['ref_psnr_vs_gt_db']:.4f} dB; travel {r['travel']:.3e}, "
-          f"param l2 diff {r['param_l2_diff']:.3e}, max abs {r['param_max_abs_diff']:.3e}")
+          f"param l2 diff {r['param_l2_diff']:.3e} (without the {r['n_sign_flipped']} sign-flipped table entries of {r['n_table_entries']}: "
+          f"{r['param_l2_diff_excl']:.3e}), max abs {r['param_max_abs_diff']:.3e}")
     # (1) the loss trajectory, step by step
     # (measured on MI355X: 1e-7 .. 3e-6)
     assert r["loss_max_rel_diff"] <= 5e-5, f"per-step loss differs by {r['loss_max_rel_diff']:.3e} relative"
     # (2) PSNR against the ground truth after K steps: both paths within 0.005 dB of each other (measured: equal to 4 decimals)
     assert abs(r["hip_psnr_vs_gt_db"] - r["ref_psnr_vs_gt_db"]) <= 0.005
-    # (3) the parameters after K steps: the two trajectories' distance is a small fraction of the distance travelled ...
-    # (measured: 6e-5 with +-0.3 tables, 2e-4 dynamic, 1e-3 from tcnn's +-1e-4 initialisation, where most table entries' gradients
-    # are rounding-sized and Adam's first steps are sign-sized)
-    # [r5] From tcnn's initialisation a single rounding-sized gradient that changes sign moves an entry by 2 lr per step, so that case's
-    # parameter distance varies from run to run (1e-3 typically; one run in ~20 of the GPU suite went past 5e-3 while its losses and
-    # PSNR stayed at 2e-6 / 0.0000 dB of the oracle's): its bound is 3x wider, the loss / PSNR bounds above are the same for every case.
-    wide = 3.0 if table_init is None else 1.0
-    assert r["param_l2_diff"] <= wide * 5e-3 * r["travel"], f"parameters differ by {r['param_l2_diff'] / r['travel']:.3e} of the distance travelled"
+    # (3) the parameters after K steps: the two trajectories' distance is a small fraction of the distance travelled
+    # (measured: 6e-5 with +-0.3 tables, 2e-4 dynamic).  [r6] ONE bound for every case.  From tcnn's +-1e-4 initialisation most table
+    # entries' gradients are rounding-sized and Adam's first steps are sign-sized, so an entry whose gradient changes sign between
+    # the two sides ends a whole step away: those entries are identified (further apart than half of the smallest step of the
+    # schedule, oracle/train_parity.py), COUNTED and bounded in number, and everything else keeps the bound of the other cases --
+    # round 5 had widened the bound 3x for this case instead.
+    # Measured over six seeds of the tcnn-initialised case and the +-0.3 case (tools/r06_parity_probe.py, profiles/r06_parity_probe.txt):
+    # 1 850 .. 15 751 flipped entries of 22.4 M (<= 7e-4), distance without them 7e-6 .. 2.1e-4 of the travel, with them 5e-5 .. 1.5e-3.
+    assert r["param_l2_diff_excl"] <= 1e-3 * r["travel"], \
+        f"parameters differ by {r['param_l2_diff_excl'] / r['travel']:.3e} of the distance travelled (sign-flipped entries excluded)"
+    assert r["n_sign_flipped"] <= 2e-3 * r["n_table_entries"], \
+        f"{r['n_sign_flipped']} of {r['n_table_entries']} table entries took a sign-sized step in the other direction"
     # ... and no MLP / embedding parameter is further apart than a few of Adam's (sign-sized) steps at the final learning rate
     lr_end = 0.01
     for name, st in r["param_stats"].items():
         if not name.endswith("tcnn_encoding.params"):
-            assert st["max_abs_diff"] <= wide * 3 * lr_end, f"{name}: {st['max_abs_diff']:.3e}"
+            assert st["max_abs_diff"] <= 3 * lr_end, f"{name}: {st['max_abs_diff']:.3e}"
 
 
 def test_graph_and_eager_training_agree(hip_lib, oracle):
