@@ -30,6 +30,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (MI355X_MICROARCH.md); 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input matrix peak, for reference (round 2 ran the heads on it)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 N_BATCHES = 8  # seeded ray batches rotated through the steps (a new batch every step)
+PROP_SHAPE = (3, 8, 1)  # (D, L, F) of the proposal networks' grids (configs/default_config.yaml:51-58)
 
 
 def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
@@ -37,6 +38,35 @@ def grid_alg_bytes(D, L, F, sp=4, so=4, sg=4):
     fwd = 4 * D + (2 ** D) * L * F * sp + L * F * so
     bwd = 4 * D + L * F * so + 2 * (2 ** D) * L * F * sg
     return fwd, bwd
+
+
+def grid_roofline(timer, shape, steps: int, fwd_names=("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac"),
+                  bwd_names=("emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add", "emer_hashgrid_bwd_params_sliced_levels")):
+    """HBM roofline of the grid launches of shape (D, L, F) recorded by ``timer`` over ``steps`` steps: achieved = SURVEY 8(d)'s
+    algorithmic bytes per sample x the samples every launch really processed (``timer.ns``) / the summed launch durations."""
+    us, tags, ns = timer.elapsed_us(), timer.tags, timer.ns
+    D, L, F = shape
+    fb, bb = grid_alg_bytes(D, L, F)
+
+    def pick(names):
+        t, n, k = 0.0, 0, 0
+        for nm in names:
+            for u, tg, cnt in zip(us.get(nm, []), tags.get(nm, []), ns.get(nm, [])):
+                if tg == shape and cnt:
+                    t, n, k = t + u, n + cnt, k + 1
+        return t, n, k
+    (tf, nf, kf), (tb, nb, kb) = pick(fwd_names), pick(bwd_names)
+    if not kf:
+        return None
+    out = {"grid": f"D{D}/L{L}/F{F}", "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "algorithmic_bytes_per_sample": {"fwd": fb, "bwd": bb},
+           "launches_per_step": {"fwd": kf / steps, "bwd": kb / steps}, "ms_per_step": {"fwd": tf / 1e3 / steps, "bwd": tb / 1e3 / steps},
+           "samples_per_step": {"fwd": nf / steps, "bwd": nb / steps},
+           "achieved_fwd": fb * nf / (tf * 1e-6) / 1e9, "frac_fwd": fb * nf / (tf * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+    if kb:
+        out.update({"achieved_bwd": bb * nb / (tb * 1e-6) / 1e9, "frac_bwd": bb * nb / (tb * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                    "frac_encode_plus_bwd_per_sample": (fb + bb) / ((tf / nf + tb / nb) * 1e-6) / 1e9 / HBM_PEAK_GBPS})
+    return out
 
 
 def cpu_baseline(trainer, rays: int, samples: int, steps: int = 12):
@@ -128,6 +158,25 @@ def pmc_traffic(dominant: str, D: int, F: int, args):
         return None, None
 
 
+def pmc_step_traffic(args):
+    """HBM bytes of one whole step from the same PMC summary: sum over kernels of bytes per launch x launches, divided by the steps of
+    the profiled command (= launches of the main table's backward, one per step).  None unless recorded on these sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files or (args.rays, args.samples, args.kind) != (8192, 128, "static"):
+        return None
+    try:
+        j = json.load(open(files[-1]))
+        if j.get("source_sha16") != source_hash():
+            return None
+        ks = j["kernels"]
+        steps = ks["hashgrid_bwd_params_sliced_kernel<3, 2>"]["launches"]
+        return {"bytes_per_step": sum(v["hbm_bytes"] * v["launches"] for v in ks.values()) / steps, "steps_profiled": steps,
+                "source": f"profiles/{os.path.basename(files[-1])}"}
+    except Exception:
+        return None
+
+
 def rccl_summary(path, world):
     """The lines of RCCL's INFO log (rank 0) that show how many ranks the communicator has and what it built."""
     keep, n = [], 0
@@ -205,6 +254,12 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
             "sample_evaluations_per_step": evals * N, "algorithmic_bytes_per_sample": {"fwd": fb4, "bwd": bb4},
             "frac_fwd": fb4 * evals * N / (sum(f4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS,
             "frac_bwd": bb4 * evals * N / (sum(b4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS}
+    # [r6] the static table these configs run (default_config.yaml:62-69: D3/L10/F4/T2^20), priced like the headline's main grid
+    c3 = tr.cfg.xyz_encoder
+    rs = grid_roofline(timer, (c3.n_input_dims, c3.n_levels, c3.n_features_per_level), steps)
+    if rs is not None:
+        rs["grid"] += f"/T2^{c3.log2_hashmap_size} (static xyz table of this config)"
+        out["roofline_static_grid"] = rs
     del tr
     torch.cuda.empty_cache()
     return out
@@ -331,15 +386,22 @@ def main():
         dist.barrier()
         if rank == 0:
             trainer.comm_events = []   # HIP events around the exposed part of every step's gradient exchange
+    # [r6] SURVEY 8(d) asks for the MEDIAN of hipEvent-timed steps: one event per step boundary on the stream the step runs on (the
+    # replayed graph, the exchange and Adam all go through torch's current stream), read after the timed region.  `value` stays the
+    # contract's wall-clock figure (K steps between two synchronisations, MAX over ranks); the median / p10 / p90 sit next to it.
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_ in range(args.steps):
+        step_events[i_].record()
         trainer.train_step(next_batch())
+    step_events[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
+    step_ms = sorted(step_events[i_].elapsed_time(step_events[i_ + 1]) for i_ in range(args.steps))
     exposed_comm = None
     if dp and rank == 0 and trainer.comm_events:
         ev = [a.elapsed_time(b) for a, b in trainer.comm_events]
@@ -530,6 +592,14 @@ def main():
         ach = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         both = (fwd_b + bwd_b) * N / ((f_avg + b_avg) * 1e-6) / 1e9 if (f_avg + b_avg) > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dominant, D, F, args)
+        # [r6] the proposal networks' grids (L8/F1/T2^20, default_config.yaml:51-58): two forward launches per step (8192 x 128 and
+        # 8192 x 64 samples on the SAME table -- the reference's late-binding lambda), backward + in-kernel add on one step in six
+        pk = PROP_SHAPE
+        roof_prop = grid_roofline(timer, pk, args.steps)
+        if roof_prop is not None:
+            roof_prop["grid"] += "/T2^20 (proposal nets; both rounds query the last one)"
+            roof_prop["timed_in"] = "the same event-bracketed loop as `roofline`"
+        step_traffic = pmc_step_traffic(args)
         roof2 = None
         if clustered is not None:
             us2, tg2 = clustered.elapsed_us(), clustered.tags
@@ -624,6 +694,14 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_p10": step_ms[len(step_ms) // 10], "ms_per_step_p90": step_ms[(9 * len(step_ms)) // 10],
+            "ms_per_step_note": "median / p10 / p90 of HIP events recorded at every step boundary of the timed region (rank 0); `value` and "
+                                "`ms_per_step` are the wall-clock mean of the same steps (contract), "
+                                f"mean / median = {elapsed / args.steps * 1e3 / step_ms[len(step_ms) // 2]:.4f}",
+            "hbm_frac_step": None if step_traffic is None else
+            {"bytes_per_step": step_traffic["bytes_per_step"], "achieved": step_traffic["bytes_per_step"] / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": step_traffic["bytes_per_step"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+             "source": step_traffic["source"] + ": sum over kernels of PMC bytes per launch x launches / profiled steps, over this run's step time"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -649,6 +727,7 @@ def main():
                          if (args.graph and world == 1) else "HIP events on the dispatch packets inside the timed region",
                          "grid_encode_plus_bwd": {"achieved": both, "frac": both / HBM_PEAK_GBPS, "fwd_avg_us": f_avg, "fwd_us_spread": spread(f_us), "bwd_us_spread": spread(b_us),
                                                   "bwd_avg_us": b_avg, "algorithmic_bytes": (fwd_b + bwd_b) * N}},
+            "roofline_prop": roof_prop,
             "roofline_trained_like": roof2,
             "roofline_fp16_tables": roof16,
             "roofline_xyzt": roof_xyzt,

@@ -143,6 +143,7 @@ INT64_FUNCTIONS = {
     "emer_rgb_head_bwd_workspace": [c_int64],
     "emer_rgb_head_bwd_fused_workspace": [c_int64, c_int32],
     "emer_density_bwd_fused_workspace": [c_int32, c_int32, c_int64],
+    "emer_importance_sample_points_capacity": [],
 }
 
 ALLOW_MISSING_SYMBOLS = False  # never set by the product path
@@ -187,6 +188,7 @@ class KernelTimer:
         self.names = set(names)
         self.events = {n: [] for n in self.names}
         self.tags = {n: [] for n in self.names}
+        self.ns = {n: [] for n in self.names}   # grid entry points: samples of the launch (the roofline's algorithmic bytes are per sample)
         self.tag = None
 
     def elapsed_us(self):
@@ -198,6 +200,9 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer to enable
 
 
+# position of the sample count among the arguments of the grid entry points (include/emernerf_hip.h)
+_N_ARG = {"emer_hashgrid_fwd": 8, "emer_hashgrid_fwd_jac": 9, "emer_hashgrid_bwd_params_sliced": 7, "emer_hashgrid_bwd_params_sliced_add": 7,
+          "emer_hashgrid_bwd_params_sliced_levels": 7, "emer_hashgrid_bwd_params": 7, "emer_hashgrid_bwd_input": 8, "emer_hashgrid_bwd_input_jac": 6}
 _TIGHT = ("emer_hashgrid_fwd", "emer_hashgrid_fwd_jac", "emer_hashgrid_bwd_params_sliced", "emer_hashgrid_bwd_params_sliced_add", "emer_hashgrid_bwd_params_sliced_levels")  # entries that record events around their kernel themselves
 
 
@@ -223,6 +228,7 @@ def call(name: str, *args) -> None:
             d = args[0]._obj
             tag = (d.n_dims, d.n_levels, d.n_features)
         t.tags[name].append(tag)
+        t.ns[name].append(int(args[_N_ARG[name]]) if name in _N_ARG else None)
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

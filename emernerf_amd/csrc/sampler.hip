@@ -171,14 +171,23 @@ extern "C" int emer_importance_sample(const float *vals, const float *cdfs, int6
     return check_launch("importance_sample");
 }
 
+// Floats of LDS a ray may use in emer_importance_sample_points (2 m + n + 1 must not exceed it): the device's LDS per workgroup over
+// the four rays of a workgroup -- 10240 on gfx950 (160 KiB), asked from the runtime rather than assumed.
+extern "C" int64_t emer_importance_sample_points_capacity(void) {
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+    return (int64_t)bytes / (kRaysPerBlock * (int64_t)sizeof(float));
+}
+
 // emer_importance_sample (interval form) + emer_ray_points of its result in one launch.  normed [R][n][3], positions [R][n][3] or NULL.
-// Needs 2 m + n + 1 <= 10240 floats of LDS per ray (four rays per workgroup): larger histograms take the two separate calls.
+// Needs 2 m + n + 1 <= emer_importance_sample_points_capacity() floats of LDS per ray: larger histograms take the two separate calls.
 extern "C" int emer_importance_sample_points(const float *vals, const float *cdfs, int64_t R, int32_t m, int32_t n, const float *jitter,
                                              float *s_out, float *t_starts, float *t_ends, float t_min, float t_max, int stot_type,
                                              const float *origins, const float *dirs, const float *aabb, int unbounded, float *normed,
                                              float *positions, void *stream) {
     EMER_REQUIRE(R >= 0 && n >= 1, "importance_sample_points: bad sizes R=%lld n=%d", (long long)R, n);
-    EMER_REQUIRE(m >= 2 && m <= 4096 && 2 * (int64_t)m + n + 1 <= 10240, "importance_sample_points: m=%d edges, n=%d intervals per ray do not fit the LDS", m, n);
+    EMER_REQUIRE(m >= 2 && m <= 4096 && 2 * (int64_t)m + n + 1 <= emer_importance_sample_points_capacity(),
+                 "importance_sample_points: m=%d edges, n=%d intervals per ray do not fit the LDS", m, n);
     if (R == 0) return EMER_OK;
     EMER_REQUIRE(vals && cdfs && s_out && t_starts && t_ends && origins && dirs && aabb && normed, "importance_sample_points: null pointer");
     EMER_REQUIRE(stot_type >= 0 && stot_type <= 5, "importance_sample_points: unknown stot_type %d", stot_type);

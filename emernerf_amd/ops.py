@@ -516,6 +516,16 @@ def ray_points(origins: Tensor, dirs: Tensor, t_starts: Tensor, t_ends: Tensor, 
 
 # ---------------------------------------------------------------------------------- sampler
 SAMPLE_POINTS = os.environ.get("EMER_FUSE_SAMPLE_POINTS", "1") != "0"   # [r5] sampler + sample points in one launch (importance_sample(points=...))
+_SAMPLE_POINTS_CAP = None
+
+
+def sample_points_capacity() -> int:
+    """Floats of LDS per ray the fused sampler + points launch may use (2 m + n + 1 must fit): asked from the device once
+    (emer_importance_sample_points_capacity; 10240 on gfx950)."""
+    global _SAMPLE_POINTS_CAP
+    if _SAMPLE_POINTS_CAP is None:
+        _SAMPLE_POINTS_CAP = int(_lib.load().emer_importance_sample_points_capacity())
+    return _SAMPLE_POINTS_CAP
 
 
 def importance_sample(vals: Tensor, cdfs: Tensor, n_intervals: int, jitter: Optional[Tensor] = None,

@@ -78,7 +78,7 @@ class PropNetEstimator(AbstractEstimator):
         draw = (lambda: next(jitters)) if jitters is not None else (lambda: self.jitter_fn(n_rays, dev))
         def sample(edges_in, cdfs_in, n_out, u, slot):
             geo = None
-            if ray_geometry is not None and ops.SAMPLE_POINTS and 2 * edges_in.shape[-1] + n_out + 1 <= 10240:
+            if ray_geometry is not None and ops.SAMPLE_POINTS and 2 * edges_in.shape[-1] + n_out + 1 <= ops.sample_points_capacity():
                 geo = ray_geometry[2][slot]
             if geo is None:
                 return ops.importance_sample(edges_in, cdfs_in, n_out, u, stot=planes, intervals=True)

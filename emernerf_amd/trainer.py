@@ -270,7 +270,12 @@ class Trainer:
         # skips them (no weight decay, no moment update).  They live in their own range so the fused Adam skips them too.
         import os as _os
         self.dp_mode = dp_mode or _os.environ.get("EMER_DP_MODE", "allreduce")
-        assert self.dp_mode in ("allreduce", "rs_ag"), self.dp_mode
+        # [r6] EMER_DP_SINGLE=1 (or dp_mode="single"): BASELINE.json's literal exchange -- ONE all-reduce of the step's gradient range after
+        # the backward, no bucket launched from inside it (what a hipGraph-replayed step does anyway), also with eager launches, so that
+        # a multi-GPU run can A/B "one all-reduce" against the bucketed default in one command
+        if self.dp_mode == "allreduce" and _os.environ.get("EMER_DP_SINGLE") == "1":
+            self.dp_mode = "single"
+        assert self.dp_mode in ("allreduce", "rs_ag", "single"), self.dp_mode
         # test hook, decided ONCE (a per-call fallback would let one rank issue all_reduce while its peers sit in reduce_scatter):
         # a backend without reduce-scatter can emulate it with an all-reduce when the environment says so explicitly
         self._rs_emulate = _os.environ.get("EMER_DP_RS_EMULATE") == "1"
@@ -357,10 +362,12 @@ class Trainer:
                 "ranges": {k: tuple(v) for k, v in self.flat.ranges.items()}, "world_size": self.world_size, "dp_mode": self.dp_mode,
                 "loss_scale": self.loss_scale, "num_iters": self.num_iters}
 
-    def load_state_dict(self, sd: Dict[str, object]) -> None:
+    def load_state_dict(self, sd: Dict[str, object], restore_schedule: bool = False) -> None:
         """Restore ``state_dict()``.  The moments are indexed by flat-buffer offset, so the saved layout must be this trainer's
         (same model kind, same rs_ag padding = same world size in that mode); dictionaries of rounds before the layout was recorded
-        are accepted when the buffer length matches."""
+        are accepted when the buffer length matches.  The length of the LR schedule and the loss scale are the CONSTRUCTOR's (the
+        reference takes them from the config of the resuming run, not from the checkpoint: train_emernerf.py:475-476, builders.py:64-89);
+        a checkpoint that was written with other values is reported with a warning, ``restore_schedule=True`` adopts its values."""
         if "ranges" in sd:
             mine = {k: tuple(v) for k, v in self.flat.ranges.items()}
             theirs = {k: tuple(v) for k, v in sd["ranges"].items()}
@@ -373,8 +380,14 @@ class Trainer:
         self.opt_steps = dict(sd["opt_steps"])
         self.step_count, self.sched_ticks = int(sd["step_count"]), int(sd["sched_ticks"])
         self.requires_grad_fn.since_last = int(sd["since_last"])
-        self.loss_scale = float(sd.get("loss_scale", self.loss_scale))
-        self.num_iters = int(sd.get("num_iters", self.num_iters))
+        for key, cast in (("loss_scale", float), ("num_iters", int)):
+            if key in sd and cast(sd[key]) != getattr(self, key):
+                if restore_schedule:
+                    setattr(self, key, cast(sd[key]))
+                else:
+                    import warnings
+                    warnings.warn(f"checkpoint was written with {key} = {sd[key]}, this trainer was constructed with {getattr(self, key)}: "
+                                  f"keeping the constructor's (load_state_dict(..., restore_schedule=True) adopts the checkpoint's)")
 
     def _with_regularisers(self, base: Tensor, results, data, grad_scale: float = 1.0) -> Tensor:
         """``base`` + the regularisers of the dynamic / flow / feature models (``base`` itself for the static model): dynamic-density
@@ -463,8 +476,8 @@ class Trainer:
         encoder of the forward pass): every MLP / embedding gradient of the main model is enqueued by now, so their
         (small) all-reduce starts here and runs on RCCL's stream while the grid backward -- the longest kernel of the
         step -- computes the table gradient.  Only the table bucket is exposed at the end of the backward."""
-        if self._dp_on and self.dp_mode == "rs_ag":
-            return  # one reduce-scatter per group after the backward
+        if self._dp_on and self.dp_mode in ("rs_ag", "single"):
+            return  # one reduce-scatter per group / one all-reduce after the backward
         if self._dp_on and self.dp_debug and not self._early_done and not self._hold_buckets:
             # debug: record what the early ranges hold NOW instead of reducing them; _exchange_grads checks nothing wrote later
             fused.join_side_stream()   # (as the real bucket does: launches moved to a side stream count as enqueued)
@@ -479,7 +492,7 @@ class Trainer:
         """Called by the static table's backward between its two launches (ops._HashGridLMFn.backward): elements [lo, hi) of the
         table's gradient are final; their all-reduce starts now and overlaps the second launch.  Not inside a graph capture and not
         during its warm-up (then the whole table goes with the late bucket)."""
-        if not self._dp_on or self.dp_mode == "rs_ag" or self._hold_buckets or torch.cuda.is_current_stream_capturing():
+        if not self._dp_on or self.dp_mode != "allreduce" or self._hold_buckets or torch.cuda.is_current_stream_capturing():
             return
         base = next(o for p, o in self.flat._table_offsets if p is param)
         a, b = base + lo, base + hi
@@ -497,7 +510,7 @@ class Trainer:
         """On the steps that train the proposal net its loss is back-propagated BEFORE the main loss, so its gradient range
         is final while the whole main backward (~2 ms) is still ahead: its all-reduce (40 MB at the metric configuration)
         starts here and is hidden completely.  Eager launches only (a collective cannot be captured into the step's graph)."""
-        if self._dp_on and self.dp_mode == "rs_ag":
+        if self._dp_on and self.dp_mode != "allreduce":
             return
         if self._dp_on and self._prop_work is None and not self._hold_buckets and not torch.cuda.is_current_stream_capturing():
             fused.join_side_stream()
@@ -633,21 +646,26 @@ class Trainer:
         if self.use_graph:
             first = prop_grad not in self._graphs   # the capture of this step type happens in this call (same schedule on every rank)
             failed, err = False, None
+            fatal = None
             try:
                 loss = self._graphed_forward_backward(data, prop_grad)
-            except FloatingPointError:  # EMER_CHECK_FINITE=1: a replayed step saw a non-finite gradient -- not a capture problem
-                raise
+            except FloatingPointError as e:  # EMER_CHECK_FINITE=1: a replayed step saw a non-finite gradient -- not a capture problem
+                fatal = e
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, once
                 if self._dp_on and not first:
                     raise   # a replay that fails later cannot be agreed on (the peers are not at a collective)
                 failed, err = True, e
             # A rank that switched to eager launches on its own would issue the early / table / xyzt buckets while its peers, still
             # replaying graphs, issue one all-reduce over the whole range: mismatched collectives hang or corrupt the gradients.  So the
-            # ranks agree right after the capture attempt: if it failed anywhere, everybody falls back.
+            # ranks agree right after the capture attempt: if it failed anywhere, everybody falls back.  The vote is taken on EVERY way
+            # out of a first-capture call -- also when this rank is about to raise (its peers sit in the vote's all-reduce and would
+            # wait for it forever otherwise); the error is re-raised after the vote.
             if self._dp_on and first:
-                failed_here, failed = failed, agree_any(failed, self.device)
-                if failed and not failed_here:
+                failed_here, failed = failed, agree_any(failed or fatal is not None, self.device)
+                if failed and not failed_here and fatal is None:
                     err = RuntimeError("a peer rank's hipGraph capture failed")
+            if fatal is not None:
+                raise fatal
             if failed:
                 import warnings
                 warnings.warn(f"hipGraph capture failed ({err!r}); continuing with eager launches")

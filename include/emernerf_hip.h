@@ -201,6 +201,9 @@ int emer_ray_points(const float *origins, const float *dirs, const float *t_star
  * Proposal sampler (replaces nerfacc.pdf.importance_sampling + _transform_stot:
  *   third_party/nerfacc_prop_net.py:153,156,172-173,299-339).  Frozen spec: SURVEY.md A.2.
  * ---------------------------------------------------------------------------------------------- */
+/* Floats of LDS per ray available to emer_importance_sample_points (device LDS per workgroup / 4 rays; 10240 on gfx950): the caller
+ * takes emer_importance_sample + emer_ray_points when 2 * n_edges_in + n_intervals_out + 1 exceeds it.  0: no device. */
+int64_t emer_importance_sample_points_capacity(void);
 /* [r5] emer_importance_sample (interval form: t_starts / t_ends [R][n]) and, in the same launch, the sample points of the new intervals:
  * what emer_ray_points computes from its result (render_utils.py:316-318,341) -- normed [R][n][3] (scene contraction by aabb /
  * unbounded), positions [R][n][3] or NULL.  Bitwise the two separate calls.  2 m + n + 1 <= 10240. */

@@ -270,12 +270,19 @@ def _exchange_worker(rank, world, port, ret, dp_mode, early, table_cut, prop_gra
     try:
         if prop_grad:
             tr._launch_prop_bucket()
-        if early and dp_mode == "allreduce":
+        if early and dp_mode in ("allreduce", "single"):   # "single": the hooks fire as in an eager step and must start nothing
             tr._launch_whole_table_bucket(xyzt.tcnn_encoding.params)         # an xyzt table, from its own last backward
             tr._launch_early_bucket()                                        # the MLP ranges, when the static table's backward starts
             if table_cut:
                 tr._launch_table_bucket(enc.tcnn_encoding.params, table_cut, 4096)   # the fine levels, between the two launches
+        if dp_mode == "single":
+            assert tr._early_work == [] and tr._table_work == [] and tr._prop_work is None, "single mode: nothing before the backward ends"
+            n_coll, orig_ar = [0], dist.all_reduce
+            dist.all_reduce = lambda *a_, **k_: (n_coll.__setitem__(0, n_coll[0] + 1), orig_ar(*a_, **k_))[1]
         tr._exchange_grads(prop_grad)
+        if dp_mode == "single":
+            dist.all_reduce = orig_ar
+            assert n_coll[0] == 1, f"EMER_DP_SINGLE: {n_coll[0]} all-reduces in one step's exchange"
     finally:
         torch.cuda.is_current_stream_capturing = orig_cap
     # reference: the plain sum over ranks
@@ -300,7 +307,8 @@ def _exchange_worker(rank, world, port, ret, dp_mode, early, table_cut, prop_gra
 
 @pytest.mark.parametrize("dp_mode,early,table_cut,prop_grad", [("allreduce", False, 0, False), ("allreduce", True, 0, False),
                                                                 ("allreduce", True, 3000, False), ("allreduce", True, 3000, True),
-                                                                ("rs_ag", False, 0, True), ("rs_ag", False, 0, False)])
+                                                                ("rs_ag", False, 0, True), ("rs_ag", False, 0, False),
+                                                                ("single", True, 3000, True), ("single", True, 0, False)])
 def test_trainer_exchange_code_over_gloo(dp_mode, early, table_cut, prop_grad):
     world, port = 2, _free_port()
     with mp.Manager() as mgr:

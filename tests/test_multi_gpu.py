@@ -95,7 +95,17 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
                 _orig(param)
                 assert len(tr._table_work) + len(tr._table_snapshots) == n_before + 1
             p._emer_after_table_grad = spy_after
+    calls["all_reduce"] = 0
+    orig_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **k):
+        calls["all_reduce"] += 1
+        return orig_all_reduce(*a, **k)
+    dist.all_reduce = counting_all_reduce
     out = _step(tr, data, jit, noise, mode)
+    dist.all_reduce = orig_all_reduce
+    if dp_mode == "single":   # BASELINE.json north_star: "a single RCCL all-reduce of grads ... per step" (EMER_DP_SINGLE=1)
+        assert calls["all_reduce"] == 1, f"single-collective mode issued {calls['all_reduce']} all-reduces"
     assert calls["xyzt"] == (2 if kind == "flow" and dp_mode == "allreduce" else 0), f"xyzt table buckets: {calls}"
     assert out["prop_grad"], "the test step must exercise the proposal-net range of the exchange"
     assert calls["prop"] == 1 and calls["early"] == 1, f"buckets not launched exactly once: {calls}"
@@ -108,10 +118,11 @@ def _worker(rank, port, out_dir, kind, mode, dp_mode, debug):
 @pytest.mark.parametrize("kind,mode,dp_mode,debug", [("static", "pixel", "allreduce", False), ("static", "pixel", "allreduce", True),
                                                      ("flow", "pixel", "allreduce", True), ("flow", "pixel", "allreduce", False),
                                                      ("static", "lidar", "allreduce", True),
-                                                     ("static", "pixel", "rs_ag", False), ("flow", "lidar", "rs_ag", False)])
+                                                     ("static", "pixel", "rs_ag", False), ("flow", "lidar", "rs_ag", False),
+                                                     ("static", "pixel", "single", False), ("flow", "pixel", "single", False)])
 def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, mode, dp_mode, debug):
-    """static and flow models, the pixel step and the lidar step, the bucketed all-reduce and the reduce-scatter -> sharded
-    Adam -> all-gather exchange.  debug=True (EMER_DP_DEBUG=1): the trainer asserts that no gradient of the early bucket's
+    """static and flow models, the pixel step and the lidar step, the bucketed all-reduce, the reduce-scatter -> sharded
+    Adam -> all-gather exchange and the single all-reduce after the backward (dp_mode="single" / EMER_DP_SINGLE=1: exactly one collective).  debug=True (EMER_DP_DEBUG=1): the trainer asserts that no gradient of the early bucket's
     ranges is written after the point where the bucket is launched (the ordering assumption behind hiding it)."""
     import torch.multiprocessing as mp
     port = _free_port()
@@ -138,6 +149,48 @@ def test_two_ranks_equal_one_rank_on_concatenated_rays(hip_lib, tmp_path, kind, 
     assert int(bad.sum()) <= max(10, int(touched.sum()) // 2000), f"{int(bad.sum())} of {int(touched.sum())} updates differ"
 
 
+def _capture_failure_worker(rank, port, out_dir):
+    """Both ranks ask for hipGraph replay; rank 1's capture attempt fails.  The ranks must agree (Trainer.train_step -> agree_any) and BOTH
+    continue with eager launches -- otherwise rank 0 would replay (one all-reduce after the graph) while rank 1 launches buckets."""
+    import warnings
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    tr = _make(2, "static", "allreduce")
+    tr.use_graph = True
+    if rank == 1:
+        def broken(data, prop_grad):
+            raise RuntimeError("injected capture failure")
+        tr._graphed_forward_backward = broken
+    data, jit, noise = _data(rank * R_HALF, (rank + 1) * R_HALF, "pixel")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _step(tr, data, jit, noise, "pixel")
+    assert tr.use_graph is False, f"rank {rank} kept replaying after a peer's capture failed"
+    assert any("capture failed" in str(x.message) for x in w), [str(x.message) for x in w]
+    torch.cuda.synchronize()
+    torch.save({"params": tr.flat.params.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_falls_back_everywhere(hip_lib, tmp_path):
+    """the agreed eager fallback end to end -- a capture failure injected on ONE of two ranks; both fall back, the replicas stay
+    identical and the step equals the one-rank step on the concatenated rays (as the all-eager two-rank run does)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_capture_failure_worker, args=(_free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "rank0.pt")["params"], torch.load(tmp_path / "rank1.pt")["params"]
+    assert torch.equal(p0, p1), "replicas diverged after the agreed fallback"
+    tr = _make(1, "static")
+    before = tr.flat.params.cpu().clone()
+    data, jit, noise = _data(0, 2 * R_HALF, "pixel")
+    _step(tr, data, jit, noise, "pixel")
+    torch.cuda.synchronize()
+    du, dv = p0 - before, tr.flat.params.cpu() - before
+    touched = dv.abs() > 0
+    bad = (du - dv).abs() > 1e-3 * dv.abs().clamp_min(1e-12)
+    assert int(touched.sum()) > 100000 and int(bad.sum()) <= max(10, int(touched.sum()) // 2000), f"{int(bad.sum())} of {int(touched.sum())} updates differ"
+
+
 def _rccl_worker(rank, port, out_dir, dp_mode):
     """One rank, backend "nccl" (= RCCL on ROCm), EMER_DP_FORCE=1: the trainer takes its data-parallel path and the REAL collectives
     run -- async all_reduce buckets, or the in-place reduce_scatter_tensor (output shard aliasing its input) and
@@ -158,13 +211,15 @@ def _rccl_worker(rank, port, out_dir, dp_mode):
     for _ in range(2):
         _step(tr, data, jit, noise, "pixel")
     torch.cuda.synchronize()
-    want = {"allreduce": {"all_reduce"}, "rs_ag": {"reduce_scatter_tensor", "all_gather_into_tensor"}}[dp_mode]
+    want = {"allreduce": {"all_reduce"}, "single": {"all_reduce"}, "rs_ag": {"reduce_scatter_tensor", "all_gather_into_tensor"}}[dp_mode]
     assert set(seen) == want, seen
+    if dp_mode == "single":
+        assert len(seen) == 2, f"one all-reduce per step: {seen}"
     torch.save({"params": tr.flat.params.cpu(), "ranges": dict(tr.flat.ranges)}, os.path.join(out_dir, "rccl.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dp_mode", ["allreduce", "rs_ag"])
+@pytest.mark.parametrize("dp_mode", ["allreduce", "rs_ag", "single"])
 def test_real_rccl_collectives_execute_on_one_rank(hip_lib, tmp_path, dp_mode):
     """``reduce_scatter_tensor`` had never executed on any backend.  On this one-GPU box RCCL can only form a communicator
     of one rank, so the exchange is numerically the identity -- which makes the check exact: two steps through the real RCCL calls

@@ -342,6 +342,13 @@ def test_trainer_state_dict_is_a_snapshot_and_checks_the_layout(hip_lib):
     tr2 = Trainer(kind="static", device=dev, num_samples=16, prop_samples=(16, 8), table_init=0.3, seed=5)
     tr2.load_state_dict(sd)
     assert torch.equal(tr2.m, m0) and tr2.step_count == 1 and tr2.loss_scale == tr.loss_scale and tr2.num_iters == tr.num_iters
+    # the schedule length and the loss scale are the resuming run's (constructor), not the checkpoint's -- unless asked for
+    tr4 = Trainer(kind="static", device=dev, num_samples=16, prop_samples=(16, 8), table_init=0.3, seed=5, num_iters=40000, loss_scale=512.0)
+    with pytest.warns(UserWarning, match="keeping the constructor's"):
+        tr4.load_state_dict(sd)
+    assert tr4.num_iters == 40000 and tr4.loss_scale == 512.0 and tr4.step_count == 1
+    tr4.load_state_dict(sd, restore_schedule=True)
+    assert tr4.num_iters == tr.num_iters and tr4.loss_scale == tr.loss_scale
     bad = dict(sd)
     bad["ranges"] = {k: (a, b + 4) for k, (a, b) in sd["ranges"].items()}
     with pytest.raises(ValueError):
