@@ -370,7 +370,7 @@ def main():
     all_names = grid_names + ["emer_hashgrid_bwd_input", "emer_linear_fwd", "emer_linear_bwd", "emer_layout_transpose",
                               "emer_render_weights_fwd", "emer_render_weights_bwd", "emer_accumulate_fwd", "emer_accumulate_bwd",
                               "emer_importance_sample", "emer_ray_points", "emer_adam_step", "emer_dir_encode", "emer_contract_fwd",
-                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd", "emer_rgb_head_bwd_fused",
+                              "emer_mlp_chain", "emer_wgrad_segmented", "emer_neck_fwd", "emer_neck_bwd", "emer_neck_bwd_fused", "emer_rgb_head_fwd", "emer_rgb_head_bwd", "emer_rgb_head_bwd_fused", "emer_rgb_head_bwd_recompute",
                               "emer_rmlp_fwd", "emer_rmlp_bwd", "emer_contract_bwd", "emer_blend_accumulate_fwd", "emer_blend_accumulate_bwd",
                               "emer_prop_loss", "emer_ray_epilogue_fwd", "emer_ray_epilogue_bwd", "emer_pixel_loss_fwd", "emer_pixel_loss_bwd",
                               "emer_trunc_exp_fwd", "emer_trunc_exp_bwd", "emer_ray_inputs_fwd", "emer_embed_grad", "emer_ray_pre_fwd",
@@ -669,7 +669,9 @@ def main():
                      "emer_rgb_head_bwd": (2.0 * N * (3 * 64 + 3 * 64 * 64), 6.0),
                      # [r4] data gradients + the weight gradients of the per-sample column blocks (dW1 [64][128], dW0 [64][64]); the transposer
                      # handles dpre1 / dpre0 only (8 tiles per 16 rows: a1 / geo are read transposed from LDS)
-                     "emer_rgb_head_bwd_fused": (2.0 * N * (3 * 64 + 3 * 64 * 64) + 2.0 * N * (64 * 128 + 64 * 64), None)}
+                     "emer_rgb_head_bwd_fused": (2.0 * N * (3 * 64 + 3 * 64 * 64) + 2.0 * N * (64 * 128 + 64 * 64), None),
+                     # [r6] the same + the recomputation of a1 / a2 (3 x 64 x 64 MACs per sample); the transposer handles dpre1 / dpre0 / a1 / geo
+                     "emer_rgb_head_bwd_recompute": (2.0 * N * (3 * 64 + 3 * 64 * 64) + 2.0 * N * (64 * 128 + 64 * 64) + 2.0 * N * 3 * 64 * 64, None)}
             for kn, (fl, mult) in flops.items():
                 v = [u for u in breakdown.elapsed_us().get(kn, [])]
                 if kn.startswith("emer_neck"):  # main-field launches only (the proposal nets are the short ones; in the static step the forward runs inside emer_field_fwd)
@@ -679,6 +681,8 @@ def main():
                     t_row = 3.0 * 2.0 * 16 * 32        # transposer flops per row and 16 x 16 operand tile
                     if kn == "emer_rgb_head_bwd_fused":
                         ex = 6.0 * fl + t_row * 8 * N
+                    elif kn == "emer_rgb_head_bwd_recompute":
+                        ex = 6.0 * fl + t_row * 16 * N
                     elif kn == "emer_neck_bwd_fused":    # tiles: h1 (4), d (4), dpre0 (4), the encoding ((k0 + 15) // 16)
                         ex = 6.0 * fl + t_row * (12 + (k0 + 15) // 16) * N
                     else:

@@ -111,6 +111,8 @@ SIGNATURES = {
     "emer_field_fwd": [_P, c_int32, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "emer_rgb_head_bwd": [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P],
     "emer_rgb_head_bwd_fused_supported": [c_int32],
+    "emer_rgb_head_bwd_recompute": [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64,
+                                    _P, c_int64, _P, _P],
     "emer_rgb_head_bwd_fused": [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64,
                                 _P, c_int32, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],

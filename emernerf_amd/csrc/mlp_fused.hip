@@ -904,7 +904,7 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
         const int64_t row0 = ray * tpr * 16;
         const float *geo = a.geo + row0 * a.ld_geo;
         float *a1 = a.a1 + row0 * 64, *a2 = a.a2 + row0 * 64, *outp = a.out + row0 * 3;
-        const bool keep = a.a1 != nullptr;  // inference: the hidden activations are not stored (2/3 of the kernel's bytes)
+        const bool keep = a.a1 != nullptr, keep2 = a.a2 != nullptr;  // inference: the hidden activations are not stored (2/3 of the kernel's bytes)
         for (int j = 0; j < tpr; ++j) {
             f32x4 x[4];
 #pragma unroll
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_fwd_kernel(const RgbFwdArgs 
             make_opd<4>(h, ho);
             tgemm<2, 4, false>(w1ap, ho, h2);
             relu<4>(h2);
-            if (keep)
+            if (keep2)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
             make_opd<4>(h2, ho);
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(kFieldThreads) void field_fwd_kernel(const FieldFwd
     const W3 w0p = w3_at(w0l, 4, 2, lane), w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w2p = w3_at(w2l, 1, 2, lane);
     const int tpr = a.r.tiles_per_ray;
     const unsigned lo64 = (unsigned)(m * 64 + 4 * g);
-    const bool keep = a.r.a1 != nullptr;
+    const bool keep = a.r.a1 != nullptr, keep2 = a.r.a2 != nullptr;   // [r6] a2 (or both) may be left to a recomputing backward
     for (int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; ray < a.r.n_rays; ray += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const float *rb0 = a.r.rb0 + ray * a.r.ld_rb + 4 * g, *rb1 = a.r.rb1 + ray * a.r.ld_rb + 4 * g;
         const int64_t row0 = ray * tpr * 16;   // wave-uniform: one scalar base per tensor, 32-bit lane offsets
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(kFieldThreads) void field_fwd_kernel(const FieldFwd
             make_opd<4>(h, ho);
             tgemm<2, 4, false>(w1ap, ho, h2);
             relu<4>(h2);
-            if (keep)
+            if (keep2)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(a2 + (lo64 + (unsigned)j * 1024u + 16u * p)) = h2[p];
             make_opd<4>(h2, ho);
@@ -1770,6 +1770,364 @@ __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdW
         for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
     }
     // ---- sum the four waves through LDS (the weights are dead), one coalesced partial per workgroup (the paired kernel's layout)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int P1 = 132, P0 = 68;
+    float *r1 = reinterpret_cast<float *>(smem), *r0 = r1 + 64 * P1, *r2 = r0 + 64 * P0;
+    const int j32 = lane & 31, h32 = lane >> 5;
+    for (int w = 0; w < kRWThreads / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+#pragma unroll
+                for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *q = r1 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * P1 + 32 * Q + j32;
+                        *q = (w == 0) ? acc1[P][Q][r] : *q + acc1[P][Q][r];
+                    }
+#pragma unroll
+                for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *q = r0 + (32 * P + 8 * (r >> 2) + 4 * h32 + (r & 3)) * P0 + 32 * Q + j32;
+                        *q = (w == 0) ? acc0[P][Q][r] : *q + acc0[P][Q][r];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2[wave * 196 + c * 64 + 16 * (m >> 2) + 4 * g + (m & 3)] = w2acc[c];
+    b2acc = row16_sum(b2acc);
+    if (m == 0 && g < 3) r2[wave * 196 + 192 + g] = b2acc;
+    __syncthreads();
+    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
+    for (int i = threadIdx.x; i < 64 * 128; i += kRWThreads) part[i] = r1[(i >> 7) * P1 + (i & 127)];
+    for (int i = threadIdx.x; i < 64 * 64; i += kRWThreads) part[64 * 128 + i] = r0[(i >> 6) * P0 + (i & 63)];
+    if ((int)threadIdx.x < 195) {
+        float t = 0.0f;
+        for (int w = 0; w < kRWThreads / 64; ++w) t += r2[w * 196 + threadIdx.x];
+        part[64 * 128 + 64 * 64 + threadIdx.x] = t;
+    }
+}
+
+// ---- [r6] the same backward with a1 / a2 RECOMPUTED from geo and the per-ray pre-activations: the forward (field_fwd_kernel / rgb_fwd_kernel
+// with a1 = a2 = NULL) then stores nothing but geo and the colours, and this kernel reads geo (256 B / sample) instead of geo + a1 + a2
+// (768 B / sample): 1.07 GB of HBM traffic per million samples and step gone.  a1 = relu(W0g geo + rb0), a2 = relu(W1g geo + W1a a1 + rb1)
+// are evaluated with the forward's fragments in the forward's order per accumulator (rb, then k-step 0, then k-step 1; for a2: the geo
+// part first), so they are BITWISE the forward's values and every result of this kernel is bitwise rgb_bwdw16_kernel's.
+//   * LDS: six 64 x 64 weight matrices as bf16x3 fragments (W0g, W1a, W1g for the recomputation, their transposes for the chain) = 144 KB,
+//     plus 1 KB per wave for the per-ray pre-activations of the current and of the next ray (global -> LDS, 4 B per lane).  No room is
+//     left for staging tiles, and none is needed: geo is the only per-sample input; the next tile's 16 floats per lane are prefetched in
+//     REGISTERS one tile ahead (an unconditional load at the top of the tile body, consumed behind the next tile's wait).
+//   * The B operands of the dW products (a1, geo with the rows on the reduction index) come from the chain-layout operands the
+//     recomputation has split anyway, through the matrix-core transposer (to_rows: 3 instructions per 16-feature tile, exact) -- the
+//     same bits b_tile() reads back from the staged tile in rgb_bwdw16_kernel (the 3-term split is elementwise).
+//   * Per tile: 144 (recomputation) + 148 (chain) + 48 (transposer: dpre1, dpre0, a1, geo) 16 x 16 x 32 instructions + 72 of 32 x 32 x 16.
+struct RgbBwdRArgs {
+    const float *dout, *out;            // [n][3]
+    const float *geo; int64_t ld_geo;   // [n][>= 64] the head's per-sample input
+    const float *rb0, *rb1; int64_t ld_rb;   // [rays][64] per-ray pre-activations of layers 0 / 1 (bias included), as the forward's
+    int32_t tiles_per_ray; int64_t n_rays;
+    const float *a1;                    // [n][64] the forward's stored a1 (A1_STORED) or null
+    WSrc w0g, w1a, w1g;                 // forward views (RgbFwdArgs)
+    WSrc w2t, w1at, w1gt, w0gt;         // transposed views (RgbBwdArgs)
+    float *dgeo;                        // [n][64]
+    float *s1, *s0;                     // [rays][64]
+    float *partials; int64_t stride;    // as RgbBwdWArgs
+};
+
+// A1_STORED: the cheaper half -- a1 comes from the forward's store (prefetched in registers like geo), only a2 is recomputed (96 instead of
+// 144 extra chain instructions; the forward then stores a1 but not a2).
+template <bool A1_STORED>
+__global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdwr_kernel(const RgbBwdRArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+    u32x4 *w0fl = smem, *w1afl = w0fl + w3_units(4, 2), *w1gfl = w1afl + w3_units(4, 2);
+    u32x4 *w1al = w1gfl + w3_units(4, 2), *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
+    if (!A1_STORED) stage_w3(w0fl, 4, 2, a.w0g);
+    stage_w3(w1afl, 4, 2, a.w1a);
+    stage_w3(w1gfl, 4, 2, a.w1g);
+    stage_w3(w1al, 4, 2, a.w1at);
+    stage_w3(w1gl, 4, 2, a.w1gt);
+    stage_w3(w0l, 4, 2, a.w0gt);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+    const W3 w0f = w3_at(w0fl, 4, 2, lane), w1af = w3_at(w1afl, 4, 2, lane), w1gf = w3_at(w1gfl, 4, 2, lane);
+    const W3 w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w0p = w3_at(w0l, 4, 2, lane);
+    const SelE sel = make_sel(lane);
+    float w2a[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
+    // per wave: [parity][rb0 (64) | rb1 (64)] floats
+    float *rbl = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * 256;
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    f32x16 acc1[2][4], acc0[2][2];
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[P][Q][r] = 0.0f;
+#pragma unroll
+        for (int Q = 0; Q < 2; ++Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[P][Q][r] = 0.0f;
+    }
+    float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
+    const int tpr = a.tiles_per_ray;
+    const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
+    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
+    const unsigned lo3c = (unsigned)(3 * m + (g < 3 ? g : 2));
+    float yn = 0.0f, dn = 0.0f;
+    f32x4 xg[4];   // the NEXT tile's geo in chain layout (lane (m, g): columns 16 p + 4 g .. + 3 of row m)
+    f32x4 ag[4];   // ... and its stored a1 (A1_STORED)
+    int rpar = 0;  // parity of the per-ray buffer the CURRENT tile reads
+    auto issue = [&](int64_t ray, int j, int par) {
+        const int64_t row0 = (ray * tpr + j) * 16;
+        const float *pg = a.geo + row0 * a.ld_geo;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xg[p] = *reinterpret_cast<const f32x4 *>(pg + (log + 16u * p));
+        if (A1_STORED) {
+            const float *pa = a.a1 + row0 * 64;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ag[p] = *reinterpret_cast<const f32x4 *>(pa + (lo64 + 16u * p));
+        }
+        yn = (a.out + row0 * 3)[lo3c];
+        dn = (a.dout + row0 * 3)[lo3c];
+        if (j == 0) {   // (wave-uniform) first tile of a ray: its pre-activations, 64 + 64 floats, one per lane each, into buffer `par`
+            if (!A1_STORED) __builtin_amdgcn_global_load_lds((gptr)(a.rb0 + ray * a.ld_rb + lane), (lptr)(rbl + 128 * par), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(a.rb1 + ray * a.ld_rb + lane), (lptr)(rbl + 128 * par + 64), 4, 0, 0);
+        }
+    };
+    auto advance = [&](int64_t ray, int j, int64_t &nr, int &nj) {   // the next tile of this wave's sequence (clamped at its end)
+        nr = ray; nj = j + 1;
+        if (nj == tpr) { nj = 0; nr = ray + n_waves; }
+        if (nr >= a.n_rays) { nr = ray; nj = j; }
+    };
+    if (wave_id < a.n_rays) issue(wave_id, 0, 0);
+    f32x4 dgp[4];
+    float *dgeo_prev = nullptr;
+    Frag6 fa, fb;
+    const W3 wfirst = A1_STORED ? w1gf : w0f;   // the matrix of a tile's first stage
+    ld_frag6(fa, wfirst, 0, 0);
+    for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
+        float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < tpr; ++j) {
+            float *dgeo = a.dgeo + ((ray * tpr + j) * 16) * 64;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (dgeo_prev) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
+            }
+            f32x4 x[4], a1[4], a2[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { x[p] = xg[p]; if (A1_STORED) a1[p] = ag[p]; }
+            const float d2 = g < 3 ? dn * yn * (1.0f - yn) : 0.0f;
+            const float *rb = rbl + 128 * rpar;   // this ray's rb0 | rb1
+            {
+                int64_t nr; int nj;
+                advance(ray, j, nr, nj);
+                issue(nr, nj, (nj == 0 && (nr != ray || tpr == 1)) ? (rpar ^ 1) : rpar);
+                // (a clamped repeat of the last tile re-reads with j != 0 unless tpr == 1: then it reloads its own ray into the other buffer, harmless)
+            }
+            // ---- recomputation: a1 = relu(W0g x + rb0), a2 = relu(W1g x + W1a a1 + rb1).  Eight stages on x (k-step 0 of all four
+            // accumulator pairs first, so that the split of k-step 1 runs next to them), four on a1.
+            Opd<2> xo, ho;
+            SwP Bq[4];   // a1 features 0-31, 32-63; geo features 0-31, 32-63 (rows on the reduction index, 32-feature blocks)
+            if constexpr (A1_STORED) {
+                // ---- a2 = relu(W1g x + W1a a1 + rb1) with a1 from the forward's store: four stages on x, four on a1
+                {
+                    f32x4 v[2] = {x[0], x[1]};
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    xo.h[0] = o1.h[0]; xo.m[0] = o1.m[0]; xo.l[0] = o1.l[0];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) a2[p] = *reinterpret_cast<const f32x4 *>(rb + 64 + 16 * p + 4 * g);
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 0, 1); mma_frag6<2>(fa, xo, 0, a2[0], a2[1]);
+                {
+                    f32x4 v[2] = {x[2], x[3]};
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    xo.h[1] = o1.h[0]; xo.m[1] = o1.m[0]; xo.l[1] = o1.l[0];
+                }
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1gf, 1, 0); mma_frag6<2>(fb, xo, 0, a2[2], a2[3]);
+                make_opd<4>(a1, ho);
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 1, 1); mma_frag6<2>(fa, xo, 1, a2[0], a2[1]);
+                Bq[2] = block32(to_rows<2>(xo, 0, sel), to_rows<2>(xo, 1, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1af, 0, 0); mma_frag6<2>(fb, xo, 1, a2[2], a2[3]);
+                Bq[3] = block32(to_rows<2>(xo, 2, sel), to_rows<2>(xo, 3, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1af, 0, 1); mma_frag6<2>(fa, ho, 0, a2[0], a2[1]);
+                Bq[0] = block32(to_rows<2>(ho, 0, sel), to_rows<2>(ho, 1, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1af, 1, 0); mma_frag6<2>(fb, ho, 0, a2[2], a2[3]);
+                Bq[1] = block32(to_rows<2>(ho, 2, sel), to_rows<2>(ho, 3, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1af, 1, 1); mma_frag6<2>(fa, ho, 1, a2[0], a2[1]);
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1ap, 0, 0); mma_frag6<2>(fb, ho, 1, a2[2], a2[3]);   // (fa: the chain's first stage)
+                EMER_RGBW_SB();
+            } else {
+                {
+                    f32x4 v[2] = {x[0], x[1]};
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    xo.h[0] = o1.h[0]; xo.m[0] = o1.m[0]; xo.l[0] = o1.l[0];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    a1[p] = *reinterpret_cast<const f32x4 *>(rb + 16 * p + 4 * g);
+                    a2[p] = *reinterpret_cast<const f32x4 *>(rb + 64 + 16 * p + 4 * g);
+                }
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 0, 0); mma_frag6<2>(fa, xo, 0, a1[0], a1[1]);
+                {
+                    f32x4 v[2] = {x[2], x[3]};
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    xo.h[1] = o1.h[0]; xo.m[1] = o1.m[0]; xo.l[1] = o1.l[0];
+                }
+                EMER_RGBW_SB();
+                ld_frag6(fa, w0f, 0, 1); mma_frag6<2>(fb, xo, 0, a2[0], a2[1]);
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 0, 1); mma_frag6<2>(fa, xo, 0, a1[2], a1[3]);
+                EMER_RGBW_SB();
+                ld_frag6(fa, w0f, 1, 0); mma_frag6<2>(fb, xo, 0, a2[2], a2[3]);
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 1, 0); mma_frag6<2>(fa, xo, 1, a1[0], a1[1]);
+                EMER_RGBW_SB();
+                ld_frag6(fa, w0f, 1, 1); mma_frag6<2>(fb, xo, 1, a2[0], a2[1]);
+                {   // a1 tiles 0, 1 are final: ReLU, split -> k-step 0 of the next operand
+                    f32x4 v[2] = {a1[0], a1[1]};
+                    relu<2>(v);
+                    a1[0] = v[0]; a1[1] = v[1];
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    ho.h[0] = o1.h[0]; ho.m[0] = o1.m[0]; ho.l[0] = o1.l[0];
+                }
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1gf, 1, 1); mma_frag6<2>(fa, xo, 1, a1[2], a1[3]);
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1af, 0, 0); mma_frag6<2>(fb, xo, 1, a2[2], a2[3]);
+                {
+                    f32x4 v[2] = {a1[2], a1[3]};
+                    relu<2>(v);
+                    a1[2] = v[0]; a1[3] = v[1];
+                    Opd<1> o1;
+                    make_opd<2>(v, o1);
+                    ho.h[1] = o1.h[0]; ho.m[1] = o1.m[0]; ho.l[1] = o1.l[0];
+                }
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1af, 0, 1); mma_frag6<2>(fa, ho, 0, a2[0], a2[1]);
+                Bq[2] = block32(to_rows<2>(xo, 0, sel), to_rows<2>(xo, 1, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1af, 1, 0); mma_frag6<2>(fb, ho, 0, a2[2], a2[3]);
+                Bq[3] = block32(to_rows<2>(xo, 2, sel), to_rows<2>(xo, 3, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fb, w1af, 1, 1); mma_frag6<2>(fa, ho, 1, a2[0], a2[1]);
+                Bq[0] = block32(to_rows<2>(ho, 0, sel), to_rows<2>(ho, 1, sel));
+                EMER_RGBW_SB();
+                ld_frag6(fa, w1ap, 0, 0); mma_frag6<2>(fb, ho, 1, a2[2], a2[3]);   // (fa: the chain's first stage)
+                Bq[1] = block32(to_rows<2>(ho, 2, sel), to_rows<2>(ho, 3, sel));
+                EMER_RGBW_SB();
+            }
+            relu<4>(a2);
+            // ---- the chain, as rgb_bwdw16_kernel (a2 / a1 from registers instead of the staged tile)
+            Opd<2> d1o, d0o;
+            {
+                f32x4 d1[4];
+                zero<4>(d1);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
+                relu_mask<4>(d1, a2);
+                make_opd<4>(d1, d1o);
+            }
+            EMER_RGBW_SB();
+            f32x4 dg[4], d0[4];
+            zero<4>(dg); zero<4>(d0);
+            // ---- GEMM 1: d0 = W1a^T d1 (stages 0-3) next to dW2 / db2
+            ld_frag6(fb, w1ap, 0, 1); mma_frag6<2>(fa, d1o, 0, d0[0], d0[1]);
+            b2acc += d2;
+            { const float dc = __shfl(d2, m, 64); w2acc[0] += row16_reduce_scatter(a2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1ap, 1, 0); mma_frag6<2>(fb, d1o, 0, d0[2], d0[3]);
+            { const float dc = __shfl(d2, 16 + m, 64); w2acc[1] += row16_reduce_scatter(a2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fb, w1ap, 1, 1); mma_frag6<2>(fa, d1o, 1, d0[0], d0[1]);
+            { const float dc = __shfl(d2, 32 + m, 64); w2acc[2] += row16_reduce_scatter(a2, dc, m); }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1gp, 0, 0); mma_frag6<2>(fb, d1o, 1, d0[2], d0[3]);
+            EMER_RGBW_SB();
+            // ---- GEMM 2: dgeo += W1g^T d1 (stages 4-7) next to the mask and split of d0
+            ld_frag6(fb, w1gp, 0, 1); mma_frag6<2>(fa, d1o, 0, dg[0], dg[1]);
+            relu_mask<4>(d0, a1);
+            EMER_RGBW_SB();
+            ld_frag6(fa, w1gp, 1, 0); mma_frag6<2>(fb, d1o, 0, dg[2], dg[3]);
+            {
+                f32x4 v[2] = {d0[0], d0[1]};
+                Opd<1> o1;
+                make_opd<2>(v, o1);
+                d0o.h[0] = o1.h[0]; d0o.m[0] = o1.m[0]; d0o.l[0] = o1.l[0];
+            }
+            EMER_RGBW_SB();
+            ld_frag6(fb, w1gp, 1, 1); mma_frag6<2>(fa, d1o, 1, dg[0], dg[1]);
+            {
+                f32x4 v[2] = {d0[2], d0[3]};
+                Opd<1> o1;
+                make_opd<2>(v, o1);
+                d0o.h[1] = o1.h[0]; d0o.m[1] = o1.m[0]; d0o.l[1] = o1.l[0];
+            }
+            EMER_RGBW_SB();
+            ld_frag6(fa, w0p, 0, 0); mma_frag6<2>(fb, d1o, 1, dg[2], dg[3]);
+            EMER_RGBW_SB();
+            // ---- GEMM 3: dgeo += W0g^T d0 (stages 8-11)
+            ld_frag6(fb, w0p, 0, 1); mma_frag6<2>(fa, d0o, 0, dg[0], dg[1]);
+            EMER_RGBW_SB();
+            ld_frag6(fa, w0p, 1, 0); mma_frag6<2>(fb, d0o, 0, dg[2], dg[3]);
+            EMER_RGBW_SB();
+            ld_frag6(fb, w0p, 1, 1); mma_frag6<2>(fa, d0o, 1, dg[0], dg[1]);
+            EMER_RGBW_SB();
+            ld_frag6(fa, wfirst, 0, 0); mma_frag6<2>(fb, d0o, 1, dg[2], dg[3]);   // (fa: the next tile's first stage)
+            EMER_RGBW_SB();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dgp[p] = dg[p];
+            dgeo_prev = dgeo;
+            EMER_RGBW_SB();
+            // ---- dW1 += dpre1^T [a1 | geo], dW0 += dpre0^T geo on this tile's 16 rows, as 32 x 32 blocks
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const SwT t0 = to_rows<2>(d1o, 2 * P, sel, &s1c[2 * P]), t1 = to_rows<2>(d1o, 2 * P + 1, sel, &s1c[2 * P + 1]);
+                const SwP A = block32(t0, t1);
+                dw_blocks<4>(acc1[P], A, Bq);
+            }
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const SwT t0 = to_rows<2>(d0o, 2 * P, sel, &s0c[2 * P]), t1 = to_rows<2>(d0o, 2 * P + 1, sel, &s0c[2 * P + 1]);
+                const SwP A = block32(t0, t1);
+                dw_blocks<2>(acc0[P], A, *reinterpret_cast<const SwP (*)[2]>(&Bq[2]));
+            }
+            EMER_RGBW_SB();
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            s1c[p] += __shfl_xor(s1c[p], 16, 64); s1c[p] += __shfl_xor(s1c[p], 32, 64);
+            s0c[p] += __shfl_xor(s0c[p], 16, 64); s0c[p] += __shfl_xor(s0c[p], 32, 64);
+            if (g == 0) { a.s1[ray * 64 + 16 * p + m] = s1c[p]; a.s0[ray * 64 + 16 * p + m] = s0c[p]; }
+        }
+        rpar ^= 1;
+    }
+    if (dgeo_prev) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo_prev + (lo64 + 16u * p)) = dgp[p];
+    }
+    // ---- sum the four waves through LDS (the weights are dead), one coalesced partial per workgroup (rgb_bwdw16_kernel's layout)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     constexpr int P1 = 132, P0 = 68;
@@ -2650,7 +3008,7 @@ extern "C" int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *
                                  const float *b2, float *a1, float *a2, float *out, void *stream) {
     EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "rgb_head_fwd: bad sizes (S must be a multiple of 16)");
     if (n_rays == 0) return EMER_OK;
-    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && (a1 != nullptr) == (a2 != nullptr) && out && ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_rb % 4 == 0,
+    EMER_REQUIRE(geo && rb0 && rb1 && w0 && w1 && w2 && (a2 == nullptr || a1 != nullptr) && out && ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_rb % 4 == 0,
                  "rgb_head_fwd: bad arguments");
     RgbFwdArgs a;
     a.geo = geo; a.ld_geo = ld_geo; a.rb0 = rb0; a.rb1 = rb1; a.ld_rb = ld_rb; a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
@@ -2681,7 +3039,7 @@ extern "C" int emer_field_fwd(const float *enc_lm, int32_t n_levels, int32_t n_f
     EMER_REQUIRE(n_rays >= 0 && samples_per_ray >= 16 && samples_per_ray % 16 == 0 && kh >= 0, "field_fwd: bad sizes (S must be a multiple of 16)");
     if (n_rays == 0) return EMER_OK;
     EMER_REQUIRE(emer_field_fwd_supported(n_levels, n_feat), "field_fwd: unsupported encoding L=%d F=%d", n_levels, n_feat);
-    EMER_REQUIRE(enc_lm && nw0 && nw1 && rb0 && rb1 && w0 && w1 && w2 && geo && dens && out && (a1 != nullptr) == (a2 != nullptr) &&
+    EMER_REQUIRE(enc_lm && nw0 && nw1 && rb0 && rb1 && w0 && w1 && w2 && geo && dens && out && (a2 == nullptr || a1 != nullptr) &&
                  ld_rb >= 64 && ld_rb % 4 == 0, "field_fwd: bad arguments");
     const int64_t n = n_rays * samples_per_ray;
     const int k0 = n_levels * n_feat;
@@ -2798,6 +3156,51 @@ extern "C" int emer_rgb_head_bwd_fused(const float *dout, const float *out, cons
     if (int rc = check_launch("rgb_head_bwd_fused")) return rc;
     // the workgroups' partials -> the parameters' gradients (+=): dW1's two column blocks land 0.. and 64 + kh.., dW0's at kh..
     // (one launch for the three)
+    const DwReduceJob jb[3] = {{0, 64, 128, dw1, ld_dw1, nullptr, 2, {0, 64}, {64, 64}, {0, 64 + kh}},
+                               {64 * 128, 64, 64, dw0, ld_dw0, nullptr, 1, {0}, {64}, {kh}},
+                               {64 * 128 + 64 * 64, 3, 64, dw2, ld_dw2, db2, 0, {0}, {0}, {0}}};
+    return launch_dw_reduce_multi(workspace, (int32_t)grid, kRgbBwdWStride, 3, jb, st);
+}
+
+// [r6] emer_rgb_head_bwd_fused WITHOUT saved activations: a1 / a2 are recomputed from geo and the per-ray pre-activations rb0 / rb1
+// ([rays][64], row stride ld_rb: what emer_ray_pre_fwd wrote for the forward), bitwise the forward's values; every output is bitwise
+// emer_rgb_head_bwd_fused's.  The forward can then be called with a1 = a2 = NULL.  Workspace: emer_rgb_head_bwd_fused_workspace.
+extern "C" int emer_rgb_head_bwd_recompute(const float *dout, const float *out, const float *a1, const float *geo, int64_t ld_geo, const float *rb0,
+                                           const float *rb1, int64_t ld_rb, int64_t n_rays, int32_t samples_per_ray, int32_t kh,
+                                           const float *w0, const float *w1, const float *w2, float *dgeo, float *s1, float *s0,
+                                           float *workspace, float *dw0, int64_t ld_dw0, float *dw1, int64_t ld_dw1, float *dw2,
+                                           int64_t ld_dw2, float *db2, void *stream) {
+    EMER_REQUIRE(n_rays >= 0 && kh >= 0, "rgb_head_bwd_recompute: bad sizes");
+    if (n_rays == 0) return EMER_OK;
+    EMER_REQUIRE(emer_rgb_head_bwd_fused_supported(samples_per_ray), "rgb_head_bwd_recompute: samples_per_ray must be a multiple of 16 (got %d)", samples_per_ray);
+    EMER_REQUIRE(dout && out && geo && rb0 && rb1 && w0 && w1 && w2 && dgeo && s1 && s0 && workspace && dw0 && dw1 && dw2 && db2,
+                 "rgb_head_bwd_recompute: null pointer");
+    EMER_REQUIRE(ld_geo >= 64 && ld_geo % 4 == 0 && ld_rb >= 64 && ld_dw0 >= 64 + kh && ld_dw1 >= 128 + kh && ld_dw2 >= 64,
+                 "rgb_head_bwd_recompute: bad leading dimension");
+    EMER_REQUIRE(n_rays * samples_per_ray * ld_geo < ((int64_t)1 << 40), "rgb_head_bwd_recompute: batch too large");
+    RgbBwdRArgs a;
+    a.dout = dout; a.out = out; a.a1 = a1; a.geo = geo; a.ld_geo = ld_geo; a.rb0 = rb0; a.rb1 = rb1; a.ld_rb = ld_rb;
+    a.tiles_per_ray = samples_per_ray / 16; a.n_rays = n_rays;
+    const int64_t k0 = kh + 64, k1 = 64 + k0;
+    a.w0g = WSrc{w0 + kh, k0, 1, 64, 64};
+    a.w1a = WSrc{w1, k1, 1, 64, 64};
+    a.w1g = WSrc{w1 + 64 + kh, k1, 1, 64, 64};
+    a.w2t = WSrc{w2, 1, 64, 64, 3};
+    a.w1at = WSrc{w1, 1, k1, 64, 64};
+    a.w1gt = WSrc{w1 + 64 + kh, 1, k1, 64, 64};
+    a.w0gt = WSrc{w0 + kh, 1, k0, 64, 64};
+    a.dgeo = dgeo; a.s1 = s1; a.s0 = s0; a.partials = workspace; a.stride = kRgbBwdWStride;
+    const size_t lds = (size_t)(6 * w3_units(4, 2)) * 16 + (size_t)(kRWThreads / 64) * 256 * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    const uint32_t grid = rgb_bwdw_grid(n_rays);
+    if (a1) {   // the cheaper half: a1 stored by the forward, a2 recomputed
+        if (int rc = set_lds(rgb_bwdwr_kernel<true>, lds, "rgb_head_bwd_recompute")) return rc;
+        hipLaunchKernelGGL(rgb_bwdwr_kernel<true>, dim3(grid), dim3(kRWThreads), lds, st, a);
+    } else {
+        if (int rc = set_lds(rgb_bwdwr_kernel<false>, lds, "rgb_head_bwd_recompute")) return rc;
+        hipLaunchKernelGGL(rgb_bwdwr_kernel<false>, dim3(grid), dim3(kRWThreads), lds, st, a);
+    }
+    if (int rc = check_launch("rgb_head_bwd_recompute")) return rc;
     const DwReduceJob jb[3] = {{0, 64, 128, dw1, ld_dw1, nullptr, 2, {0, 64}, {64, 64}, {0, 64 + kh}},
                                {64 * 128, 64, 64, dw0, ld_dw0, nullptr, 1, {0}, {64}, {kh}},
                                {64 * 128 + 64 * 64, 3, 64, dw2, ld_dw2, db2, 0, {0}, {0}, {0}}};

@@ -201,6 +201,21 @@ FUSED_WGRAD = True   # weight gradients inside the backward kernels where the li
 FUSED_RMLP_WGRAD = os.environ.get("EMER_FUSE_RMLP_WGRAD", "1") != "0"  # ... of the plain 2- / 3-layer heads with <= 16 outputs (emer_rmlp_bwd_fused) [r5]
 FUSED_RMLP_WIDE = os.environ.get("EMER_FUSE_RMLP_WIDE", "1") != "0"    # ... incl. the 64-wide feature heads (one wave per SIMD, 192 accumulator registers)
 FUSED_RGB_WGRAD = os.environ.get("EMER_FUSE_RGB_WGRAD", "1") != "0"   # ... of the rgb head's layers 0 / 1 too (emer_rgb_head_bwd_fused) [r4]
+# [r6] ... optionally with a1 / a2 recomputed in that kernel from geo and the per-ray pre-activations (emer_rgb_head_bwd_recompute): the
+# forward stores no hidden activations (512 B / sample less written and kept alive until the backward, 512 B / sample less read); bitwise
+# the saved-activation path's results.  EMER_RGB_RECOMPUTE = 0: both stored (default); 1: both recomputed; 2: a1 stored, a2 recomputed.
+# Same-session A/B at the metric shape (profiles/r06_ab_rgb_recompute.txt): field_fwd 311 -> 212 / 236 us, backward 368 -> 504 / 484 us,
+# step 2.365 -> 2.385 / 2.405 ms -- the recomputation's 168 / 120 matrix instructions per tile cost more in the one-wave-per-SIMD
+# backward than the stores cost the four-waves-per-SIMD forward.  It stays as the MEMORY mode (-537 MB of saved activations per million
+# samples), off by default.
+RGB_RECOMPUTE = int(os.environ.get("EMER_RGB_RECOMPUTE", "0"))
+
+
+def rgb_recompute(n_rays: int, samples_per_ray: int) -> int:
+    """Which hidden activations the backward of an rgb head of this shape will recompute (so that its forward need not store them):
+    0 none, 1 a1 and a2, 2 a2 only."""
+    ok = FUSED_WGRAD and FUSED_RGB_WGRAD and _lib.load().emer_rgb_head_bwd_fused_workspace(n_rays, samples_per_ray) > 0
+    return int(RGB_RECOMPUTE) if ok else 0
 RGB_WGRAD_PAIR = os.environ.get("EMER_RGBW_PAIR", "0") == "1"         # its variant that pairs two row tiles per weight-gradient step
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
 
@@ -362,7 +377,7 @@ class RgbRider:
     def __init__(self, hray: Tensor, samples_per_ray: int, params, keep: bool):
         self.hray, self.S, self.params, self.keep = hray, int(samples_per_ray), tuple(params), bool(keep)
         self.geo_ptr = None
-        self.rb = self.a1 = self.a2 = self.out = None
+        self.rb = self.a1 = self.a2 = self.out = None   # rb: the per-ray pre-activations [R, 128] of layers 0 | 1
 
     def usable(self, L: int, F: int, N: int, n_out: int) -> bool:
         w0, _, w1, _, w2, _ = self.params
@@ -468,15 +483,16 @@ def _field_fwd(enc: Tensor, W0, B0, W1, B1, rider: RgbRider):
     geo = torch.empty((N, 64), device=dev, dtype=torch.float32)
     dens = torch.empty((N,), device=dev, dtype=torch.float32)
     rb = torch.empty((R, 128), device=dev, dtype=torch.float32)
-    a1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if rider.keep else None
-    a2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if rider.keep else None
+    rec = rgb_recompute(R, rider.S) if rider.keep else 0   # [r6] recomputing backward: the activations it recomputes are not stored
+    a1 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (rider.keep and rec != 1) else None
+    a2 = torch.empty((N, 64), device=dev, dtype=torch.float32) if (rider.keep and rec == 0) else None
     out = torch.empty((N, 3), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         _lib.call("emer_ray_pre_fwd", _p(hr), hr.stride(0), R, Kh, 64, _p(RW0), RW0.stride(0), _p(RB0), _p(RW1[:, 64:]), RW1.stride(0),
                   _p(RB1), _p(rb), 128, _stream(enc))
         _lib.call("emer_field_fwd", _p(enc), L, F, R, rider.S, _p(W0), _p(B0), _p(W1), _p(B1), _p(rb), _p(rb[:, 64:]), 128, Kh,
                   _p(RW0), _p(RW1), _p(RW2), _p(RB2), _p(geo), _p(dens), _p(a1), _p(a2), _p(out), _stream(enc))
-    rider.geo_ptr, rider.a1, rider.a2, rider.out = geo.data_ptr(), a1, a2, out
+    rider.geo_ptr, rider.a1, rider.a2, rider.out, rider.rb = geo.data_ptr(), a1, a2, out, rb
     _RIDERS[geo.data_ptr()] = rider
     return geo, dens
 
@@ -587,15 +603,19 @@ class _RgbHeadFn(torch.autograd.Function):
         dev = g.device
         keep = any(ctx.needs_input_grad)  # inference (inputs detached by rgb_head): the fast kernel stores no activations
         fast = (H == 64 and NG == 64 and C == 3 and Kh <= 64 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
-        a1 = torch.empty((N, H), device=dev, dtype=torch.float32) if (keep or not fast) else None
-        a2 = torch.empty((N, H), device=dev, dtype=torch.float32) if (keep or not fast) else None
+        # [r6] the fused backward recomputes a1 / a2 from geo and the per-ray pre-activations: the forward then stores neither
+        ctx.recompute = rgb_recompute(R, S) if (keep and fast) else 0
+        a1 = torch.empty((N, H), device=dev, dtype=torch.float32) if ((keep and ctx.recompute != 1) or not fast) else None
+        a2 = torch.empty((N, H), device=dev, dtype=torch.float32) if ((keep and ctx.recompute == 0) or not fast) else None
         out = torch.empty((N, C), device=dev, dtype=torch.float32)
         ctx.S = S
         ctx.sinks = tuple(_sink(p) for p in (w0, b0, w1, b1, w2, b2))
-        ctx.fast = (H == 64 and NG == 64 and C == 3 and Kh <= 64 and S % 16 == 0 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0)
+        ctx.fast = fast
         if pre is not None and ctx.fast and (pre.keep or not keep):
             # already evaluated inside the neck's launch on exactly these tensors (rgb_head checked): nothing to launch
-            ctx.save_for_backward(hr, g, W0, W1, W2, pre.a1, pre.a2, pre.out)
+            assert not keep or ((pre.a1 is None) == (ctx.recompute == 1) and (pre.a2 is None) == (ctx.recompute != 0)), \
+                "rider and rgb head disagree about stored activations"
+            ctx.save_for_backward(hr, g, W0, W1, W2, pre.a1, pre.a2, pre.out, pre.rb if ctx.recompute else None)
             return pre.out
         if ctx.fast:
             # per-ray part of layers 0 and 1 as per-ray pre-activations (ONE 8192-row launch instead of two 1M-row GEMMs),
@@ -608,7 +628,7 @@ class _RgbHeadFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.call("emer_rgb_head_fwd", _p(g), g.stride(0), _p(rb0), _p(rb1), rb.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2), _p(B2),
                           _p(a1), _p(a2), _p(out), _stream(g))
-            ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
+            ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out, rb if ctx.recompute else None)
             return out
         c_x = _r4(H)               # [A1 | hray | geo] laid out exactly like torch.cat([x, input]) of mlp.py:42
         # A2 overwrites A1 in place: a <= 64-wide layer is one column group, so every input column has been
@@ -619,12 +639,12 @@ class _RgbHeadFn(torch.autograd.Function):
                    layer(W1, B1, 0, 0, ACT_RELU, store=a2),
                    layer(W2, B2, 0, c_o, ACT_SIGMOID, store=out)],
                   c_o + 4, N, g)
-        ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out)
+        ctx.save_for_backward(hr, g, W0, W1, W2, a1, a2, out, None)
         return out
 
     @staticmethod
     def backward(ctx, dout: Optional[Tensor]):
-        hr, g, W0, W1, W2, a1, a2, out = ctx.saved_tensors
+        hr, g, W0, W1, W2, a1, a2, out, rb = ctx.saved_tensors
         if dout is None:
             return (None,) * 10
         S = ctx.S
@@ -650,9 +670,14 @@ class _RgbHeadFn(torch.autograd.Function):
                 # dpre1 / dpre0 never reach memory and the two streamed weight-gradient launches are gone
                 ws = torch.empty((n_ws,), device=dev, dtype=torch.float32)
                 with torch.cuda.device(dev):
-                    _lib.call("emer_rgb_head_bwd_fused", _p(_c(dout)), _p(out), _p(a1), _p(a2), _p(g), g.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2),
-                              _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2), tw2.stride(0), _p(tb2),
-                              1 if RGB_WGRAD_PAIR else 0, _stream(g))
+                    if ctx.recompute:   # [r6] hidden activations recomputed from geo + the per-ray pre-activations
+                        _lib.call("emer_rgb_head_bwd_recompute", _p(_c(dout)), _p(out), _p(a1), _p(g), g.stride(0), _p(rb), _p(rb[:, H:]), rb.stride(0), R, S, Kh,
+                                  _p(W0), _p(W1), _p(W2), _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2),
+                                  tw2.stride(0), _p(tb2), _stream(g))
+                    else:
+                        _lib.call("emer_rgb_head_bwd_fused", _p(_c(dout)), _p(out), _p(a1), _p(a2), _p(g), g.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2),
+                                  _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2), tw2.stride(0), _p(tb2),
+                                  1 if RGB_WGRAD_PAIR else 0, _stream(g))
                 ray_wgrad([(s1, [(hr, Kh, H)], tw1, tb1), (s0, [(hr, Kh, 0)], tw0, tb0)], g, aux=all(r is None for r in (rw0, rb0, rw1, rb1)))
                 dhray = torch.empty((R, Kh), device=dev, dtype=torch.float32)
                 with torch.cuda.device(dev):

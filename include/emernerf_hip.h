@@ -558,7 +558,7 @@ int emer_rmlp_bwd_fused(const float *dout, int64_t ldd, const float *out, int64_
  * pre-activations rb0 = hray W0[:, :kh]^T + b0 and rb1 = hray W1[:, 64:64+kh]^T + b1 ([rays][64], row stride ld_rb); the kernel
  * does the per-sample part: a1 = relu(geo W0[:, kh:]^T + rb0), a2 = relu(a1 W1[:, :64]^T + geo W1[:, 64+kh:]^T
  * + rb1), out = sigmoid(a2 W2^T + b2).  w0 [64][kh+64], w1 [64][64+kh+64], w2 [3][64] are the torch Linear
- * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward (both NULL:
+ * weights; rows of ray r are r*S .. r*S+S-1 and S % 16 == 0.  a1 / a2 [n][64] are saved for the backward (a2 NULL, or both NULL: left to emer_rgb_head_bwd_recompute;
  * inference, nothing is stored). */
 int emer_rgb_head_fwd(const float *geo, int64_t ld_geo, const float *rb0, const float *rb1, int64_t ld_rb, int64_t n_rays,
                       int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1,
@@ -578,7 +578,7 @@ int emer_density_bwd_fused(const float *ddens, const float *dens, const float *e
  * static model: radiance_field.py:302-318,400 then :622-658): a wave keeps its 16 rows in registers from the grid encoding to
  * the colour; the geometry features are written once (the backward needs them) and never read back.  enc_lm [L][n][F] with
  * n = n_rays * samples_per_ray, nw0 [64][L F], nw1 [64][64] (the neck), the other arguments as in emer_rgb_head_fwd.
- * Outputs geo [n][64], dens [n] = exp(geo[:, 0] - 1), a1 / a2 [n][64] (both NULL: inference), out [n][3].  The results are
+ * Outputs geo [n][64], dens [n] = exp(geo[:, 0] - 1), a1 / a2 [n][64] (a2 or both NULL: inference, or a recomputing backward), out [n][3].  The results are
  * bit-identical to the two separate calls. */
 int emer_field_fwd_supported(int32_t n_levels, int32_t n_feat);
 int emer_field_fwd(const float *enc_lm, int32_t n_levels, int32_t n_feat, int64_t n_rays, int32_t samples_per_ray,
@@ -614,6 +614,17 @@ int emer_rgb_head_bwd_fused(const float *dout, const float *out, const float *a1
                             const float *w1, const float *w2, float *dgeo, float *s1, float *s0, float *workspace,
                             float *dw0, int64_t ld_dw0, float *dw1, int64_t ld_dw1, float *dw2, int64_t ld_dw2,
                             float *db2, int32_t pair_tiles, void *stream);
+/* [r6] The same backward WITHOUT saved activations: a1 / a2 are recomputed in the kernel from geo and the per-ray pre-activations
+ * rb0 / rb1 [n_rays][64] (row stride ld_rb; emer_ray_pre_fwd's output, bias included), bitwise the forward's values -- the forward
+ * (emer_rgb_head_fwd / emer_field_fwd) is then called with a1 = a2 = NULL and writes 512 B / sample less, this kernel reads 512 B /
+ * sample less.  a1 != NULL: the cheaper half -- the forward stored a1 [n][64] (and not a2), only a2 is recomputed.  Outputs and
+ * accumulation targets as emer_rgb_head_bwd_fused, bitwise.  Workspace: emer_rgb_head_bwd_fused_workspace.
+ * Autograd of radiance_fields/mlp.py:38-46 as instantiated at radiance_field.py:130-143 (rgb_head), same as the entries above. */
+int emer_rgb_head_bwd_recompute(const float *dout, const float *out, const float *a1, const float *geo, int64_t ld_geo, const float *rb0,
+                                const float *rb1, int64_t ld_rb, int64_t n_rays, int32_t samples_per_ray, int32_t kh,
+                                const float *w0, const float *w1, const float *w2, float *dgeo, float *s1, float *s0,
+                                float *workspace, float *dw0, int64_t ld_dw0, float *dw1, int64_t ld_dw1, float *dw2,
+                                int64_t ld_dw2, float *db2, void *stream);
 
 /* density_activation of the reference: y[i] = exp(x[i*x_stride] - 1); backward
  * dx[i*dx_stride] = dy[i] * min(y[i], e^15)   (radiance_field.py:28,461; nerf_utils.py:59-75). */

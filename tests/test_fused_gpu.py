@@ -108,14 +108,16 @@ def test_density_mlp(hip_lib, monkeypatch, L, N, Fe, fusedw):
 
 # weight gradients: all inside the backward kernel (one row tile per step / two paired tiles per step), only the output layer's
 # inside it (round 3: layers 0 / 1 streamed), or every one as a separate pass
-@pytest.mark.parametrize("fusedw", ["all", "all_paired", "w2_only", False])
+# [r6] "all": additionally with the hidden activations RECOMPUTED in that kernel (the default); "all_stored": read back from the forward's stores
+@pytest.mark.parametrize("fusedw", ["all", "all_a2", "all_stored", "all_paired", "w2_only", False])
 @pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64), (5000, 16, 49, 64, 64),
                                           (1031, 32, 49, 64, 64), (2, 96, 17, 64, 192)])
 def test_rgb_head(hip_lib, monkeypatch, R, S, Kh, NG, ld, fusedw):
     from emernerf_amd import fused
     monkeypatch.setattr(fused, "FUSED_WGRAD", bool(fusedw))
-    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", fusedw in ("all", "all_paired"))
+    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", fusedw in ("all", "all_a2", "all_stored", "all_paired"))
     monkeypatch.setattr(fused, "RGB_WGRAD_PAIR", fusedw == "all_paired")
+    monkeypatch.setattr(fused, "RGB_RECOMPUTE", {"all": 1, "all_a2": 2}.get(fusedw, 0))
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(R * S + Kh)
     N, H, K0 = R * S, 64, Kh + NG
@@ -142,6 +144,45 @@ def test_rgb_head(hip_lib, monkeypatch, R, S, Kh, NG, ld, fusedw):
     _close("dfeats", fd.grad, f64.grad, rtol=2e-4, scale_atol=5e-5)
     for i, (a, b) in enumerate(zip(wd, w64)):
         _close(f"dW{i}", a.grad, b.grad, rtol=2e-4, scale_atol=5e-5)
+
+
+@pytest.mark.parametrize("R,S,Kh,ld", [(16, 64, 49, 64), (5, 16, 49, 128), (1031, 32, 49, 64), (4100, 128, 49, 64), (2, 96, 17, 192), (1, 16, 49, 64)])
+def test_rgb_head_recomputed_activations_are_bitwise_the_stored_ones(hip_lib, monkeypatch, R, S, Kh, ld):
+    """[r6] emer_rgb_head_bwd_recompute (a1 / a2 recomputed from geo and the per-ray pre-activations with the forward's fragments in the
+    forward's order) against emer_rgb_head_bwd_fused on the forward's stored activations: every gradient bit for bit, with and without the
+    forward riding along in the neck's launch being irrelevant here (plain rgb_head calls).  4100 x 128: more rays than resident waves
+    (several rays per wave, the per-ray pre-activation buffers alternate), 1 x 16: one tile."""
+    from emernerf_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(R + S)
+    N, H, NG, K0 = R * S, 64, 64, Kh + 64
+    hray = torch.randn(R, max(Kh, 1), generator=g)[:, :Kh].contiguous().to(dev)
+    feats = torch.randn(N, ld, generator=g).to(dev)
+    Ws = [torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g) * 0.1, torch.randn(H, H + K0, generator=g) / (H + K0) ** 0.5,
+          torch.randn(H, generator=g) * 0.1, torch.randn(3, H, generator=g) / H ** 0.5, torch.randn(3, generator=g) * 0.1]
+    go = torch.randn(N, 3, generator=g).to(dev)
+    res = {}
+    for mode in (1, 2, 0):   # both recomputed / a2 only / both stored
+        monkeypatch.setattr(fused, "RGB_RECOMPUTE", mode)
+        hd, fd = hray.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+        wd = [w.to(dev).requires_grad_(True) for w in Ws]
+        rgb = fused.rgb_head(hd, fd[:, :NG], S, *wd)
+        assert rgb.grad_fn is not None
+        (rgb * go).sum().backward()
+        w0g, b0g, w1g, b1g, w2g, b2g = [w.grad for w in wd]
+        # bit for bit: the colours, dgeo and (through the per-ray sums s0 / s1 and emer_ray_pre_bwd) dhray.  The weight gradients leave the
+        # kernel as per-workgroup partials that are bitwise equal too, but their final reduction (linear_dw_reduce_multi over ranges of
+        # workgroups, emer_ray_wgrad over chunks of rays) meets in float atomics above ~8 workgroups / 256 rays: order-dependent in the
+        # last bits from run to run of EITHER path, so they are compared to 1e-5 of their scale
+        res[mode] = {"exact": [rgb.detach(), hd.grad, fd.grad],
+                     "close": [w0g, b0g, w1g, b1g, w2g, b2g]}
+    for mode in (1, 2):
+        for i, (a, b) in enumerate(zip(res[mode]["exact"], res[0]["exact"])):
+            assert torch.equal(a, b), f"mode {mode}, tensor {i}: recomputed != stored (max |diff| {float((a - b).abs().max()):.3e})"
+        for i, (a, b) in enumerate(zip(res[mode]["close"], res[0]["close"])):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30, f"mode {mode}, weight gradient {i}"
+            if R <= 16:   # one workgroup range, one chunk of rays: nothing meets in an atomic
+                assert torch.equal(a, b), f"mode {mode}, weight gradient {i}: recomputed != stored"
 
 
 def test_grad_sinks_equal_autograd_accumulation(hip_lib):
