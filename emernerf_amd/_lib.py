@@ -53,8 +53,6 @@ SIGNATURES = {
     "emer_hashgrid_bwd_input": [_GP, _P, _P, c_int, _P, c_int64, c_int64, _P, c_int64, _P],
     "emer_hashgrid_fwd_jac": [_GP, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, c_int64, _P],
     "emer_hashgrid_bwd_input_jac": [_GP, _P, _P, c_int64, c_int64, _P, c_int64, _P],
-    "emer_prop_density_supported": [_GP, c_int32, c_int32],
-    "emer_prop_density_fwd": [_GP, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int32, _P, _P],
     "emer_layout_transpose": [_P, _P, c_int32, c_int64, c_int32, c_int, _P],
     "emer_contract_fwd": [_P, _P, c_int, _P, c_int64, _P],
     "emer_contract_bwd": [_P, _P, c_int, _P, _P, c_int64, _P],
@@ -114,7 +112,7 @@ SIGNATURES = {
     "emer_rgb_head_bwd_recompute": [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64,
                                     _P, c_int64, _P, _P],
     "emer_rgb_head_bwd_fused": [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, c_int64,
-                                _P, c_int32, _P],
+                                _P, _P],
     "emer_trunc_exp_fwd": [_P, c_int64, _P, c_int64, _P],
     "emer_trunc_exp_bwd": [_P, _P, _P, c_int64, c_int64, _P],
     "emer_dir_encode": [_P, _P, c_int64, c_int32, c_int, _P],

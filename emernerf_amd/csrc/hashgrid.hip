@@ -50,52 +50,6 @@ template <> __device__ __forceinline__ void load_feats<8, __half>(const __half *
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
 }
 
-#ifndef EMER_DENSE_PAIR
-#define EMER_DENSE_PAIR 0   // [r4 experiment, off] double-width gathers of x-adjacent entries on DENSE levels.  Same-session A/B on MI355X
-#endif                      // (tools/ab_grid.sh): main grid fwd 229 vs 231 us, proposal grids 80 vs 77 and 108 vs 106 us, step 2.398 vs 2.397 ms --
-                            // the coarse levels are L1 hits whose lane-request count is not what bounds the kernel; nothing to gain
-// 2 F consecutive features (two x-adjacent entries of a dense level) from an address that is only ENTRY-aligned: one double-width
-// gather (buffer loads need dword alignment only)
-// (16 bytes at 8-byte alignment: hipcc splits the plain load into two dwordx2; the buffer form of the instruction carries no alignment
-// assumption -- `table` / `table_bytes` are level-uniform, the entry offset rides in the 32-bit voffset)
-template <int NW, typename PT>
-__device__ __forceinline__ void words_to_feats(const uint32_t (&w)[NW], float (&v)[NW * 4 / (int)sizeof(PT)]) {
-    if constexpr (sizeof(PT) == 4) {
-#pragma unroll
-        for (int i = 0; i < NW; ++i) v[i] = __builtin_bit_cast(float, w[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            uint32_t wv = w[i];
-            const float2 t = __half22float2(*reinterpret_cast<__half2 *>(&wv));
-            v[2 * i] = t.x; v[2 * i + 1] = t.y;
-        }
-    }
-}
-template <int F, typename PT>
-__device__ __forceinline__ void load_feats_pair(const PT *__restrict__ table, uint32_t table_bytes, uint32_t idx0, float (&v)[2 * F]) {
-    constexpr int NW = (int)(sizeof(PT) * 2 * F / 4), AL = (int)(sizeof(PT) * F) < 4 ? 4 : (int)(sizeof(PT) * F);
-    // (the buffer form for both widths: a plain 8-byte load next to the two-load fallback of the wrap case was if-converted by hipcc
-    // into two dword loads with a selected address -- the double-width gather gone)
-    static_assert(NW == 2 || NW == 4, "entry pairs of 8 or 16 bytes");
-    (void)AL;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<PT *>(table), (short)0, (int)table_bytes, 0x00020000);
-    const int off = (int)(idx0 * (uint32_t)(sizeof(PT) * F));
-    if constexpr (NW == 4) {
-        using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
-        const u32x4_t q = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-        const uint32_t w[4] = {q[0], q[1], q[2], q[3]};
-        words_to_feats<4, PT>(w, v);
-    } else {
-        using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
-        const u32x2_t q = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
-        const uint32_t w[2] = {q[0], q[1]};
-        words_to_feats<2, PT>(w, v);
-    }
-}
-
-// Relaxed device-scope float atomics.  The file is built with -munsafe-fp-atomics so these lower
-// to global_atomic_add_f32 / global_atomic_pk_add_f16 (no CAS loop, no return value).
 template <int F>
 __device__ __forceinline__ void atomic_add_feats(float *p, const float (&v)[F]) {
 #pragma unroll
@@ -235,10 +189,8 @@ struct SlicePlan {
     uint32_t sched_shift;                // log2 of the scheduling block: consecutive work items dealt to one XCD
 };
 
-#ifndef EMER_SLICE_THREADS
-#define EMER_SLICE_THREADS 1024   // owner workgroup: 1024 lanes with a 128 KiB slice (one per CU), or -- r4 experiment, see DESIGN 4.1 -- 512 lanes
-#endif                            // with a 64 KiB slice (two per CU: 128 slices per hashed level, 256-row bitmaps)
-constexpr uint32_t kSchedBlock = EMER_SLICE_THREADS == 1024 ? 32 : 64;  // consecutive work items dealt to one XCD (= its resident owners: one round)
+                           // with a 64 KiB slice (two per CU: 128 slices per hashed level, 256-row bitmaps)
+constexpr uint32_t kSchedBlock = 32;  // consecutive work items dealt to one XCD (= its resident owners: one round)
 // [r5] Grids WITHOUT dense levels (the xyzt tables: 10 hashed levels x 64 slices = 640 items of 300-450 us for 256 owners) have no
 // small items to fill the tail with: tools/trace_sliced.py showed four XCDs working three rounds and four XCDs two -- 1041 us of work
 // per owner in a 1400 us kernel.  For such grids (a) the levels at the END of the order, whose items make up the last, incomplete
@@ -269,19 +221,13 @@ static float item_cost(const emer_grid_desc *g, const SlicePlan &p, uint32_t l) 
     return 2.0f / (float)p.n_ranges[l];
 }
 
-#ifndef EMER_HASHED_SPLIT_RES
-#define EMER_HASHED_SPLIT_RES 0
-#endif
-#ifndef EMER_HASHED_SPLIT
-#define EMER_HASHED_SPLIT 2
-#endif
 #ifndef EMER_DENSE_ITEMS
 #define EMER_DENSE_ITEMS 512  // work items per dense level (slabs x sample ranges): 256 -> 512 -3 %, 1024 +8 % (merge atomics) on MI355X
 #endif
 static SlicePlan make_slice_plan(const emer_grid_desc *g) {
     SlicePlan p;
     const uint32_t F = g->n_features;
-    const uint32_t max_entries = ((EMER_SLICE_THREADS == 1024 ? 128u : 64u) * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
+    const uint32_t max_entries = ((128u) * 1024u) / (F * 8u);  // 128 KiB of the CU's 160 KiB LDS, double accumulators
     p.max_local = 0; p.ok = 1;
     for (uint32_t l = 0; l < EMER_MAX_LEVELS; ++l) { p.shift[l] = 0; p.n_slices[l] = 0; p.n_ranges[l] = 1; p.gsub[l] = 0; }
     for (uint32_t l = 0; l < g->n_levels; ++l) {
@@ -296,7 +242,7 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             // items of level 5 (res 81) take 2.5x the level's mean (tools/trace_sliced.py) and, started in a second round,
             // set the kernel's tail.  Cutting THEIR sample stream in ranges (merged with atomics, like the dense levels)
             // bounds the longest item.
-            p.n_ranges[l] = (g->res[l] <= (uint32_t)EMER_HASHED_SPLIT_RES) ? (uint32_t)EMER_HASHED_SPLIT : 1u;
+            p.n_ranges[l] = 1u;   // (sample ranges on hashed levels: measured, merge atomics cost what the balance gains; only the tail split below cuts them)
         } else {
             // dense level: a slice is a contiguous z-slab and a flat scene lands in two or three of them, so
             // use as FEW slices as the LDS allows and cut the sample stream instead
@@ -328,10 +274,10 @@ static SlicePlan make_slice_plan(const emer_grid_desc *g) {
             if (g->hashed[l]) hashed_items += p.n_slices[l];
             else dense_items += p.n_slices[l] * p.n_ranges[l];
         }
-        const uint32_t owners = EMER_SLICE_THREADS == 1024 ? 256u : 512u;
+        const uint32_t owners = 256u;
         const uint32_t rem = hashed_items % owners;
         const float hole = (float)(owners - rem), filler = 0.12f * (float)dense_items;
-        if (EMER_TAIL_SPLIT > 1 && EMER_SLICE_THREADS == 1024 && hashed_items > owners && rem != 0u && filler < 0.5f * hole) {
+        if (EMER_TAIL_SPLIT > 1 && hashed_items > owners && rem != 0u && filler < 0.5f * hole) {
             if (dense_items == 0u) {   // (scheduling block experiment: only ever measured on a grid without dense levels)
                 if (EMER_SCHED_BLOCK_NOFILL == 16) p.sched_shift = 4u;
                 else if (EMER_SCHED_BLOCK_NOFILL == 8) p.sched_shift = 3u;
@@ -557,52 +503,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             }
         }
         }
-        if constexpr (sizeof(PT) * F <= 8 && sizeof(PT) * F >= 4 && !JAC && EMER_DENSE_PAIR) {
-        if (!li.hashed) {  // level-uniform
-            // [r4] Dense level: index = x + res * (y + res * (...)), so the x-neighbours of a (y, z[, t]) combination are ADJACENT entries
-            // -- one double-width gather from an entry-aligned address instead of two (half the L1/TA lane requests on the coarse
-            // levels: a third of the proposal grids' gathers).  The exception is the one entry at which the index wraps (idx0 = size - 1,
-            // only reachable from coordinates outside [0, 1]): two loads there.  Accumulation order unchanged (corner-major, x fastest).
-            paired = true;
-#pragma unroll
-            for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
-                uint32_t c[D];
-                float t[D];
-                c[0] = gi[0];
-#pragma unroll
-                for (int d = 1; d < D; ++d) {
-                    const uint32_t bit = (m >> (d - 1)) & 1u;
-                    c[d] = gi[d] + bit;
-                    t[d] = bit ? w[d] : 1.0f - w[d];
-                }
-                const uint32_t idx0 = grid_index<D>(li, c);
-                uint32_t idx1 = idx0 + 1u;
-                float v0[F], v1[F];
-                if (idx1 < li.size) {
-                    float e[2 * F];
-                    load_feats_pair<F, PT>(table, li.size * (uint32_t)(sizeof(PT) * F), idx0, e);
-#pragma unroll
-                    for (int f = 0; f < F; ++f) { v0[f] = e[f]; v1[f] = e[F + f]; }
-                } else {
-                    c[0] = gi[0] + 1u;
-                    idx1 = grid_index<D>(li, c);
-                    load_feats<F, PT>(table + (size_t)idx0 * F, v0);
-                    load_feats<F, PT>(table + (size_t)idx1 * F, v1);
-                }
-                float wa = 1.0f - w[0], wb = w[0];  // ((t0*t1)*t2)*t3, as the generic loop
-#pragma unroll
-                for (int d = 1; d < D; ++d) { wa *= t[d]; wb *= t[d]; }
-#pragma unroll
-                for (int f = 0; f < F; ++f) acc[f] += wa * v0[f];
-#pragma unroll
-                for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
-                if (masks) {
-                    set_row<Q>(mask, slice_of(plan, level, idx0));
-                    set_row<Q>(mask, slice_of(plan, level, idx1));
-                }
-            }
-        }
-        }
         if (!paired) {
         float vv[JAC ? (1 << D) : 1][F];   // JAC: every corner's features stay live for the differences along each axis
 #pragma unroll
@@ -672,185 +572,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
     }
     if (masks)  // the whole workgroup takes part (tail lanes carry an empty mask)
         store_slice_bitmaps<Q>(masks, mask, level, bitmap_rows(plan, level), (int64_t)chunk * 256, (N + 63) >> 6, (int)threadIdx.x);
-}
-
-// ------------------------------------------------------------------------ proposal round, no gradient [r4]
-// One launch for sigma_fn of a proposal network outside autograd recording (5 steps in 6, and evaluation): sample position
-// (render_utils.py:316-318,341: o + d (t0 + t1) / 2, scene contraction) -> L-level encoding -> 8..16 -> 64 -> 1 MLP -> exp(. - 1)
-// (radiance_field.py:808-812,836-840).  thread = sample, ALL levels: measured (tools/prop_probe.py) the per-sample gather of all
-// levels costs what the level-major forward costs on these small tables (52 vs 58 us, 94 vs 90 us at 1 M samples), so nothing is lost
-// by giving up the level-major blocks, and the positions ([N,3]), the encoding ([L][N][F]) and a 20-us MLP launch never exist.
-// The encoding is computed exactly as hashgrid_fwd_kernel does (same branches, same order); the MLP is a plain fmaf chain on the
-// vector pipe with the weights as scalar operands (641 floats: uniform loads), hidden under the gathers of the other waves.
-__device__ __forceinline__ void ray_point_contracted(const float *__restrict__ aabb, bool unbounded, const float *__restrict__ o,
-                                                     const float *__restrict__ d, float tsum, float (&v)[3]) {
-#pragma clang fp contract(off)   // bit-exact with emer_ray_points (csrc/elementwise.hip is compiled with contraction off)
-    float p[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) p[k] = o[k] + d[k] * tsum / 2.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = (p[k] - aabb[k]) / (aabb[3 + k] - aabb[k]);
-    if (unbounded) {
-        float mag = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { v[k] = v[k] * 2.0f - 1.0f; mag = fmaxf(mag, fabsf(v[k])); }
-        if (!(mag < 1.0f)) {
-            const float sc = 2.0f - 1.0f / mag;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = sc * (v[k] / mag);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = v[k] / 4.0f + 0.5f;
-    }
-    bool inside = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) inside = inside && (v[k] > 0.0f) && (v[k] < 1.0f);
-    if (!inside) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) v[k] = v[k] * 0.0f;
-    }
-}
-
-// one level of the D = 3 encoding of one sample: the arithmetic of hashgrid_fwd_kernel<3, F, float, ., false> (paired gathers on hashed
-// power-of-two levels, generic corner loop elsewhere)
-template <int F>
-__device__ __forceinline__ void encode_level_d3(const LevelInfo &li, const float *__restrict__ table, const float (&xv)[3], float (&acc)[F]) {
-    constexpr int D = 3;
-    float w[D];
-    uint32_t gi[D];
-    cell_of<D>(li, xv, gi, w);
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
-    const bool pow2 = (li.size & (li.size - 1u)) == 0u;
-    if (F <= 2 && li.hashed && pow2) {
-        const uint32_t primes[4] = {1u, 2654435761u, 805459861u, 3674653429u};
-        const uint32_t maskv = li.size - 1u;
-        const bool x_even = (gi[0] & 1u) == 0u;
-#pragma unroll
-        for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
-            uint32_t h = 0;
-            float t[D];
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                const uint32_t bit = (m >> (d - 1)) & 1u;
-                h ^= (gi[d] + bit) * primes[d];
-                t[d] = bit ? w[d] : 1.0f - w[d];
-            }
-            const uint32_t idx0 = (gi[0] ^ h) & maskv, idx1 = ((gi[0] + 1u) ^ h) & maskv;
-            float v0[F], v1[F];
-            if (x_even) {
-                float e[2 * F];
-                load_feats<2 * F, float>(table + (size_t)(idx0 & ~1u) * F, e);
-#pragma unroll
-                for (int f = 0; f < F; ++f) { v0[f] = (idx0 & 1u) ? e[F + f] : e[f]; v1[f] = (idx0 & 1u) ? e[f] : e[F + f]; }
-            } else {
-                load_feats<F, float>(table + (size_t)idx0 * F, v0);
-                load_feats<F, float>(table + (size_t)idx1 * F, v1);
-            }
-            float wa = 1.0f - w[0], wb = w[0];
-#pragma unroll
-            for (int d = 1; d < D; ++d) { wa *= t[d]; wb *= t[d]; }
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] += wa * v0[f];
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] += wb * v1[f];
-        }
-    } else {
-#pragma unroll
-        for (uint32_t m = 0; m < (1u << D); ++m) {
-            float wt = 1.0f;
-            uint32_t c[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (m & (1u << d)) { wt *= w[d]; c[d] = gi[d] + 1u; }
-                else { wt *= 1.0f - w[d]; c[d] = gi[d]; }
-            }
-            float v[F];
-            load_feats<F, float>(table + (size_t)grid_index<D>(li, c) * F, v);
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] += wt * v[f];
-        }
-    }
-}
-
-// MLP part: the arithmetic of density_fwd_kernel (csrc/mlp_fused.hip) -- v_mfma_f32_16x16x4_f32 with W0 as the A operand held in
-// registers, the bias as the initial accumulator, relu, the 64-term dot product with w1 as an fmaf chain per lane and two xor shuffles --
-// so the density is BITWISE what emer_neck_fwd(n_out = 1) returns for the same encoding.  The encodings of a wave's 64 samples change
-// layout (lane = sample -> lane (m, g) = feature 4 s + g of row 16 j + m) through a wave-private LDS tile: no barrier.
-template <int F>
-__global__ __launch_bounds__(256) void prop_density_fwd_kernel(const emer_grid_desc g, const float *__restrict__ params,
-                                                               const float *__restrict__ origins, const float *__restrict__ dirs,
-                                                               const float *__restrict__ ts, const float *__restrict__ te,
-                                                               const float *__restrict__ aabb, int unbounded, const float *__restrict__ w0,
-                                                               const float *__restrict__ b0, const float *__restrict__ w1,
-                                                               const float *__restrict__ b1, int64_t R, int32_t S, float *__restrict__ dens) {
-    constexpr int LMAX = 8, K0P = LMAX * F, KS4 = K0P / 4, PITCH = 80;   // (levels past n_levels contribute zero features with zero weights)
-    using f32x4m = __attribute__((ext_vector_type(4))) float;
-    __shared__ float tile[4][K0P][PITCH];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, gq = lane >> 4;
-    const int32_t K0 = (int32_t)g.n_levels * F;
-    float aw[4][KS4];
-#pragma unroll
-    for (int s = 0; s < KS4; ++s) {
-        const int32_t k = 4 * s + gq;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) aw[p][s] = k < K0 ? w0[(int64_t)(16 * p + m) * K0 + k] : 0.0f;
-    }
-    f32x4m b0r[4], w1r[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            b0r[p][i] = b0 ? b0[16 * p + 4 * gq + i] : 0.0f;
-            w1r[p][i] = w1[16 * p + 4 * gq + i];
-        }
-    const float b1v = b1 ? b1[0] : 0.0f;
-    const int64_t N = R * (int64_t)S, n_chunks = (N + 63) >> 6, n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < n_chunks; c += n_waves) {
-        const int64_t n = c * 64 + lane;
-        const int64_t nc = n < N ? n : N - 1;   // (clamped: every lane computes, rows past the end are not stored)
-        const int64_t r = nc / S;
-        float xv[3];
-        ray_point_contracted(aabb, unbounded != 0, origins + r * 3, dirs + r * 3, ts[nc] + te[nc], xv);
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) {
-            float acc[F];
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] = 0.0f;
-            if (l < (int)g.n_levels) {
-                const LevelInfo li = level_info(g, (uint32_t)l);
-                encode_level_d3<F>(li, params + (size_t)li.offset * F, xv, acc);
-            }
-#pragma unroll
-            for (int f = 0; f < F; ++f) tile[wave][l * F + f][lane] = acc[f];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private tile: no barrier)
-        float x[4][KS4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int s = 0; s < KS4; ++s) x[j][s] = tile[wave][4 * s + gq][16 * j + m];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4m h[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) h[p] = b0r[p];
-#pragma unroll
-            for (int s = 0; s < KS4; ++s)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) h[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[p][s], x[j][s], h[p], 0, 0, 0);
-            float dot = 0.0f;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dot = fmaf(w1r[p][i], fmaxf(h[p][i], 0.0f), dot);
-            dot += __shfl_xor(dot, 16, 64);
-            dot += __shfl_xor(dot, 32, 64);
-            const int64_t row = c * 64 + 16 * j + m;
-            if (gq == 0 && row < N) dens[row] = expf(dot + b1v - 1.0f);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile has been read before the next chunk overwrites it
-    }
 }
 
 // ------------------------------------------------------------------------ backward (params)
@@ -924,28 +645,18 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_params_kernel(const emer_gri
 // trace[0] = item counter; record i at trace[8 + 4 i] = {level | slice << 8 | range << 24 | block << 40, start, end, hits}
 __device__ unsigned long long *g_sliced_trace = nullptr;
 #endif
-#ifndef EMER_PACE
-#define EMER_PACE 0        // soft pacing of the owners of a scheduling block (r4 experiment; measured): off
-#endif
-#ifndef EMER_PACE_LEAD
-#define EMER_PACE_LEAD 2   // a wave may run at most this many 65 536-sample trips ahead of the slowest wave of its block
-#endif
-constexpr int kSliceThreads = EMER_SLICE_THREADS;
+constexpr int kSliceThreads = 1024;   // owner workgroup: 1024 lanes with a 128 KiB slice, one per CU (two 512-lane owners per CU: measured +9 %, DESIGN 4.1 [r4])
 constexpr int kSliceWaves = kSliceThreads / 64;
 #ifndef EMER_STRIDED_MAX_RES
 #define EMER_STRIDED_MAX_RES 420
 #endif
 constexpr uint32_t kStridedHitsMaxRes = EMER_STRIDED_MAX_RES;          // one-feature hashed levels (no run reduction) up to this resolution spread a wave's hits over distant samples
-constexpr int kDrainK = 6;                            // chunks per drain of the NON-pipelined build (-DEMER_PIPELINE=0, A/B only)
 
 
 // ---- DPP wave scans (gfx9 data-parallel primitives: a VALU operand modifier, no LDS round trip) -------------------
 // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source lane does not exist, or whose row is
 // masked off, keep `old`.  row_shr:n = 0x110 + n (inside a 16-lane row), row_bcast15 = 0x142 (lane 15 of each row to
 // the next row), row_bcast31 = 0x143 (lane 31 to rows 2 and 3), wave_shr:1 = 0x138, wave_shl:1 = 0x130.
-#ifndef EMER_DPP_SCANS
-#define EMER_DPP_SCANS 1
-#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t src, uint32_t old = 0u) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
@@ -962,9 +673,6 @@ __device__ __forceinline__ uint32_t wave_next_u32(uint32_t v, uint32_t edge) { r
 // multiply-add per value and step.  The scan operator on (head flag, value) pairs is
 // (f1, v1) (+) (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2); keep[s] = 1.0 where the lane still ACCEPTS the partner's value
 // at step s (no head seen so far between the partner and itself), else 0.0.
-#ifndef EMER_RUN_EARLY_OUT
-#define EMER_RUN_EARLY_OUT 1
-#endif
 struct RunMasks {
     float keep[6];
     bool need[6];  // (wave-uniform) some lane still accepts a value at this step: runs longer than 2^s lanes exist
@@ -986,9 +694,6 @@ __device__ __forceinline__ RunMasks run_masks(bool head) {
 // initialisation, a v_mov_b32_dpp and a v_fmac_f32 per step: 288 instead of 96 instructions for the 16 reductions of a
 // chunk), so the step is written out.  A DPP source written by the previous VALU instruction needs two wait states, the
 // assembler does not add them inside inline asm: every step starts with s_nop 1 and walks all values before the next.
-#ifndef EMER_FMAC_DPP
-#define EMER_FMAC_DPP 1
-#endif
 #define EMER_DPP_STEP(CTRL, KEEP)                                                                                         \
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                                      \
         if (i == 0) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " CTRL " bank_mask:0xf" : "+v"(v[i]) : "v"(KEEP)); \
@@ -996,27 +701,15 @@ __device__ __forceinline__ RunMasks run_masks(bool head) {
     }
 template <int NV>
 __device__ __forceinline__ void run_reduce_dpp(float (&v)[NV], const RunMasks &m) {
-#if EMER_FMAC_DPP
     // a step whose keep mask is zero on every lane adds nothing: with eight or more values per step (the pair sums of the
     // four-feature grids) it is skipped (wave-uniform test; short runs on the fine levels need one or two of the six steps:
     // xyzt grid 1424 -> 1388 us); with fewer values the test costs what it saves (main grid: +1 %)
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[0]) { EMER_DPP_STEP("row_shr:1 row_mask:0xf", m.keep[0]) }
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[1]) { EMER_DPP_STEP("row_shr:2 row_mask:0xf", m.keep[1]) }
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[2]) { EMER_DPP_STEP("row_shr:4 row_mask:0xf", m.keep[2]) }
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[3]) { EMER_DPP_STEP("row_shr:8 row_mask:0xf", m.keep[3]) }
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[4]) { EMER_DPP_STEP("row_bcast:15 row_mask:0xa", m.keep[4]) }
-    if (!(EMER_RUN_EARLY_OUT && NV >= 8) || m.need[5]) { EMER_DPP_STEP("row_bcast:31 row_mask:0xc", m.keep[5]) }
-#else
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = fmaf(dpp_f32<0x111, 0xF>(v[i]), m.keep[0], v[i]);
-        v[i] = fmaf(dpp_f32<0x112, 0xF>(v[i]), m.keep[1], v[i]);
-        v[i] = fmaf(dpp_f32<0x114, 0xF>(v[i]), m.keep[2], v[i]);
-        v[i] = fmaf(dpp_f32<0x118, 0xF>(v[i]), m.keep[3], v[i]);
-        v[i] = fmaf(dpp_f32<0x142, 0xA>(v[i]), m.keep[4], v[i]);
-        v[i] = fmaf(dpp_f32<0x143, 0xC>(v[i]), m.keep[5], v[i]);
-    }
-#endif
+    if (NV < 8 || m.need[0]) { EMER_DPP_STEP("row_shr:1 row_mask:0xf", m.keep[0]) }
+    if (NV < 8 || m.need[1]) { EMER_DPP_STEP("row_shr:2 row_mask:0xf", m.keep[1]) }
+    if (NV < 8 || m.need[2]) { EMER_DPP_STEP("row_shr:4 row_mask:0xf", m.keep[2]) }
+    if (NV < 8 || m.need[3]) { EMER_DPP_STEP("row_shr:8 row_mask:0xf", m.keep[3]) }
+    if (NV < 8 || m.need[4]) { EMER_DPP_STEP("row_bcast:15 row_mask:0xa", m.keep[4]) }
+    if (NV < 8 || m.need[5]) { EMER_DPP_STEP("row_bcast:31 row_mask:0xc", m.keep[5]) }
 }
 #undef EMER_DPP_STEP
 
@@ -1040,7 +733,6 @@ __device__ __forceinline__ void run_reduce(float (&v)[NV], int run_start, int la
 
 // ---- analytic hit compaction (used by the owner-computes backward) ----------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v, int lane) {
-#if EMER_DPP_SCANS
     (void)lane;
     v += dpp_u32<0x111, 0xF>(v);
     v += dpp_u32<0x112, 0xF>(v);
@@ -1049,14 +741,6 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum_u32(uint32_t v, int lane)
     v += dpp_u32<0x142, 0xA>(v);
     v += dpp_u32<0x143, 0xC>(v);
     return v;
-#else
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, off, kWave);
-        if (lane >= off) v += o;
-    }
-    return v;
-#endif
 }
 // position of the k-th (0-based) set bit of w; k < popcount(w)
 __device__ __forceinline__ uint32_t select64(uint64_t w, uint32_t k) {
@@ -1090,13 +774,6 @@ __device__ __forceinline__ uint32_t select64_lut(uint64_t w, uint32_t k, const u
 }
 
 // ---- pair helpers of the owner-computes backward (hashed power-of-two levels) -------------------------------------
-#ifndef EMER_PAIR_QUEUE
-#define EMER_PAIR_QUEUE 1
-#endif
-#ifdef EMER_QUEUE_DEBUG
-__device__ uint32_t g_queue_dbg[8];   // [0] bad ids read back, [1] appended, [2] drained, [4..6] last bad entry / head / count
-__device__ int64_t g_queue_dbg_n;
-#endif
 constexpr uint32_t kPairQueue = 72;        // ring capacity per wave (words): drain threshold - 1 + one chunk of 64
 #ifndef EMER_QUEUE_DRAIN
 #define EMER_QUEUE_DRAIN 8
@@ -1143,7 +820,6 @@ __device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], c
         wa *= t; wb *= t;
     }
     const uint32_t l0 = (gi[0] ^ h) & local_mask, l1 = ((gi[0] + 1u) ^ h) & local_mask;  // offsets inside the slice
-#if EMER_ROT_FEATS
     if (F == 2) {
         // An entry is F doubles, so "feature f of a random entry" reaches only half of the 32 bank pairs; odd lanes
         // therefore add feature 1 in the first instruction and feature 0 in the second: each instruction's addresses cover
@@ -1159,19 +835,11 @@ __device__ __forceinline__ void add_pair(double *acc, const uint32_t (&gi)[D], c
         }
         return;
     }
-#endif
     if (has) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-#if EMER_ABL & 4
-            acc[(size_t)l0 * F + f] = (double)(wa * go[f]);
-            acc[(size_t)l1 * F + f] = (double)(wb * go[f]);
-#elif EMER_ABL & 8
-            if (wa * go[f] == 12345.0f && wb * go[f] == 54321.0f) acc[(size_t)(l0 ^ l1) * F + f] = 1.0;
-#else
             atomicAdd(acc + (size_t)l0 * F + f, (double)(wa * go[f]));  // ds_add_f64
             atomicAdd(acc + (size_t)l1 * F + f, (double)(wb * go[f]));
-#endif
         }
     }
 }
@@ -1239,10 +907,6 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
     // hipcc 7.2 (gfx950) folded the former `id = e & 0xFFFFFF` INTO the x address as `e * 12` (mask dropped: memory
     // fault); the id is made opaque here so the address arithmetic cannot be rewritten across the unpacking
     asm volatile("" : "+v"(n));
-#ifdef EMER_QUEUE_DEBUG
-    if (on) atomicAdd(g_queue_dbg + 2, 1u);
-    if (n >= (uint32_t)g_queue_dbg_n) { atomicAdd(g_queue_dbg + 0, 1u); g_queue_dbg[4] = e; g_queue_dbg[5] = q_head; g_queue_dbg[6] = count; n = 0; match = 0; }
-#endif
     float xv[D], go[F], w[D];
     uint32_t gi[D], hd[D][2];
     load_x<D>(x, (int64_t)n, xv);
@@ -1254,27 +918,12 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
     while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go, match, local_mask);
 }
 
-#ifndef EMER_PIPELINE
-#define EMER_PIPELINE 1
-#endif
-#ifndef EMER_WIDE_PAIRS
-#define EMER_WIDE_PAIRS 1
-#endif
 // Timing-only ablation builds (tools/ab_grid.sh; results are WRONG, never in the product library): bit 0 = gathers from a
 // 16 K-sample window (L2 hits), bit 1 = gathers from a 1 K-sample window (L1 hits), bit 2 = plain LDS stores instead of
 // ds_add_f64, bit 3 = no LDS accumulation at all, bit 4 = hit -> sample mapping without the compaction look-ups.
-#ifndef EMER_ABL
-#define EMER_ABL 0
-#endif
 // chunks (of 64 hits) per register set of the software-pipelined drain: two sets are live, D + F + 1 registers per chunk
 #ifndef EMER_PIPE_K
 #define EMER_PIPE_K 2
-#endif
-#ifndef EMER_ROT_FEATS
-#define EMER_ROT_FEATS 1
-#endif
-#ifndef EMER_SKIP_DEAD
-#define EMER_SKIP_DEAD 1
 #endif
 template <int D, int F> constexpr int kPipeK() {
     constexpr int per = D + F + 1, k = 28 / per;  // register budget of one set
@@ -1297,7 +946,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                                                                                    const uint64_t *__restrict__ masks,
                                                                                    uint32_t *__restrict__ work_ctr,
                                                                                    float *__restrict__ grad, int64_t N,
-                                                                                   uint32_t *__restrict__ pace, uint32_t pace_trips, uint32_t accumulate) {
+                                                                                   uint32_t accumulate) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ uint32_t s_item;
     // Persistent workgroups with XCD-affine work lists.  Each XCD has a list of (level, slice, range) items -- whole
@@ -1337,19 +986,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // local index on the XCD's list -> global item index (blocks of kSchedBlock dealt round-robin) -> (level, slice, range)
     uint32_t j = item & 0xFFFFFFu;
     j = ((((j >> plan.sched_shift) << 3) + xcd) << plan.sched_shift) + (j & ((1u << plan.sched_shift) - 1u));
-#if EMER_PACE
-    const uint32_t gj = j;   // global item index: block gj / kSchedBlock is one round of one XCD's CUs
-    uint32_t lvl_base = 0;   // global index of the level's first item
-#endif
     uint32_t level = 0, slice = 0, range = 0;
     for (uint32_t oi = 0; oi < g.n_levels; ++oi) {
         level = plan.order[oi];
         const uint32_t nb = plan.n_slices[level] * plan.n_ranges[level];
         if (j < nb) { slice = j % plan.n_slices[level]; range = j / plan.n_slices[level]; break; }
         j -= nb;
-#if EMER_PACE
-        lvl_base += nb;
-#endif
     }
     const LevelInfo li = level_info(g, level);
 #ifdef EMER_SLICED_TRACE
@@ -1357,12 +999,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     unsigned long long trace_hits = 0;
 #endif
     const bool dense_rt = !li.hashed;
-    // [r5] EMER_WIDE_PAIRS: levels whose resolution reaches the slice width (the xyzt tables' res 4424 / 8192 against 4096-entry slices)
+    // [r5] wide pairs: levels whose resolution reaches the slice width (the xyzt tables' res 4424 / 8192 against 4096-entry slices)
     // are pairable too -- the x-neighbours still share a slice unless x sits at the last position of a slice-wide block, a 1-in-4096
     // event handled like the out-of-range wrap (wave-uniform fallback to the per-corner path).  Before, those levels took the per-corner
     // path for EVERY hit: 680 us per work item against 450 us for the level below them (tools/trace_sliced.py).
-    const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && (EMER_WIDE_PAIRS || li.res < (1u << plan.shift[level]));
-    const bool run_reduced = pairable_rt && EMER_DPP_SCANS && F >= 2 && li.res <= (uint32_t)EMER_RUN_RES;  // coarse hashed level: runs of equal cells are summed before the LDS
+    const bool pairable_rt = li.hashed && (li.size & (li.size - 1u)) == 0u && true;
+    const bool run_reduced = pairable_rt && F >= 2 && li.res <= (uint32_t)EMER_RUN_RES;  // coarse hashed level: runs of equal cells are summed before the LDS
     const bool consecutive = dense_rt || run_reduced || li.res > kStridedHitsMaxRes;  // hit -> lane assignment, see the compaction below
     const uint32_t shift = plan.shift[level], n_ranges = plan.n_ranges[level];
     const uint32_t first = slice << shift;
@@ -1381,26 +1023,12 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     unsigned long long *Hv = reinterpret_cast<unsigned long long *>(scratch + 64);  // (one type for plain and atomic accesses)
     uint32_t *El = reinterpret_cast<uint32_t *>(scratch + 128), *Hx = reinterpret_cast<uint32_t *>(scratch + 160);
 
-#if EMER_PACE
-    // Soft pacing of a round [r4 experiment, DESIGN 4.1]: the (up to) 32 items of a scheduling block are the slices of ONE level that one
-    // XCD's CUs work on together; each 128-byte x / dout line is wanted by ~10 of them, but they drift apart in the sample stream and
-    // only a third of those requests hit in the XCD's L2.  Here every wave counts the 65 536-sample trips it has finished in a per-block
-    // counter and does not start trip t before ALL waves of the block have finished trip t - EMER_PACE_LEAD: the block's owners stay
-    // within EMER_PACE_LEAD trips of each other.  Only for blocks that lie entirely on an unsplit hashed level (every member paces);
-    // members that have not started yet are picked up by CUs that never wait on this block (items are taken in order), so the wait
-    // cannot deadlock.
-    const uint32_t blk = gj / kSchedBlock;
-    const uint32_t blk_first = blk * kSchedBlock, blk_last = (blk_first + kSchedBlock < plan.total_items ? blk_first + kSchedBlock : plan.total_items) - 1u;
-    const bool paced = pace_trips != 0u && li.hashed && n_ranges == 1u && blk_first >= lvl_base && blk_last < lvl_base + plan.n_slices[level];
-    uint32_t *pc = pace + (size_t)blk * 64u;
-    const uint32_t pace_full = (blk_last - blk_first + 1u) * (uint32_t)kSliceWaves;
-#endif
     for (uint32_t i = threadIdx.x; i < n_local * F; i += kSliceThreads) acc[i] = 0.0;
     __syncthreads();
     // second-pair queue (pairable levels): wave-private ring of kPairQueue words behind the compaction scratch
     uint32_t *Qw = reinterpret_cast<uint32_t *>(reinterpret_cast<uint64_t *>(smem + (size_t)plan.max_local * F) + (size_t)kSliceWaves * kScanWords)
                    + (size_t)wave * kPairQueue;
-    const bool use_queue = EMER_PAIR_QUEUE && pairable_rt && N <= (1ll << kPairQueueShift) && (1u << (D - 1)) <= 8u;
+    const bool use_queue = pairable_rt && N <= (1ll << kPairQueueShift) && (1u << (D - 1)) <= 8u;
     const uint32_t slice_bits = (li.size - 1u) & ~((1u << shift) - 1u), slice_want = first, local_mask = (1u << shift) - 1u;
 
     const float *__restrict__ dl = dout + (int64_t)level * sl;
@@ -1435,11 +1063,11 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     // ---- the hit stream of this item, as GROUPS of up to KG chunks of 64 hits --------------------------------------
     // next_trip() compacts the next non-empty 1024-word trip into the wave's scratch (hv / hexcl / total / n_chunks);
     // issue(G) materialises the next KG chunks of the current trip -- sample ids, then the x / dout gathers, left IN
-    // FLIGHT in G's registers -- and consume(G) does the arithmetic and the LDS adds.  With EMER_PIPELINE the two are
+    // FLIGHT in G's registers -- and consume(G) does the arithmetic and the LDS adds.  The two are
     // software-pipelined over two register sets: the gathers of group g + 1 (and the compaction of its trip) are issued
     // before group g is consumed, so a wave overlaps its own gather latency instead of relying on the three other
     // waves of its SIMD (the slice fills the LDS: one 1024-thread workgroup per CU, four waves per SIMD).
-    constexpr int KG = EMER_PIPELINE ? kPipeK<D, F>() : kDrainK;
+    constexpr int KG = kPipeK<D, F>();
     int64_t wbase = w_begin;          // next trip to compact
     uint32_t trip_w0 = 0;             // first word (32-bit) of the trip held in the scratch
     uint32_t total = 0, n_chunks = 0, c0 = 0, hexcl = 0;
@@ -1447,20 +1075,6 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     uint64_t pre = (w_begin + my_word < w_end) ? bm[w_begin + my_word] : 0ull;
     auto next_trip = [&]() __attribute__((always_inline)) -> bool {
         while (wbase < w_end) {
-#if EMER_PACE
-            if (!dense && paced) {   // (wave-uniform)
-                const uint32_t t = (uint32_t)((wbase - w_begin) / kSliceThreads);   // the trip about to start
-                if (t > 0u && lane == 0) __hip_atomic_fetch_add(pc + (t - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // trip t - 1 is done
-                if (t >= (uint32_t)EMER_PACE_LEAD) {
-                    for (;;) {
-                        uint32_t v = lane == 0 ? __hip_atomic_load(pc + (t - (uint32_t)EMER_PACE_LEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-                        if (v >= pace_full) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-            }
-#endif
             const uint64_t wv = pre;
             trip_w0 = (uint32_t)wbase;
             wbase += kSliceThreads;
@@ -1514,9 +1128,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             // far apart (different rays).
             uint32_t n = 0u;               // chunks past the end of the trip fetch sample 0 (cached) and are never consumed
             bool in_range = false;
-#if EMER_SKIP_DEAD
             if (live) {                     // wave-uniform: only the sample id is merged (one register), the gathers below are unconditional
-#endif
             uint32_t j = consecutive ? 64u * c + (uint32_t)lane : __umul24((uint32_t)lane, n_chunks) + c;  // (n_chunks <= 64: full-rate multiply)
             in_range = j < total;
             j = in_range ? j : last_hit;                                             // out-of-range lanes repeat the last hit (masked below)
@@ -1539,19 +1151,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             if constexpr (use_select_lut<D>()) bit = select64_lut(wq, j - (el & 0xFFFFu), sel_lut);
             else bit = select64(wq, j - (el & 0xFFFFu));
             n = ((trip_w0 + (uint32_t)wave_word0 + ((el >> 16) << lane_word_shift)) << 6) + bit;  // (32-bit: n < 2^28)
-#if EMER_SKIP_DEAD
             }
-#else
-            n = live ? n : 0u;
-#endif
-#if EMER_ABL & 16
-            n = live ? (((trip_w0 + (uint32_t)wave_word0) << 6) + ((j * 16u + (j >> 8)) & 4095u)) : 0u;
-#endif
-#if EMER_ABL & 1
-            n &= 0x3FFFu;
-#elif EMER_ABL & 2
-            n &= 0x3FFu;
-#endif
             G.vld[k] = in_range && live;
             G.ns[k] = n;
             // 32-bit byte offsets from the (uniform) bases: the host checked N * 16 < 2^32, so the gathers use the
@@ -1596,22 +1196,10 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
 #pragma unroll
                 for (int d = 0; d < D; ++d) { cell += gi[d] * mul; mul *= li.res + 1u; }
                 if (!valid) cell = 0xFFFFFFFFu;
-#if EMER_DPP_SCANS
                 const uint32_t prev = wave_prev_u32(cell, ~cell);
                 const bool head = cell != prev;  // (lane 0 compares with ~cell: always a head)
                 const RunMasks rm = run_masks(head);
                 const bool next_head = wave_next_u32(head ? 1u : 0u, 1u) != 0u;
-#else
-                const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);
-                const bool head = lane == 0 || cell != prev;
-                int run_start = head ? lane : 0;
-#pragma unroll
-                for (int off = 1; off < kWave; off <<= 1) {  // max-scan of the head lanes
-                    const int t = __shfl_up(run_start, off, kWave);
-                    if (lane >= off) run_start = run_start > t ? run_start : t;
-                }
-                const bool next_head = __shfl_down((int)head, 1, kWave) != 0;
-#endif
                 const bool tail = valid && (lane == 63 || next_head);
                 // dense index of corner m = index of the cell + a level-uniform offset (same arithmetic mod 2^32 as
                 // grid_index: the strides are scalars, so the per-corner multiplies collapse to one add)
@@ -1637,11 +1225,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                     float v[F];
 #pragma unroll
                     for (int f = 0; f < F; ++f) v[f] = wt * G.go[k][f];
-#if EMER_DPP_SCANS
                     run_reduce_dpp<F>(v, rm);
-#else
-                    run_reduce<F>(v, run_start, lane);
-#endif
                     uint32_t idx = cell_idx + off_m;
                     if ((li.size & (li.size - 1u)) == 0u) idx &= li.size - 1u;
                     else if (idx >= li.size) { idx -= li.size; if (idx >= li.size) idx %= li.size; }
@@ -1650,7 +1234,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         for (int f = 0; f < F; ++f) atomicAdd(acc + (size_t)(idx - first) * F + f, (double)v[f]);
                     }
                 }
-            } else if (pairable && !__ballot(valid && (gi[0] >= li.res || (EMER_WIDE_PAIRS && (gi[0] & local_mask) == local_mask)))) {
+            } else if (pairable && !__ballot(valid && (gi[0] >= li.res || (gi[0] & local_mask) == local_mask))) {
                 // hashed power-of-two level whose resolution is below the slice width: the two x-corners of a
                 // (y, z[, t]) combination differ only in index bits BELOW the slice bits, so they always share a
                 // slice -- for cells inside the grid (gi[0] + 1 <= res < slice width).  Inputs outside [0, 1] wrap
@@ -1663,10 +1247,7 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                 uint32_t hd[D][2];
                 hash_terms<D>(gi, hd);
                 // (the x index reaches into the slice bits when the resolution exceeds the slice width: it joins the test)
-                uint32_t match = valid ? pair_matches<D>(hd, EMER_WIDE_PAIRS ? slice_want ^ (gi[0] & slice_bits) : slice_want, slice_bits) : 0u;
-#if EMER_ABL & (1 | 2 | 16)
-                match = valid ? 1u : 0u;
-#endif
+                uint32_t match = valid ? pair_matches<D>(hd, slice_want ^ (gi[0] & slice_bits), slice_bits) : 0u;
                 if (run_reduced) add_pair_runs<D, F>(acc, gi, w, hd, G.go[k], match, local_mask, valid, lane);  // (level-uniform)
                 else add_pair<D, F>(acc, gi, w, hd, G.go[k], match, local_mask);
                 if (use_queue) {
@@ -1677,9 +1258,6 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
                         if (q_len + n_more <= kPairQueue) {
                             if (more) Qw[(q_head + q_len + (uint32_t)__popcll(mb & lt_mask)) % kPairQueue] = (G.ns[k] << 8) | match;
                             q_len += n_more;
-#ifdef EMER_QUEUE_DEBUG
-                            if (lane == 0) atomicAdd(g_queue_dbg + 1, n_more);
-#endif
                         } else {
                             // ring full (the queue is drained between groups, see below): add the further pairs right here,
                             // on masked lanes -- no gathers inside the chunk loop, so the compiler's wait counts for the
@@ -1722,7 +1300,6 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
     };
     {
         HitGroup<D, F, KG> ga;
-#if EMER_PIPELINE
         HitGroup<D, F, KG> gb;
         bool more = issue(ga);
         while (more) {
@@ -1732,9 +1309,6 @@ __global__ __launch_bounds__(kSliceThreads) void hashgrid_bwd_params_sliced_kern
             more = issue(ga);
             consume(gb);
         }
-#else
-        while (issue(ga)) consume(ga);
-#endif
     }
     while (q_len) {  // wave-uniform: second pairs still queued
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2009,33 +1583,6 @@ extern "C" int emer_hashgrid_bwd_input_jac(const emer_grid_desc *g, const float 
     });
 }
 
-extern "C" int emer_prop_density_supported(const emer_grid_desc *g, int32_t hidden, int32_t n_out) {
-    if (check_desc(g) != EMER_OK) return 0;
-    // (F = 1: up to 8 levels -- two 16-byte pieces of a weight row; F = 2: up to 8 levels = 16 inputs)
-    return (g->n_dims == 3 && (g->n_features == 1 || g->n_features == 2) && g->n_levels <= 8 && hidden == 64 && n_out == 1) ? 1 : 0;
-}
-
-// density [R * S] of a proposal network for the samples (t_starts, t_ends) [R, S] of the rays (origins, dirs) [R, 3], outside autograd:
-// emer_ray_points -> emer_hashgrid_fwd -> emer_neck_fwd(n_out = 1) in one launch.  w0 [64][L * F] row-major, b0 [64], w1 [64], b1 [1].
-extern "C" int emer_prop_density_fwd(const emer_grid_desc *g, const float *params, const float *origins, const float *dirs, const float *t_starts,
-                                     const float *t_ends, const float *aabb, int unbounded, const float *w0, const float *b0, const float *w1,
-                                     const float *b1, int64_t n_rays, int32_t n_samples, float *density, void *stream) {
-    if (int rc = check_desc(g)) return rc;
-    EMER_REQUIRE(n_rays >= 0 && n_samples >= 1, "prop_density_fwd: bad sizes");
-    if (n_rays == 0) return EMER_OK;
-    EMER_REQUIRE(emer_prop_density_supported(g, 64, 1), "prop_density_fwd: needs a D3 grid with F in {1, 2} and at most 8 levels");
-    EMER_REQUIRE(params && origins && dirs && t_starts && t_ends && aabb && w0 && w1 && density, "prop_density_fwd: null pointer");
-    int64_t blocks64 = ceil_div(n_rays * (int64_t)n_samples, 256 * 4);   // ~four 64-sample chunks per wave (the MLP weights are loaded once per wave)
-    const uint32_t blocks = (uint32_t)(blocks64 < 1 ? 1 : blocks64);
-    if (g->n_features == 1)
-        hipLaunchKernelGGL(prop_density_fwd_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), *g, params, origins, dirs, t_starts, t_ends, aabb,
-                           unbounded, w0, b0, w1, b1, n_rays, n_samples, density);
-    else
-        hipLaunchKernelGGL(prop_density_fwd_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream), *g, params, origins, dirs, t_starts, t_ends, aabb,
-                           unbounded, w0, b0, w1, b1, n_rays, n_samples, density);
-    return check_launch("prop_density_fwd");
-}
-
 extern "C" int emer_hashgrid_bwd_params(const emer_grid_desc *g, const float *x, const float *dout, int64_t sn,
                                         int64_t sl, void *grad, int grad_dtype, int64_t n, void *stream) {
     if (int rc = check_desc(g)) return rc;
@@ -2158,7 +1705,7 @@ extern "C" int emer_hashgrid_sliced_split_level(const emer_grid_desc *g) {
     if (check_desc(g) != EMER_OK) return 0;
     const SlicePlan plan = make_slice_plan(g);
     if (!plan.ok) return 0;
-    const uint32_t owners = EMER_SLICE_THREADS == 1024 ? 256 : 512;
+    const uint32_t owners = 256;
     if (plan.total_items <= owners) return 0;
     uint32_t items = 0, k = g->n_levels;
     while (k > 1u) {
@@ -2204,11 +1751,7 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
     ZeroRegions zr;
     zr.count = 0;
     uint32_t *work_ctr = reinterpret_cast<uint32_t *>(slice_masks + (size_t)g->n_levels * (64 * plan.mask_q) * (size_t)ceil_div(n, 64));
-    // (EMER_PACE builds: 64 blocks x 64 trip counters behind the cursors, zeroed with them; larger launches run unpaced)
-    uint32_t *pace = work_ctr + 16;
-    const uint32_t n_trips = (uint32_t)ceil_div(ceil_div(n, 64), kSliceThreads), n_blk = (total_items + kSchedBlock - 1u) / kSchedBlock;
-    const uint32_t pace_trips = (EMER_PACE && n_trips <= 64u && n_blk <= 64u && n_trips > (uint32_t)EMER_PACE_LEAD) ? n_trips : 0u;
-    zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = pace_trips ? 16u + 64u * 64u : 8u; ++zr.count;
+    zr.p[zr.count] = reinterpret_cast<float *>(work_ctr); zr.n[zr.count] = 8u; ++zr.count;
     for (uint32_t l = level_begin; l < level_end; ++l) {
         if (plan.n_ranges[l] > 1u && !accumulate) {   // (accumulate: the merging atomics add onto what is there)
             zr.p[zr.count] = grad + (size_t)g->offset[l] * F; zr.n[zr.count] = g->size[l] * F; ++zr.count;
@@ -2217,7 +1760,7 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
     hipLaunchKernelGGL(zero_regions_kernel, dim3(64, (uint32_t)zr.count), dim3(256), 0, as_stream(stream), zr);
     if (int rc = check_launch("hashgrid_bwd_params_sliced(zero)")) return rc;
     // persistent grid: one workgroup per CU (the LDS slice fills a CU), block b lands on XCD b % 8
-    uint32_t n_blocks = EMER_SLICE_THREADS == 1024 ? 256 : 512;
+    uint32_t n_blocks = 256;
     if (total_items < n_blocks) n_blocks = (total_items + 7u) / 8u * 8u;
     const size_t lds_base = (size_t)plan.max_local * F * sizeof(double) + (size_t)kSliceWaves * (kScanWords * sizeof(uint64_t) + kPairQueue * sizeof(uint32_t));
     return dispatch_df(g->n_dims, g->n_features, [&](auto d, auto f) {
@@ -2227,17 +1770,11 @@ static int hashgrid_bwd_params_sliced_range(const emer_grid_desc *g, const float
         if (int rc = reserve_lds(reinterpret_cast<const void *>(kern), lds, "hashgrid_bwd_params_sliced")) return rc;
         const ProfileEvents ev = take_profile_events();
         EMER_LAUNCH_PROFILED(ev, kern, dim3(n_blocks), dim3(kSliceThreads), lds, as_stream(stream), *g, plan, x, dout, sn, sl,
-                           slice_masks, work_ctr, grad, n, pace, pace_trips, accumulate ? 1u : 0u);
+                           slice_masks, work_ctr, grad, n, accumulate ? 1u : 0u);
         return check_launch("hashgrid_bwd_params_sliced");
     });
 }
 
-#ifdef EMER_QUEUE_DEBUG
-extern "C" int emer_debug_queue(int64_t n, uint32_t *out8, int reset) {
-    if (reset) { uint32_t z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_queue_dbg), z, sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_queue_dbg_n), &n, sizeof(n)); return 0; }
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_queue_dbg), 8 * sizeof(uint32_t)) == hipSuccess ? 0 : -1;
-}
-#endif
 #ifdef EMER_SLICED_TRACE
 extern "C" int emer_debug_sliced_trace(unsigned long long *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_sliced_trace), &buf, sizeof(buf)) == hipSuccess ? EMER_OK : EMER_E_LAUNCH;

@@ -795,9 +795,6 @@ __global__ __launch_bounds__(256) void wgrad_seg_kernel(const float *__restrict_
 // two 16-row blocks of loads are in flight ahead of the block being multiplied.  The four waves are summed through LDS
 // once at the end.  Column k of the virtual concatenation maps to "base + m * stride" for row-major and level-major
 // segments alike, so the per-lane addressing is hoisted out of the loop.
-#ifndef EMER_WGRAD_2BUF_TILES
-#define EMER_WGRAD_2BUF_TILES 9  // tiles from which only one block of loads is kept in flight (9: never)
-#endif
 
 template <int W> struct VecF;
 template <> struct VecF<1> { using T = float; };
@@ -1008,19 +1005,8 @@ __global__ __launch_bounds__(256) void wgrad_stream_kernel(const float *__restri
         const int64_t last = n_full - 1;
         auto ahead = [&](int64_t i, int d) { return (int)((i + d <= last ? i + d : last) - i); };  // blocks past the pointers (clamped)
         int64_t i = 0;
-        if constexpr (NT * KT >= EMER_WGRAD_2BUF_TILES) {
-            Blk v0, v1;
-            load(kFull, 0, 0, v0);
-            for (; i + 1 < n_full; i += 2) {
-                load(kFull, 0, 1, v1);
-                mult(v0);
-                load(kFull, 0, ahead(i, 2), v0);
-                mult(v1);
-                advance(2);
-            }
-            if (i < n_full) { mult(v0); advance(1); }
-        } else {
-            Blk v0, v1, v2;
+        {
+            Blk v0, v1, v2;   // three 16-row blocks rotate: two blocks of loads in flight ahead of the one being multiplied
             load(kFull, 0, 0, v0);
             load(kFull, 0, ahead(0, 1), v1);
             for (; i + 2 < n_full; i += 3) {

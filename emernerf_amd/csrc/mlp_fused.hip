@@ -615,15 +615,7 @@ __device__ __forceinline__ void dw_blocks(f32x16 (&acc)[NQ], const SwP &a, const
 #undef EMER_DWB
 }
 
-// [r5 experiment, off] encodings of 33-64 features (KT0 >= 3: the dynamic / flow necks on the 40-feature xyzt encoding) need more than the
-// 256 registers two waves per SIMD leave (hipcc spills 26-73 dwords per lane).  EMER_NECKW_WPS1_KT = 3 runs those instantiations with 4
-// waves per workgroup = one per SIMD and 512 registers (348 used, no scratch), as rgb_bwdw16_kernel does.  Same-session A/B: flow step at
-// 2048 rays 0.451 vs 0.450 ms of neck backward, dynamic step at 8192 rays 0.818 vs 0.784 ms -- the second wave hides more than the
-// spills cost.  Default 5 = never.
-#ifndef EMER_NECKW_WPS1_KT
-#define EMER_NECKW_WPS1_KT 5
-#endif
-constexpr int neckw_threads(int kt0, int no = 1) { return (no == 2 || kt0 >= EMER_NECKW_WPS1_KT) ? 256 : 512; }
+constexpr int neckw_threads(int kt0, int no = 1) { return no == 2 ? 256 : 512; }
 // (512 threads = 8 waves, ONE workgroup per CU = 2 waves per SIMD, <= 256 registers; the weights, 48-72 KB, are staged once per CU and
 // leave room for 7-10 KB of per-wave staging)
 
@@ -1189,17 +1181,14 @@ __global__ __launch_bounds__(kNThreads, 4) void rgb_bwd_kernel(const RgbBwdArgs 
 // launches: 1.9 of the step's 8.4 GB).  What made this "not feasible" at four waves per SIMD is the accumulator count -- 48 tiles of
 // 16 x 16 = 192 registers -- so the kernel runs ONE wave per SIMD (256-lane workgroups, one per CU, up to 512 registers per lane) and
 // does by hand what the other waves of a SIMD do for the four-wave kernels:
-//   * inputs of the next tile are in flight while this one is in the matrix pipe: a2 / a1 go global -> LDS directly
-//     (global_load_lds_dwordx4, lane-major staging as in neck_bwdw_kernel), geo rides in registers;
-//   * four output tiles are interleaved in every chain GEMM (tgemm4), so that consecutive matrix instructions never wait for their own
-//     accumulator; the 48 dW accumulators are independent by construction;
-//   * rows come onto the reduction index through the matrix core (to_rows), and TWO 16-row tiles are paired per dW step: the K = 32
-//     instruction's reduction index enumerates (tile 0: rows 4 g .. 4 g + 3 | tile 1: rows 4 g .. 4 g + 3) on lane group g -- any
-//     bijection of k is a valid GEMM as long as both operands use it -- so an operand is the concatenation of the two tiles' transposer
-//     outputs and the legacy K = 16 instruction (same issue cost, half the work) is not needed.  Tile 0's B operands (a1, geo) wait in
-//     12 KB of wave-private LDS while tile 1 runs through the chain.
-// Per 16 rows: 148 chain + 48 transposer + 144 dW instructions (rgb_bwd_kernel: 148, plus two streaming launches over 1.4 GB).
-// Requires an even number of tiles per ray (S % 32 == 0); other shapes stay on rgb_bwd_kernel + the streamed weight gradients.
+//   * every input of the next tile is in flight while this one is in the matrix pipe: global -> LDS directly (global_load_lds_dwordx4,
+//     lane-major staging as in neck_bwdw_kernel), no register holds a prefetched value;
+//   * the chain GEMMs run as stages of twelve matrix instructions on two accumulators whose weight fragments were read one stage ahead
+//     (Frag6); the dW accumulators are independent by construction;
+//   * rows come onto the reduction index through the matrix core (to_rows) for what the chain produced (dpre1, dpre0) and by transposed
+//     LDS reads for the staged inputs (a1, geo); two 16-feature tiles make one operand of a 32 x 32 x 16 product (block32).
+// (A variant that paired two row tiles per dW step on the K = 32 form of the 16 x 16 instruction spilled 33 accumulator moves per tile and
+// ran at 0.57 ms against 0.37: deleted in round 6, the record is DESIGN.md 4.3 [r4] and profiles/r04_ab_step.txt.)
 constexpr int kRWThreads = 256;
 
 struct RgbBwdWArgs {
@@ -1213,63 +1202,6 @@ struct RgbBwdWArgs {
     float *partials; int64_t stride;    // per workgroup: dW1 [64][128] (columns: a1 0..63 | geo 64..127) | dW0 [64][64] (geo) | dW2 [3][64] | db2 [3] | pad
 };
 
-__device__ __forceinline__ SwP pair_rows(const SwT &t0, const SwT &t1) {
-    return SwP{u32x4{t0.h[0], t0.h[1], t1.h[0], t1.h[1]}, u32x4{t0.m[0], t0.m[1], t1.m[0], t1.m[1]}, u32x4{t0.l[0], t0.l[1], t1.l[0], t1.l[1]}};
-}
-
-// acc[p] += W[16 p ..][:] . in for FOUR output tiles at once, the four accumulators interleaved term by term
-template <int KS>
-__device__ __forceinline__ void tgemm4(const W3 w, const Opd<KS> &b, f32x4 (&acc)[4]) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        u32x4 fh[4], fm[4], fl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const u32x4 *f = w.p + (p * w.ks + s) * 64;
-            fl[p] = f[2 * w.plane]; fh[p] = f[0]; fm[p] = f[w.plane];
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fl[p], b.h[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.l[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.m[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.h[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.m[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.h[s], acc[p]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// The same without scheduling barriers (one fragment set per k-step): for sections whose instruction mix is laid out with
-// sched_group_barrier pipelines (EMER_PIPE) instead
-template <int KS>
-__device__ __forceinline__ void tgemm4_free(const W3 w, const Opd<KS> &b, f32x4 (&acc)[4]) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        u32x4 fh[4], fm[4], fl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const u32x4 *f = w.p + (p * w.ks + s) * 64;
-            fl[p] = f[2 * w.plane]; fh[p] = f[0]; fm[p] = f[w.plane];
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fl[p], b.h[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.l[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.m[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fm[p], b.h[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.m[s], acc[p]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[p] = EMER_MF(fh[p], b.h[s], acc[p]);
-    }
-}
 // One software-pipeline stage of a chain GEMM for the one-wave kernels: the A fragments of two output tiles at one k-step (six
 // ds_read_b128), loaded ONE STAGE AHEAD of the twelve matrix instructions that use them -- with a single wave per SIMD nothing else
 // covers the LDS latency of a read issued right in front of its use (measured: ~2500 of 14000 cycles per tile sat in s_waitcnt).
@@ -1290,278 +1222,15 @@ __device__ __forceinline__ void mma_frag6(const Frag6 &f, const Opd<KS> &b, int 
     a0 = EMER_MF(f.h[0], b.m[s], a0); a1 = EMER_MF(f.h[1], b.m[s], a1);
     a0 = EMER_MF(f.h[0], b.h[s], a0); a1 = EMER_MF(f.h[1], b.h[s], a1);
 }
-// N times { NM matrix instructions, NV vector instructions }: the instruction mix of a section, for the scheduler (it may only pick
-// instructions whose operands are ready, so a pattern that asks for more of a kind than the section holds just ends early)
-#ifdef EMER_USE_PIPE
-#define EMER_PIPE(N, NM, NV)                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) {          \
-        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);       \
-        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);       \
-    }
-#else
-#define EMER_PIPE(N, NM, NV)
-#endif
 
-// acc[p][b0 + i] += A[p]^T B[i] over the 32 paired rows, NB B tiles at a time: 4 NB independent accumulators per term
-template <int NB, int NBT>
-__device__ __forceinline__ void dw_pairs(f32x4 (&acc)[4][NBT], int b0, const SwP (&a)[4], const SwP (&b)[NB]) {
-#define EMER_DWP(X, Y)                                                                                   \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                        \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) acc[p][b0 + i] = EMER_MF(a[p].X, b[i].Y, acc[p][b0 + i]);
-    EMER_DWP(l, h) EMER_DWP(h, l) EMER_DWP(m, m) EMER_DWP(m, h) EMER_DWP(h, m) EMER_DWP(h, h)
-#undef EMER_DWP
-}
-
-// Sum the four waves' weight-gradient accumulators through LDS (the weights are dead) and write one coalesced partial per workgroup.
-__device__ __forceinline__ void rgb_bwdw_epilogue(const RgbBwdWArgs &a, f32x4 (&acc1)[4][8], f32x4 (&acc0)[4][4], float (&w2acc)[3], float b2acc,
-                                                  int wave, int m, int g) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last prefetch targets the staging buffers, not the reduction area; drain it anyway
-    __syncthreads();
-    constexpr int P1 = 132, P0 = 68;   // row pitches (floats): the four lane groups of a store hit different banks
-    float *r1 = reinterpret_cast<float *>(smem), *r0 = r1 + 64 * P1, *r2 = r0 + 64 * P0;   // dW1 [64][P1] | dW0 [64][P0] | 4 x 196
-    for (int w = 0; w < kRWThreads / 64; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float *q = r1 + (16 * p + 4 * g + r) * P1 + 16 * b + m;
-                        *q = (w == 0) ? acc1[p][b][r] : *q + acc1[p][b][r];
-                    }
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float *q = r0 + (16 * p + 4 * g + r) * P0 + 16 * b + m;
-                        *q = (w == 0) ? acc0[p][b][r] : *q + acc0[p][b][r];
-                    }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r2[wave * 196 + c * 64 + 16 * (m >> 2) + 4 * g + (m & 3)] = w2acc[c];
-    b2acc = row16_sum(b2acc);
-    if (m == 0 && g < 3) r2[wave * 196 + 192 + g] = b2acc;
-    __syncthreads();
-    float *part = a.partials + (int64_t)blockIdx.x * a.stride;
-    for (int i = threadIdx.x; i < 64 * 128; i += kRWThreads) part[i] = r1[(i >> 7) * P1 + (i & 127)];
-    for (int i = threadIdx.x; i < 64 * 64; i += kRWThreads) part[64 * 128 + i] = r0[(i >> 6) * P0 + (i & 63)];
-    if ((int)threadIdx.x < 195) {
-        float t = 0.0f;
-        for (int w = 0; w < kRWThreads / 64; ++w) t += r2[w * 196 + threadIdx.x];
-        part[64 * 128 + 64 * 64 + threadIdx.x] = t;
-    }
-}
-
-#ifndef EMER_RGBW_TG4
-#define EMER_RGBW_TG4 0
-#endif
-#ifndef EMER_RGBW_TGPAIR
-#define EMER_RGBW_TGPAIR true
-#endif
-#if EMER_RGBW_TG4
-#define EMER_TG(W, B, ACC) tgemm4<2>(W, B, ACC)
-#else
-#define EMER_TG(W, B, ACC) tgemm<2, 4, EMER_RGBW_TGPAIR>(W, B, ACC)
-#endif
-__global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw_kernel(const RgbBwdWArgs a) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-    u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
-    stage_w3(w1al, 4, 2, a.w1at);
-    stage_w3(w1gl, 4, 2, a.w1gt);
-    stage_w3(w0l, 4, 2, a.w0gt);
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
-    const W3 w1ap = w3_at(w1al, 4, 2, lane), w1gp = w3_at(w1gl, 4, 2, lane), w0p = w3_at(w0l, 4, 2, lane);
-    const SelE sel = make_sel(lane);
-    float w2a[4];   // W2^T (64 x 3) in four registers, as in rgb_bwd_kernel
-#pragma unroll
-    for (int p = 0; p < 4; ++p) w2a[p] = (g < a.w2t.k && 16 * p + m < a.w2t.n) ? a.w2t.w[(16 * p + m) * a.w2t.sn + g * a.w2t.sk] : 0.0f;
-    // per wave: staging of the next tile's a2 | a1 (2 x 4 KB, lane-major) and the parked B operands of a pair's first tile (12 KB)
-    float *stg = reinterpret_cast<float *>(w0l + w3_units(4, 2)) + wave * (2048 + 3072);
-    u32x2 *park = reinterpret_cast<u32x2 *>(stg + 2048) + lane;   // entry (3 b + term) at park[(3 b + term) * 64]
-    using gptr = const __attribute__((address_space(1))) void *;
-    using lptr = __attribute__((address_space(3))) void *;
-
-    f32x4 acc1[4][8], acc0[4][4];   // dW1 [64][128], dW0 [64][64] as 16 x 16 tiles: lane (j, g), register r = dW[16 p + 4 g + r][16 b + j]
-#pragma unroll
-    for (int p = 0; p < 4; ++p) { zero<8>(acc1[p]); zero<4>(acc0[p]); }
-    float w2acc[3] = {0.0f, 0.0f, 0.0f}, b2acc = 0.0f;
-
-    const int tpr = a.tiles_per_ray;
-    const int64_t wave_id = (int64_t)blockIdx.x * (kRWThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kRWThreads / 64);
-    const unsigned lo64 = (unsigned)(m * 64 + 4 * g), log = (unsigned)m * (unsigned)a.ld_geo + 4u * g;
-    f32x4 gn[4];   // the next tile's geo rows (registers: needed only at the end of a tile)
-    float yn = 0.0f, dn = 0.0f;   // ... and its sigmoid output / incoming gradient entry (lane (m, g): channel min(g, 2) of row m)
-    const unsigned lo3c = (unsigned)(3 * m + (g < 3 ? g : 2));
-    // tile sequence of this wave: (ray, j) -> (ray, j + 1) ... -> (ray + n_waves, 0); loads are unconditional (past the end the last tile is
-    // read again) and go out right after the previous tile's staging buffer has been read
-    auto issue = [&](int64_t ray, int j) {
-        const int64_t row0 = (ray * tpr + j) * 16;
-        const float *p2 = a.a2 + row0 * 64, *p1 = a.a1 + row0 * 64, *pg = a.geo + row0 * a.ld_geo;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p2 + (lo64 + 16u * p)), (lptr)(stg + 256 * p), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((gptr)(p1 + (lo64 + 16u * p)), (lptr)(stg + 1024 + 256 * p), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) gn[p] = *reinterpret_cast<const f32x4 *>(pg + (log + 16u * p));
-        yn = (a.out + row0 * 3)[lo3c];
-        dn = (a.dout + row0 * 3)[lo3c];
-    };
-    if (wave_id < a.n_rays) issue(wave_id, 0);
-    for (int64_t ray = wave_id; ray < a.n_rays; ray += n_waves) {
-        // per-ray sums of dpre1 / dpre0 ride on the transposer (its fp32 output, summed over the lane's four rows): lane (j, g) holds the
-        // partial of feature 16 p + j over rows 4 g .. 4 g + 3 of every tile of the ray
-        float s1c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s0c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int jp = 0; jp < tpr; jp += 2) {
-            SwT A1t[4], A0t[4];   // first tile of the pair: transposed dpre1 / dpre0 (registers); its a1 / geo operands wait in LDS
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int j = jp + half;
-                float *dgeo = a.dgeo + ((ray * tpr + j) * 16) * 64;
-                // ---- this tile's inputs (issued one tile ago); then the next tile's go out
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                f32x4 m2[4], m1[4], x[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    m2[p] = *reinterpret_cast<const f32x4 *>(stg + 256 * p + 4 * lane);
-                    m1[p] = *reinterpret_cast<const f32x4 *>(stg + 1024 + 256 * p + 4 * lane);
-                    x[p] = gn[p];
-                }
-                const float d2 = g < 3 ? dn * yn * (1.0f - yn) : 0.0f;   // sigmoid'; lane (m, g): channel g of row m
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging buffer has been read: it may be overwritten
-                {
-                    int64_t nr = ray; int nj = j + 1;
-                    if (nj == tpr) { nj = 0; nr = ray + n_waves; }
-                    if (nr >= a.n_rays) { nr = ray; nj = j; }
-                    issue(nr, nj);
-                }
-                // ---- a1 (0..3) and geo (4..7) tiles with the rows on the reduction index (B operands of the dW products).  First tile of a
-                // pair: now, straight into LDS (nothing else is live yet); second tile: after its chain, when the chain's registers are free
-                if (half == 0) {
-                    Opd<2> bo;
-                    make_opd<4>(m1, bo);
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { const SwT t = to_rows<2>(bo, p, sel); park[(3 * p + 0) * 64] = t.h; park[(3 * p + 1) * 64] = t.m; park[(3 * p + 2) * 64] = t.l; if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                    make_opd<4>(x, bo);
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { const SwT t = to_rows<2>(bo, p, sel); park[(3 * (4 + p) + 0) * 64] = t.h; park[(3 * (4 + p) + 1) * 64] = t.m; park[(3 * (4 + p) + 2) * 64] = t.l; if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // ---- the data-gradient chain (rgb_bwd_kernel's), four output tiles interleaved
-                b2acc += d2;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float dc = __shfl(d2, 16 * c + m, 64);
-                    w2acc[c] += row16_reduce_scatter(m2, dc, m);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                Opd<2> d1o, d0o;
-                {
-                    f32x4 d1[4];
-                    zero<4>(d1);
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) d1[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[p], d2, d1[p], 0, 0, 0);
-                    relu_mask<4>(d1, m2);
-                    make_opd<4>(d1, d1o);
-                }
-                // B operands of the pair for one group of four tiles (bg 0: a1, bg 1: geo): tile 0's half from LDS, tile 1's through the transposer
-                // (two tiles at a time: tiles 2 h, 2 h + 1 of the group are k-step h of the group's split operand)
-                auto pair_b = [&](int bg, int h, SwP (&Bp)[2]) {
-                    f32x4 v[2];
-                    v[0] = bg == 0 ? m1[2 * h] : x[2 * h]; v[1] = bg == 0 ? m1[2 * h + 1] : x[2 * h + 1];
-                    Opd<1> bo;
-                    make_opd<2>(v, bo);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int b = 4 * bg + 2 * h + i;
-                        SwT t0;
-                        t0.h = park[(3 * b + 0) * 64]; t0.m = park[(3 * b + 1) * 64]; t0.l = park[(3 * b + 2) * 64];
-                        Bp[i] = pair_rows(t0, to_rows<1>(bo, i, sel));
-                    }
-                };
-                if (half == 0) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { A1t[p] = to_rows<2>(d1o, p, sel, &s1c[p]); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                } else {
-                    // ---- dW1 += (dpre1 of both tiles)^T [a1 | geo] of both tiles: 32 output tiles x six K = 32 products, sixteen independent
-                    // accumulators per term.  Done HERE, before the rest of the chain: the first tile's dpre1 operands die early
-                    SwP Ap[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { Ap[p] = pair_rows(A1t[p], to_rows<2>(d1o, p, sel, &s1c[p])); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int bh = 0; bh < 4; ++bh) {
-                        SwP Bp[2];
-                        pair_b(bh >> 1, bh & 1, Bp);
-                        __builtin_amdgcn_sched_barrier(0);
-                        dw_pairs<2, 8>(acc1, 2 * bh, Ap, Bp);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                {
-                    f32x4 d0[4];
-                    zero<4>(d0);
-                    EMER_TG(w1ap, d1o, d0);
-                    relu_mask<4>(d0, m1);
-                    make_opd<4>(d0, d0o);
-                }
-                {
-                    f32x4 dg[4];
-                    zero<4>(dg);
-                    EMER_TG(w1gp, d1o, dg);
-                    EMER_TG(w0p, d0o, dg);
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(dgeo + (lo64 + 16u * p)) = dg[p];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (half == 0) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { A0t[p] = to_rows<2>(d0o, p, sel, &s0c[p]); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                } else {
-                    // ---- dW0 += (dpre0 of both tiles)^T geo of both tiles
-                    SwP Ap[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) { Ap[p] = pair_rows(A0t[p], to_rows<2>(d0o, p, sel, &s0c[p])); if (p & 1) __builtin_amdgcn_sched_barrier(0); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        SwP Bp[2];
-                        pair_b(1, h, Bp);
-                        __builtin_amdgcn_sched_barrier(0);
-                        dw_pairs<2, 4>(acc0, 2 * h, Ap, Bp);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            s1c[p] += __shfl_xor(s1c[p], 16, 64); s1c[p] += __shfl_xor(s1c[p], 32, 64);
-            s0c[p] += __shfl_xor(s0c[p], 16, 64); s0c[p] += __shfl_xor(s0c[p], 32, 64);
-            if (g == 0) { a.s1[ray * 64 + 16 * p + m] = s1c[p]; a.s0[ray * 64 + 16 * p + m] = s0c[p]; }
-        }
-    }
-    rgb_bwdw_epilogue(a, acc1, acc0, w2acc, b2acc, wave, m, g);
-}
-
-// The same backward one 16-row tile at a time (no state carried between tiles, no parked operands, half the live registers), with the dW
+// One 16-row tile at a time (no state carried between tiles), with the dW
 // products on v_mfma_f32_32x32x16_bf16: its reduction index is 16 long -- one row tile -- and one instruction covers a 32 x 32 block of
 // dW (four of the 16 x 16 tiles) in 32.5 cycles, where four K = 16 instructions of the 16 x 16 shape cost 79.  The operand of a 32-feature
 // block -- lane (i, kg): feature i of the block, eight rows -- is two transposer outputs (lane (j, g): rows 4 g .. 4 g + 3 of feature j)
 // after ONE v_permlane16_swap_b32 per register: lanes 16-31 / 48-63 take the second tile's rows 0-3 / 8-11 from lanes 0-15 / 32-47 and
 // give the first tile's rows 4-7 / 12-15 back, which leaves lane (i, kg) with rows 8 kg .. 8 kg + 7 of its feature.
 // Per tile: 148 chain + 48 transposer (16 x 16 x 32) + 72 dW (32 x 32 x 16) instructions.  Any S % 16 == 0.
-#ifndef EMER_RGBW_NOSB
-#define EMER_RGBW_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define EMER_RGBW_SB()
-#endif
+#define EMER_RGBW_SB() __builtin_amdgcn_sched_barrier(0)   // pins the order of the stages of the one-wave kernels; inside a stage the scheduler is free
 __global__ __launch_bounds__(kRWThreads, 1) void rgb_bwdw16_kernel(const RgbBwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
     u32x4 *w1al = smem, *w1gl = w1al + w3_units(4, 2), *w0l = w1gl + w3_units(4, 2);
@@ -3125,7 +2794,7 @@ extern "C" int64_t emer_rgb_head_bwd_fused_workspace(int64_t n_rays, int32_t sam
 extern "C" int emer_rgb_head_bwd_fused(const float *dout, const float *out, const float *a1, const float *a2, const float *geo, int64_t ld_geo,
                                        int64_t n_rays, int32_t samples_per_ray, int32_t kh, const float *w0, const float *w1, const float *w2,
                                        float *dgeo, float *s1, float *s0, float *workspace, float *dw0, int64_t ld_dw0, float *dw1,
-                                       int64_t ld_dw1, float *dw2, int64_t ld_dw2, float *db2, int32_t pair_tiles, void *stream) {
+                                       int64_t ld_dw1, float *dw2, int64_t ld_dw2, float *db2, void *stream) {
     EMER_REQUIRE(n_rays >= 0 && kh >= 0, "rgb_head_bwd_fused: bad sizes");
     if (n_rays == 0) return EMER_OK;
     EMER_REQUIRE(emer_rgb_head_bwd_fused_supported(samples_per_ray), "rgb_head_bwd_fused: samples_per_ray must be a multiple of 16 (got %d)", samples_per_ray);
@@ -3144,15 +2813,8 @@ extern "C" int emer_rgb_head_bwd_fused(const float *dout, const float *out, cons
     const size_t lds = (size_t)(3 * w3_units(4, 2)) * 16 + (size_t)(kRWThreads / 64) * (2048 + 3072) * sizeof(float);
     hipStream_t st = as_stream(stream);
     const uint32_t grid = rgb_bwdw_grid(n_rays);
-    // pair_tiles: two row tiles per weight-gradient step (K = 32 products, 340 instead of 484 matrix instructions per tile; needs an even
-    // number of tiles per ray and more registers than the compiler currently fits without spilling a few accumulators) / one tile per step
-    if (pair_tiles && samples_per_ray % 32 == 0) {
-        if (int rc = set_lds(rgb_bwdw_kernel, lds, "rgb_head_bwd_fused")) return rc;
-        hipLaunchKernelGGL(rgb_bwdw_kernel, dim3(grid), dim3(kRWThreads), lds, st, a);
-    } else {
-        if (int rc = set_lds(rgb_bwdw16_kernel, lds, "rgb_head_bwd_fused")) return rc;
-        hipLaunchKernelGGL(rgb_bwdw16_kernel, dim3(grid), dim3(kRWThreads), lds, st, a);
-    }
+    if (int rc = set_lds(rgb_bwdw16_kernel, lds, "rgb_head_bwd_fused")) return rc;
+    hipLaunchKernelGGL(rgb_bwdw16_kernel, dim3(grid), dim3(kRWThreads), lds, st, a);
     if (int rc = check_launch("rgb_head_bwd_fused")) return rc;
     // the workgroups' partials -> the parameters' gradients (+=): dW1's two column blocks land 0.. and 64 + kh.., dW0's at kh..
     // (one launch for the three)

@@ -56,14 +56,9 @@ class RayWgradJob(ctypes.Structure):
                 ("dbias", c_void_p), ("n", c_int32), ("n_segs", c_int32), ("width", c_int32 * 2), ("dst_col", c_int32 * 2)]
 
 
-def ray_wgrad(jobs, ref: Tensor, aux: bool = False) -> None:
+def ray_wgrad(jobs, ref: Tensor) -> None:
     """Weight gradients of per-ray layers in ONE launch.  jobs: [(dy [M, n], [(x [M, >= width], width, dst_col), ...], dw, dbias | None)]
-    -- dw[:, dst_col : dst_col + width] += dy^T x and dbias += colsum(dy), accumulated into the given tensors.  ``aux``: every target is a
-    gradient sink of the trainer (nobody reads it before ``join_side_stream``), so the launch may leave the critical path (``on_aux``)."""
-    if aux:
-        with on_aux(ref.device, [t for dy, blocks, dw, db in jobs for t in (dy, *[b[0] for b in blocks])]) as go:
-            if go:
-                return ray_wgrad(jobs, ref)
+    -- dw[:, dst_col : dst_col + width] += dy^T x and dbias += colsum(dy), accumulated into the given tensors."""
     arr = (RayWgradJob * len(jobs))()
     M = jobs[0][0].shape[0]
     for a, (dy, blocks, dw, db) in zip(arr, jobs):
@@ -216,49 +211,13 @@ def rgb_recompute(n_rays: int, samples_per_ray: int) -> int:
     0 none, 1 a1 and a2, 2 a2 only."""
     ok = FUSED_WGRAD and FUSED_RGB_WGRAD and _lib.load().emer_rgb_head_bwd_fused_workspace(n_rays, samples_per_ray) > 0
     return int(RGB_RECOMPUTE) if ok else 0
-RGB_WGRAD_PAIR = os.environ.get("EMER_RGBW_PAIR", "0") == "1"         # its variant that pairs two row tiles per weight-gradient step
 SIDE_STREAM = None  # a torch.cuda.Stream: set by a trainer that joins it before reading gradients (see wgrad)
-
-
-# [r5] Small launches that only produce WEIGHT gradients of per-ray layers (two emer_ray_wgrad launches and the embedding gradient: 60 us
-# of an eager static step) sit on the critical path of the data-gradient chain although nothing reads their results before Adam.  With
-# the trainer's gradient sinks on (it joins before the exchange / the optimizer) they are enqueued on an auxiliary stream behind what
-# the current stream holds so far, and run under the long kernels that follow (under hipGraph capture: a parallel branch of the graph).
-# Measured [r5, same session, static step]: eager launches 2.440 -> 2.428 ms, but the hipGraph replay -- the default launch mode -- gets
-# SLOWER, 2.369 -> 2.420 ms (a graph with a second branch loses more in its replay than the 60 us it hides), flow step at 2048 rays 5.67
-# -> 5.74 ms.  Off by default; EMER_AUX_WGRAD=1 turns it on.
-AUX_WGRAD = os.environ.get("EMER_AUX_WGRAD", "0") == "1"
-_AUX_STREAMS: dict = {}
-_AUX_PENDING: list = []   # [(stream, tensors kept alive until the join)]
-
-
-@contextlib.contextmanager
-def on_aux(dev, tensors):
-    """``with on_aux(dev, inputs) as go:`` -- when ``go`` is true the body's launches go to the auxiliary stream, ordered behind the current
-    stream; the inputs stay referenced until ``join_side_stream``.  False (body runs on the current stream) unless the gradient sinks
-    are on right now: only then is somebody committed to join before the results are read."""
-    if not (AUX_WGRAD and _USE_GRAD_SINKS):
-        yield False
-        return
-    dev = torch.device(dev)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _AUX_STREAMS.get(key)
-    if st is None:
-        st = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
-    st.wait_stream(torch.cuda.current_stream(dev))
-    _AUX_PENDING.append((st, list(tensors)))
-    with torch.cuda.stream(st):
-        yield True
 
 
 def join_side_stream() -> None:
     """Make the current stream wait for the weight-gradient side streams (no-op when unused)."""
     if SIDE_STREAM is not None:
         torch.cuda.current_stream().wait_stream(SIDE_STREAM)
-    if _AUX_PENDING:
-        for st in {id(s): s for s, _ in _AUX_PENDING}.values():
-            torch.cuda.current_stream(st.device).wait_stream(st)
-        _AUX_PENDING.clear()
 
 
 def _sink(p) -> Optional[Tensor]:
@@ -676,9 +635,8 @@ class _RgbHeadFn(torch.autograd.Function):
                                   tw2.stride(0), _p(tb2), _stream(g))
                     else:
                         _lib.call("emer_rgb_head_bwd_fused", _p(_c(dout)), _p(out), _p(a1), _p(a2), _p(g), g.stride(0), R, S, Kh, _p(W0), _p(W1), _p(W2),
-                                  _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2), tw2.stride(0), _p(tb2),
-                                  1 if RGB_WGRAD_PAIR else 0, _stream(g))
-                ray_wgrad([(s1, [(hr, Kh, H)], tw1, tb1), (s0, [(hr, Kh, 0)], tw0, tb0)], g, aux=all(r is None for r in (rw0, rb0, rw1, rb1)))
+                                  _p(dgeo), _p(s1), _p(s0), _p(ws), _p(tw0), tw0.stride(0), _p(tw1), tw1.stride(0), _p(tw2), tw2.stride(0), _p(tb2), _stream(g))
+                ray_wgrad([(s1, [(hr, Kh, H)], tw1, tb1), (s0, [(hr, Kh, 0)], tw0, tb0)], g)
                 dhray = torch.empty((R, Kh), device=dev, dtype=torch.float32)
                 with torch.cuda.device(dev):
                     _lib.call("emer_ray_pre_bwd", _p(s0), _p(s1), H, R, Kh, H, _p(W0), W0.stride(0), _p(W1[:, H:]), W1.stride(0), _p(dhray), Kh,
@@ -780,13 +738,8 @@ class _RayInputsFn(torch.autograd.Function):
         (ga, lda), (gb, ldb) = cols(g_rgb), cols(g_sky)
         tw, rw = _target(ctx.sink, ctx.shape, dev)
         with torch.cuda.device(dev):
-            if rw is None:   # accumulated into the trainer's buffer: off the critical path (see on_aux)
-                with on_aux(dev, [t for t in (ga, gb, idx) if t is not None]):
-                    _lib.call("emer_embed_grad", _p(ga), lda, _p(gb), ldb, _p(idx), idx.stride(0), idx.shape[0], ctx.shape[0], ctx.shape[1],
-                              _p(tw), _stream(idx))
-            else:
-                _lib.call("emer_embed_grad", _p(ga), lda, _p(gb), ldb, _p(idx), idx.stride(0), idx.shape[0], ctx.shape[0], ctx.shape[1],
-                          _p(tw), _stream(idx))
+            _lib.call("emer_embed_grad", _p(ga), lda, _p(gb), ldb, _p(idx), idx.stride(0), idx.shape[0], ctx.shape[0], ctx.shape[1],
+                      _p(tw), _stream(idx))
         return rw, None, None, None
 
 
@@ -873,8 +826,7 @@ class _SkipMLP3Fn(torch.autograd.Function):
         tw0, rw0 = _target(sw0, (H, K0), dev)
         tb0, rb0 = _target(sb0, (H,), dev)
         if ctx.fast and N <= 65536:  # per-ray head: all three layers in one launch
-            ray_wgrad([(dpre2, [(a2, H, 0)], tw2, tb2), (dpre1, [(a1, H, 0), (X, K0, H)], tw1, tb1), (dpre0, [(X, K0, 0)], tw0, tb0)], X,
-                      aux=all(r is None for r in (rw0, rb0, rw1, rb1, rw2, rb2)))
+            ray_wgrad([(dpre2, [(a2, H, 0)], tw2, tb2), (dpre1, [(a1, H, 0), (X, K0, H)], tw1, tb1), (dpre0, [(X, K0, 0)], tw0, tb0)], X)
         else:
             wgrad(dpre2, [seg(a2, 0, H)], H, out_w=tw2, out_b=tb2)
             wgrad(dpre1, [seg(a1, 0, H), seg(X, H, K0)], H + K0, out_w=tw1, out_b=tb1)

@@ -114,29 +114,6 @@ def _jac_fits(desc, rows: int) -> bool:
     return GRID_JAC_MAX_BYTES <= 0 or rows * desc.n_levels * desc.n_features * desc.n_dims * 4 <= GRID_JAC_MAX_BYTES
 
 
-def prop_density_supported(desc: GridDesc, hidden: int, n_out: int) -> bool:
-    return bool(_lib.load().emer_prop_density_supported(ctypes.byref(desc), int(hidden), int(n_out)))
-
-
-def prop_density(desc: GridDesc, params: Tensor, origins: Tensor, viewdirs: Tensor, t_starts: Tensor, t_ends: Tensor, aabb: Tensor,
-                 unbounded: bool, w0: Tensor, b0: Optional[Tensor], w1: Tensor, b1: Optional[Tensor]) -> Tensor:
-    """Density [R, S] of a proposal network at the interval midpoints, no autograd (emer_prop_density_fwd)."""
-    _check_cuda(params, origins, viewdirs, t_starts, t_ends, w0, w1)
-    o, d, ts, te = _f32c(origins), _f32c(viewdirs), _f32c(t_starts), _f32c(t_ends)
-    R, S = ts.shape
-    bb = _f32c(aabb).reshape(-1)
-    W0, W1 = _f32c(w0), _f32c(w1).reshape(-1)
-    B0 = None if b0 is None else _f32c(b0)
-    B1 = None if b1 is None else _f32c(b1)
-    pc = params.detach().contiguous()
-    assert o.shape == (R, 3) and d.shape == (R, 3) and W0.shape == (64, desc.n_levels * desc.n_features) and W1.numel() == 64
-    with torch.cuda.device(ts.device):
-        out = torch.empty((R, S), device=ts.device, dtype=torch.float32)
-        _lib.call("emer_prop_density_fwd", ctypes.byref(desc), _ptr(pc), _ptr(o), _ptr(d), _ptr(ts), _ptr(te), _ptr(bb), int(bool(unbounded)),
-                  _ptr(W0), _ptr(B0), _ptr(W1), _ptr(B1), R, S, _ptr(out), _stream(ts))
-    return out
-
-
 def slice_masks(desc: GridDesc, x: Tensor) -> Tensor:
     _check_cuda(x)
     with torch.cuda.device(x.device):

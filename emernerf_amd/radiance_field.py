@@ -127,11 +127,6 @@ class MLP(nn.Module):
 
 FUSE_FLOW_WARP = True  # ... and build its warped xyzt query points (and their gradient) in one launch each way (ops.flow_warp) [r4]
 BATCH_XYZT = True  # flow configs: evaluate each xyzt table once per dependency level (RadianceField._flow_branch_batched)
-# [r4 experiment, off] proposal rounds outside autograd as one launch per round (emer_prop_density_fwd: positions + encode + MLP, bitwise
-# the separate kernels' densities).  Measured (profiles/r04_prop_fusion.txt): 86 vs 95 us and 79 vs 82 us per round in isolation, but the
-# full step is 15-30 us SLOWER with it (2.385-2.390 vs 2.340-2.378 ms, same session): the level-major encode + the 20-us MLP launch is
-# already what the gathers cost, and a thread that walks all eight levels holds fewer gathers in flight.  EMER_FUSE_PROP_DENSITY=1 enables it.
-FUSE_PROP_DENSITY = os.environ.get("EMER_FUSE_PROP_DENSITY", "0") == "1"
 FUSE_FIELD = os.environ.get("EMER_FUSE_FIELD", "1") != "0"   # neck + rgb head of the static model as one forward launch (fused.RgbRider); 0: two launches
 
 
@@ -830,19 +825,6 @@ class DensityField(nn.Module):
         lin0, lin1 = self.base_mlp[0], self.base_mlp[2]
         d = fused.density_mlp(enc_lm, lin0.weight, lin0.bias, lin1.weight, lin1.bias)  # grid -> 64 -> 1 -> trunc_exp, one chain
         return d.view(*normed.shape[:-1], 1)
-
-    def density_from_rays(self, origins: Tensor, viewdirs: Tensor, t_starts: Tensor, t_ends: Tensor) -> Optional[Tensor]:
-        """[r4] density [R, S, 1] at the interval midpoints of rays (origins, viewdirs) [R, 3] OUTSIDE autograd recording: sample positions,
-        contraction, encoding and the density MLP in one launch (emer_prop_density_fwd).  None when the fused kernel does not apply (grad
-        mode on, CPU tensors, fp16 tables, another stack shape): the caller then takes ray_points -> density_from_normed."""
-        enc = self.xyz_encoder.tcnn_encoding
-        lin0, lin1 = self.base_mlp[0], self.base_mlp[2]
-        if (torch.is_grad_enabled() or not FUSE_PROP_DENSITY or not t_starts.is_cuda or enc.params.dtype != torch.float32
-                or getattr(enc, "dtype", torch.float32) != torch.float32 or t_starts.dim() != 2
-                or not ops.prop_density_supported(enc.desc, lin0.out_features, lin1.out_features)):
-            return None
-        return ops.prop_density(enc.desc, enc.params, origins, viewdirs, t_starts, t_ends, self.aabb, self.unbounded, lin0.weight, lin0.bias,
-                                lin1.weight, lin1.bias).unsqueeze(-1)
 
     def forward(self, positions: Tensor, data_dict: Dict[str, Tensor] = None) -> Dict[str, Tensor]:
         normed = ops.contract_points(positions, self.aabb.reshape(-1), self.unbounded)

@@ -162,9 +162,6 @@ def render_rays(radiance_field: RadianceField = None, proposal_estimator: PropNe
         return {k: chunk[k][..., None].expand(*chunk[k].shape, n_samples) for k in keys if k in chunk}
 
     def prop_sigma_fn(t_starts, t_ends, proposal_network: DensityField):
-        fused_density = proposal_network.density_from_rays(chunk[prefix + "origins"], chunk[prefix + "viewdirs"], t_starts, t_ends)
-        if fused_density is not None:   # outside autograd recording: positions, encoding and MLP in one launch
-            return {"density": fused_density}
         pre = getattr(t_starts, "_emer_points", None)   # [r5] computed by the sampler's launch for exactly this network's box
         if pre is not None and pre[2] is proposal_network.aabb and pre[3] == bool(proposal_network.unbounded):
             normed = pre[0]

@@ -150,18 +150,6 @@ int emer_hashgrid_fwd_jac(const emer_grid_desc *host_desc, const float *x, const
 int emer_hashgrid_bwd_input_jac(const emer_grid_desc *host_desc, const float *jac, const float *dout,
                                 int64_t dout_stride_n, int64_t dout_stride_l, float *dx, int64_t n_rows, void *stream);
 
-/* [r4] sigma_fn of a proposal network OUTSIDE autograd recording (the proposal sampling of the steps that do not train the proposal nets,
- * evaluation) as one launch: emer_ray_points (positions o + d (t0 + t1) / 2, contraction: render_utils.py:316-318,341) ->
- * emer_hashgrid_fwd -> the DensityField MLP L*F -> 64 -> 1 and exp(. - 1) (radiance_field.py:808-812,836-840).  Positions and encoding
- * are bitwise those of the separate calls; the MLP is an fmaf chain (differs from emer_neck_fwd's matrix-core order by fp32 rounding).
- * w0 [64][L * F] row-major, b0 [64] (may be NULL), w1 [64], b1 [1] (may be NULL); density [n_rays * n_samples].
- * emer_prop_density_supported: 1 for D = 3, F in {1, 2}, at most 8 levels, hidden 64, one output. */
-int emer_prop_density_supported(const emer_grid_desc *host_desc, int32_t hidden, int32_t n_out);
-int emer_prop_density_fwd(const emer_grid_desc *host_desc, const float *params, const float *origins, const float *dirs,
-                          const float *t_starts, const float *t_ends, const float *aabb, int unbounded, const float *w0,
-                          const float *b0, const float *w1, const float *b1, int64_t n_rays, int32_t n_samples,
-                          float *density, void *stream);
-
 /* Layout glue: level-major [L][N][F] <-> row-major [N, L*F] (the layout tcnn_modules.py:263 returns).
  * to_row_major != 0: src is level-major, dst row-major; 0: the reverse.  src != dst. */
 int emer_layout_transpose(const float *src, float *dst, int32_t n_levels, int64_t n,
@@ -605,15 +593,14 @@ int emer_rgb_head_bwd(const float *dout, const float *out, const float *a1, cons
  *   dw0[:, kh : kh + 64] += dpre0^T geo                                        (dw0 [64][ld_dw0 >= 64 + kh]: layers.0.weight),
  *   dw2 [3][ld_dw2 >= 64] += dpre2^T a2,  db2 [3] += column sums of dpre2.
  * The per-ray column blocks (hray) and b0 / b1 follow from s1 / s0 (emer_ray_wgrad, emer_ray_pre_bwd).  geo [n][ld_geo] is the
- * forward's input.  samples_per_ray % 16 == 0; workspace: emer_rgb_head_bwd_fused_workspace(n_rays, samples_per_ray) floats.
- * pair_tiles != 0 (and samples_per_ray % 32 == 0): the variant that pairs two 16-row tiles per weight-gradient step. */
+ * forward's input.  samples_per_ray % 16 == 0; workspace: emer_rgb_head_bwd_fused_workspace(n_rays, samples_per_ray) floats. */
 int emer_rgb_head_bwd_fused_supported(int32_t samples_per_ray);
 int64_t emer_rgb_head_bwd_fused_workspace(int64_t n_rays, int32_t samples_per_ray);
 int emer_rgb_head_bwd_fused(const float *dout, const float *out, const float *a1, const float *a2, const float *geo,
                             int64_t ld_geo, int64_t n_rays, int32_t samples_per_ray, int32_t kh, const float *w0,
                             const float *w1, const float *w2, float *dgeo, float *s1, float *s0, float *workspace,
                             float *dw0, int64_t ld_dw0, float *dw1, int64_t ld_dw1, float *dw2, int64_t ld_dw2,
-                            float *db2, int32_t pair_tiles, void *stream);
+                            float *db2, void *stream);
 /* [r6] The same backward WITHOUT saved activations: a1 / a2 are recomputed in the kernel from geo and the per-ray pre-activations
  * rb0 / rb1 [n_rays][64] (row stride ld_rb; emer_ray_pre_fwd's output, bias included), bitwise the forward's values -- the forward
  * (emer_rgb_head_fwd / emer_field_fwd) is then called with a1 = a2 = NULL and writes 512 B / sample less, this kernel reads 512 B /

@@ -216,15 +216,15 @@ def test_hashgrid_sliced_add_accumulates(hip_lib, oracle, name):
 
 
 # ------------------------------------------------------------------------------------------ fused heads
-@pytest.mark.parametrize("rgbw", ["tile", "paired", "streamed"])
+@pytest.mark.parametrize("rgbw", ["tile", "recompute", "streamed"])
 def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):
     """neck / rgb head forward, data gradients and weight gradients at 1 048 576 rows (8192 rays x 128 samples)
     against fp64 torch evaluated on the GPU, every row and every weight gradient compared.  ``rgbw``: the rgb head's layer-0 / 1
-    weight gradients inside the backward kernel (one 16-row tile per step -- the default -- or two paired tiles per step) or as the
-    round-3 streamed passes."""
+    weight gradients inside the backward kernel (the default; "recompute": with the hidden activations recomputed there instead of
+    stored by the forward, emer_rgb_head_bwd_recompute) or as the round-3 streamed passes."""
     from emernerf_amd import fused
     monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", rgbw != "streamed")
-    monkeypatch.setattr(fused, "RGB_WGRAD_PAIR", rgbw == "paired")
+    monkeypatch.setattr(fused, "RGB_RECOMPUTE", 1 if rgbw == "recompute" else 0)
     dev = _dev()
     g = torch.Generator().manual_seed(3)
     R, S, Kh, L, Fe = 8192, 128, 49, 16, 2
@@ -251,6 +251,18 @@ def test_heads_metric_rows(hip_lib, monkeypatch, rgbw):
         geo, sem, dens = fused.neck(enc, *wn)
         rgb = fused.rgb_head(hray, geo, S, *wc)
     acts = [t for t in saved if t.shape == (N, 64) and t.data_ptr() != geo.data_ptr()]
+    if rgbw == "recompute":
+        # [r6] the recomputing rgb backward saves no hidden activation either (it recomputes them bitwise): its masks come from a forward
+        # of the stored-activation path on the same inputs
+        assert len(acts) == 0, [tuple(t.shape) for t in saved]
+        saved.clear()
+        monkeypatch.setattr(fused, "RGB_RECOMPUTE", 0)
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
+            rgb_s = fused.rgb_head(hray, geo.detach().requires_grad_(True), S, *wc)
+        monkeypatch.setattr(fused, "RGB_RECOMPUTE", 1)
+        assert torch.equal(rgb_s, rgb), "both rgb head paths share the forward kernel"
+        acts = [t for t in saved if t.shape == (N, 64) and t.data_ptr() != geo.data_ptr() and t.requires_grad is False and t.grad_fn is None][-2:]
+        del rgb_s
     if len(acts) == 2:
         # [r5] the 128-output neck's backward recomputes its hidden layer too (bitwise the forward's values) and saves none: its mask
         # comes from a forward of the unfused path on the same inputs

@@ -106,17 +106,16 @@ def test_density_mlp(hip_lib, monkeypatch, L, N, Fe, fusedw):
         _close("density_nograd", fused.density_mlp(*[v.detach() for v in t]), d_ref)
 
 
-# weight gradients: all inside the backward kernel (one row tile per step / two paired tiles per step), only the output layer's
+# weight gradients: all inside the backward kernel, only the output layer's
 # inside it (round 3: layers 0 / 1 streamed), or every one as a separate pass
-# [r6] "all": additionally with the hidden activations RECOMPUTED in that kernel (the default); "all_stored": read back from the forward's stores
-@pytest.mark.parametrize("fusedw", ["all", "all_a2", "all_stored", "all_paired", "w2_only", False])
+# [r6] "all" / "all_a2": with the hidden activations (both / a2 only) RECOMPUTED in that kernel; "all_stored": read back from the forward's stores (the default)
+@pytest.mark.parametrize("fusedw", ["all", "all_a2", "all_stored", "w2_only", False])
 @pytest.mark.parametrize("R,S,Kh,NG,ld", [(16, 64, 49, 64, 64), (5, 16, 49, 64, 128), (3, 128, 33, 64, 64), (1, 16, 49, 64, 64), (5000, 16, 49, 64, 64),
                                           (1031, 32, 49, 64, 64), (2, 96, 17, 64, 192)])
 def test_rgb_head(hip_lib, monkeypatch, R, S, Kh, NG, ld, fusedw):
     from emernerf_amd import fused
     monkeypatch.setattr(fused, "FUSED_WGRAD", bool(fusedw))
-    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", fusedw in ("all", "all_a2", "all_stored", "all_paired"))
-    monkeypatch.setattr(fused, "RGB_WGRAD_PAIR", fusedw == "all_paired")
+    monkeypatch.setattr(fused, "FUSED_RGB_WGRAD", fusedw in ("all", "all_a2", "all_stored"))
     monkeypatch.setattr(fused, "RGB_RECOMPUTE", {"all": 1, "all_a2": 2}.get(fusedw, 0))
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(R * S + Kh)

@@ -1139,36 +1139,3 @@ def test_blend_accumulate_wide_matches_the_reference_expression(hip_lib, R, S, C
         assert err <= 5e-6 * scale, f"d {name}: {err:.3e} of {scale:.3e}"
 
 
-@pytest.mark.parametrize("R,S,unbounded", [(300, 128, True), (129, 64, True), (64, 48, False)])
-def test_fused_proposal_round_equals_the_separate_kernels(hip_lib, monkeypatch, R, S, unbounded):
-    """[r4] emer_prop_density_fwd (positions + contraction + L8/F1 encode + 8 -> 64 -> 1 MLP + exp, one launch, no autograd) against
-    emer_ray_points -> emer_hashgrid_fwd -> emer_neck_fwd: bitwise the same densities; rays that leave the box, both proposal grids of
-    the default config."""
-    from emernerf_amd import radiance_field as rf
-    dev = _dev()
-    g = torch.Generator().manual_seed(51)
-    for max_res in (512, 2048):
-        net = rf.build_density_field(n_levels=8, base_resolution=16, max_resolution=max_res, log2_hashmap_size=20, n_features_per_level=1,
-                                     unbounded=unbounded).to(dev)
-        with torch.no_grad():
-            net.xyz_encoder.tcnn_encoding.params.copy_((torch.rand(net.xyz_encoder.tcnn_encoding.params.shape, generator=g) - 0.5).to(dev))
-            for lin in (net.base_mlp[0], net.base_mlp[2]):
-                lin.weight.copy_((torch.randn(lin.weight.shape, generator=g) * 0.3).to(dev))
-                lin.bias.copy_((torch.randn(lin.bias.shape, generator=g) * 0.1).to(dev))
-        o = (torch.rand(R, 3, generator=g) * 0.6 - 0.3).to(dev)
-        d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
-        ts = torch.sort(torch.rand(R, S + 1, generator=g) * (30.0 if unbounded else 2.5), dim=-1).values.to(dev)
-        t0, t1 = ts[:, :-1].contiguous(), ts[:, 1:].contiguous()
-        with torch.no_grad():
-            monkeypatch.setattr(rf, "FUSE_PROP_DENSITY", False)
-            assert net.density_from_rays(o, d, t0, t1) is None   # (the default: off, see radiance_field.FUSE_PROP_DENSITY)
-            monkeypatch.setattr(rf, "FUSE_PROP_DENSITY", True)
-            fused = net.density_from_rays(o, d, t0, t1)
-            assert fused is not None, "the default proposal networks must be covered by the fused kernel"
-            from emernerf_amd import ops
-            normed, _ = ops.ray_points(o, d, t0, t1, net.aabb, net.unbounded)
-            ref = net.density_from_normed(normed)
-        assert net.density_from_rays(o, d, t0, t1) is None, "with autograd on the separate, differentiable kernels run"
-        assert fused.shape == ref.shape
-        # positions, encoding and MLP follow the separate kernels instruction for instruction (same matrix-core order): bitwise
-        assert torch.equal(fused, ref), f"max relative density difference {((fused - ref).abs() / ref.abs().clamp_min(1e-30)).max().item():.3e}"

@@ -163,9 +163,12 @@ def _capture_failure_worker(rank, port, out_dir):
             raise RuntimeError("injected capture failure")
         tr._graphed_forward_backward = broken
     data, jit, noise = _data(rank * R_HALF, (rank + 1) * R_HALF, "pixel")
+    import itertools
+    draws = itertools.cycle(jit)   # (the capturing rank runs the forward several times -- warm-up, capture, replay, fallback: three draws each)
+    tr.estimator.jitter_fn = lambda n, d: next(draws)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        _step(tr, data, jit, noise, "pixel")
+        tr.train_step(data)
     assert tr.use_graph is False, f"rank {rank} kept replaying after a peer's capture failed"
     assert any("capture failed" in str(x.message) for x in w), [str(x.message) for x in w]
     torch.cuda.synchronize()
