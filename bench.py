@@ -253,6 +253,10 @@ def measure_config(kind: str, rays: int, samples: int, dev, steps: int, warmup: 
             "ms_per_step": {"fwd": sum(f4) / 1e3 / steps, "bwd": sum(b4) / 1e3 / steps, "bwd_input": sum(i4) / 1e3 / steps},
             "sample_evaluations_per_step": evals * N, "algorithmic_bytes_per_sample": {"fwd": fb4, "bwd": bb4},
             "frac_fwd": fb4 * evals * N / (sum(f4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS,
+            # [r6] the evaluations whose positions need a gradient also STORE d out / d x (F * D * 4 bytes per sample and level): flow
+            # configs differentiate 2 N rows of the 3 N-row dynamic evaluation and the 2 N rows of the flow table at the warped points
+            "frac_fwd_incl_jacobian": (fb4 * evals * N + (4 * N * L4 * F4 * D4 * 4 if kind in ("flow", "feature") and i4 else 0))
+            / (sum(f4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS,
             "frac_bwd": bb4 * evals * N / (sum(b4) * 1e-6 / steps) / 1e9 / HBM_PEAK_GBPS}
     # [r6] the static table these configs run (default_config.yaml:62-69: D3/L10/F4/T2^20), priced like the headline's main grid
     c3 = tr.cfg.xyz_encoder

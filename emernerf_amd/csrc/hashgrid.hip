@@ -526,6 +526,21 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             if (masks) set_row<Q>(mask, slice_of(plan, level, idx));  // by-product for the owner-computes backward
         }
         if constexpr (JAC) {
+            // [r6] The encoding leaves FIRST.  hipcc used to schedule the Jacobian (and its four 16-byte stores) ahead of the accumulation
+            // of the encoding; on gfx950 stores count in vmcnt like loads, so the waits that hand the gathered corners to the accumulation
+            // (vmcnt 15 .. 0 in its model) then also waited for the Jacobian stores' acknowledgements -- a memory round trip in the
+            // middle of every wave.  The barrier pins: accumulate, store the encoding, then the Jacobian (same-session A/B,
+            // profiles/r06_xyzt_jac.txt: 448 -> 440 us at the 2048-ray shard, 1822 -> 1757 us at 8192 rays; results bitwise unchanged).
+            {
+                float *o = out + n * sn + (int64_t)level * sl;
+                if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
+                else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
+                else {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) o[f] = acc[f];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (n >= jac_row0) {
                 // J[f][gd] = scale * sum over the corners m with bit gd clear of prod_{d != gd} t_d(m) * (v[m | gd] - v[m])[f]:
                 // the same differences, weights and corner order as hashgrid_bwd_input_kernel forms after projecting on dOut
@@ -562,12 +577,14 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
             }
         }
         }
+        if constexpr (!JAC) {
         float *o = out + n * sn + (int64_t)level * sl;
         if (F == 2) { *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1 < F ? 1 : 0]); }
         else if (F == 4) { *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1 < F ? 1 : 0], acc[2 < F ? 2 : 0], acc[3 < F ? 3 : 0]); }
         else {
 #pragma unroll
             for (int f = 0; f < F; ++f) o[f] = acc[f];
+        }
         }
     }
     if (masks)  // the whole workgroup takes part (tail lanes carry an empty mask)

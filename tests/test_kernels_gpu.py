@@ -77,6 +77,39 @@ def test_hashgrid_fwd(hip_lib, oracle, name, n):
     assert torch.equal(back, lm)
 
 
+@pytest.mark.parametrize("name", ["cfg2_static", "prop0", "default_static", "flow_xyzt", "tiny_2d"])
+@pytest.mark.parametrize("half", [False, True])
+def test_hashgrid_fwd_is_independent_of_the_launch_size(hip_lib, oracle, name, half):
+    """The encoding of 40 000 samples in one launch is BITWISE the concatenation of five 8 000-sample launches (the XCD-aware level map
+    and the chunking only move work), its slice bitmaps drive the owner-computes backward to the oracle's table gradient, coordinates
+    outside [0, 1] wrap as tcnn's do.  (Written in round 6 for the LDS-staged coarse levels, profiles/r06_fwd_lds_stage.txt: that path
+    was bit-identical and lost the A/B; the test stays as a consistency check of the forward.)"""
+    from emernerf_amd import ops
+    meta, desc = _mk(oracle, name)
+    n = 40000
+    x, p = _inputs(meta, n, 7)
+    x[5] = torch.tensor([1.3, -0.2, 0.5, 0.1][: meta.n_dims])   # outside [0, 1]: the dense index wraps (tcnn does not clamp)
+    if half:
+        p = p.half()
+    dev = _dev()
+    xd, pd = x.to(dev), p.to(dev)
+    big, masks = ops.hashgrid_fwd_raw(desc, xd, pd, level_major=True, want_masks=True)
+    parts = [ops.hashgrid_fwd_raw(desc, xd[i:i + 8000].contiguous(), pd, level_major=True) for i in range(0, n, 8000)]
+    assert torch.equal(big, torch.cat(parts, dim=1)), "the encoding depends on how the samples are cut into launches"
+    ref = oracle.hashgrid_fwd(meta, x, p.float())
+    np.testing.assert_allclose(big.permute(1, 0, 2).reshape(n, -1).cpu().numpy(), ref, rtol=0, atol=2e-6)
+    if not half and ops.sliced_supported(desc):
+        dout = torch.randn(meta.n_levels, n, meta.n_features, generator=torch.Generator().manual_seed(3)).to(dev)
+        import ctypes
+        from emernerf_amd import _lib
+        g_big = torch.empty(meta.n_params, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.call("emer_hashgrid_bwd_params_sliced", ctypes.byref(desc), ops._ptr(xd), ops._ptr(dout), meta.n_features, n * meta.n_features,
+                      ops._ptr(masks), ops._ptr(g_big), n, ops._stream(xd))
+        ref_g = oracle.hashgrid_bwd_params(meta, x, dout.permute(1, 0, 2).reshape(n, -1).cpu())
+        np.testing.assert_allclose(g_big.cpu().numpy(), ref_g, rtol=0, atol=2e-5 * float(np.abs(ref_g).max()))
+
+
 @pytest.mark.parametrize("name", ["cfg2_static", "dynamic_xyzt", "prop0", "tiny_f8", "tiny_2d"])
 def test_hashgrid_fp16_tables(hip_lib, oracle, name):
     from emernerf_amd import ops
