@@ -455,7 +455,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         for (int f = 0; f < F; ++f) acc[f] = 0.0f;
         const bool pow2 = (li.size & (li.size - 1u)) == 0u;
         bool paired = false;
-        if constexpr (sizeof(PT) * F <= 8 && !JAC) {
+        float vv[JAC ? (1 << D) : 1][F];   // JAC: every corner's features stay live for the differences along each axis
+        // [r6] ... and for 16-byte fp32 entries (F = 4: the default static table and the xyzt tables) the pair is two 16-byte loads from ONE
+        // 32-byte sector instead of two sectors of two lines: a quarter fewer lines per hashed level -- xyzt forward 516 -> 429 us, flow
+        // table 472 -> 407 us, default static table 519 -> 503 us per million samples, dynamic step 6.18 -> 6.04 ms (same-session A/B,
+        // profiles/r06_pair16.txt).  The Jacobian forward keeps the generic loop: paired it needs 130 registers, three waves per SIMD
+        // instead of four, and loses what the pairs gain (448 vs 437 us; forced to 128 registers it spills: 575 us).
+        if constexpr ((sizeof(PT) * F <= 8 || (sizeof(PT) == 4 && F == 4)) && !JAC) {
         if (li.hashed && pow2) {  // level-uniform
             paired = true;
             // Hashed power-of-two level: the x-neighbours of a (y, z[, t]) combination are idx0 = (x ^ h) & mask and
@@ -504,7 +510,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
         }
         }
         if (!paired) {
-        float vv[JAC ? (1 << D) : 1][F];   // JAC: every corner's features stay live for the differences along each axis
 #pragma unroll
         for (uint32_t m = 0; m < (1u << D); ++m) {
             float wt = 1.0f;
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
                 for (int f = 0; f < F; ++f) vv[m][f] = v[f];
             }
             if (masks) set_row<Q>(mask, slice_of(plan, level, idx));  // by-product for the owner-computes backward
+        }
         }
         if constexpr (JAC) {
             // [r6] The encoding leaves FIRST.  hipcc used to schedule the Jacobian (and its four 16-byte stores) ahead of the accumulation
@@ -575,7 +581,6 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const emer_grid_desc 
                     for (int i = 0; i < F * D; ++i) jp[i] = J[i / D][i % D];
                 }
             }
-        }
         }
         if constexpr (!JAC) {
         float *o = out + n * sn + (int64_t)level * sl;
