@@ -940,9 +940,6 @@ __device__ __forceinline__ void drain_pair_queue(double *acc, const LevelInfo &l
     while (__ballot(match != 0u)) add_pair<D, F>(acc, gi, w, hd, go, match, local_mask);
 }
 
-// Timing-only ablation builds (tools/ab_grid.sh; results are WRONG, never in the product library): bit 0 = gathers from a
-// 16 K-sample window (L2 hits), bit 1 = gathers from a 1 K-sample window (L1 hits), bit 2 = plain LDS stores instead of
-// ds_add_f64, bit 3 = no LDS accumulation at all, bit 4 = hit -> sample mapping without the compaction look-ups.
 // chunks (of 64 hits) per register set of the software-pipelined drain: two sets are live, D + F + 1 registers per chunk
 #ifndef EMER_PIPE_K
 #define EMER_PIPE_K 2
